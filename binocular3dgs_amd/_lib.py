@@ -1,0 +1,99 @@
+"""ctypes binding of the C ABI declared in include/b3gs_raster.h.
+
+There is no fallback: if libb3gs_raster.so is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libb3gs_raster.so")
+
+ABI_VERSION = 1
+OK = 0
+ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
+             -5: "B3GS_ERR_NO_DEVICE"}
+
+c_float_p = C.c_void_p  # device pointers travel as plain integers
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class B3gsScene(C.Structure):
+    _fields_ = [("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("W", C.c_int32), ("H", C.c_int32),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("scale_modifier", C.c_float),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class B3gsDebugViews(C.Structure):
+    _fields_ = [("tiles_touched", C.c_void_p), ("depths", C.c_void_p), ("records", C.c_void_p),
+                ("point_list", C.c_void_p), ("tile_ids", C.c_void_p), ("ranges", C.c_void_p),
+                ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
+
+
+class B3gsKernelTimes(C.Structure):
+    _fields_ = [("preprocess_ms", C.c_double), ("sort_ms", C.c_double), ("render_fwd_ms", C.c_double),
+                ("render_bwd_ms", C.c_double), ("preprocess_bwd_ms", C.c_double), ("calls", C.c_int64)]
+
+
+# every symbol include/b3gs_raster.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_geometry_bytes", "b3gs_image_bytes",
+           "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
+           "b3gs_debug_views")
+
+_lib = None
+
+
+class B3gsError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise B3gsError(f"{LIB_PATH} not found: run `python -m binocular3dgs_amd.build` (hipcc, gfx950). "
+                        "There is no CPU or PyTorch fallback for the rasterizer.")
+    L = C.CDLL(LIB_PATH)
+    L.b3gs_abi_version.restype = C.c_int
+    L.b3gs_last_error.restype = C.c_char_p
+    L.b3gs_set_timing.argtypes = [C.c_void_p]
+    L.b3gs_set_timing.restype = None
+    L.b3gs_geometry_bytes.argtypes = [C.c_int32]
+    L.b3gs_geometry_bytes.restype = C.c_size_t
+    L.b3gs_image_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.b3gs_image_bytes.restype = C.c_size_t
+    L.b3gs_binning_bytes.argtypes = [C.c_int32, C.c_int64]
+    L.b3gs_binning_bytes.restype = C.c_size_t
+    L.b3gs_forward.argtypes = [C.POINTER(B3gsScene), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int32), C.c_void_p]
+    L.b3gs_forward.restype = C.c_int
+    L.b3gs_forward_capacity.argtypes = [C.POINTER(B3gsScene), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.b3gs_forward_capacity.restype = C.c_int
+    L.b3gs_backward.argtypes = [C.POINTER(B3gsScene), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]
+    L.b3gs_backward.restype = C.c_int
+    L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.b3gs_mark_visible.restype = C.c_int
+    L.b3gs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(B3gsDebugViews)]
+    L.b3gs_debug_views.restype = C.c_int
+    if L.b3gs_abi_version() != ABI_VERSION:
+        raise B3gsError(f"libb3gs_raster.so ABI {L.b3gs_abi_version()} != binding {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        msg = lib().b3gs_last_error().decode("utf-8", "replace")
+        raise B3gsError(f"{what} failed: {ERR_NAMES.get(rc, rc)}: {msg}")

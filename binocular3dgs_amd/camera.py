@@ -1,0 +1,127 @@
+"""Camera matrices exactly as the reference builds them, plus the binocular (shifted) view.
+
+Mirrors scene/cameras.py:17-83 (Camera / MiniCam attribute names: `world_view_transform`,
+`full_proj_transform`, `camera_center`, `FoVx`, `FoVy`, `image_width`, `image_height`),
+utils/graphics_utils.py:38-77 (getWorld2View2, getProjectionMatrix, fov2focal) and
+scene/__init__.py:96-115 (getShiftedCamera).  Convention: ROW-vector, i.e. the stored matrices
+are the transposes of the conventional ones: [x y z 1] @ world_view_transform = view coords.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def world_to_view(R: np.ndarray, t: np.ndarray, translate=np.array([0.0, 0.0, 0.0]), scale: float = 1.0) -> np.ndarray:
+    """utils/graphics_utils.py:38-49.  `R` is the camera-to-world rotation (stored transposed in
+    the W2C matrix), `t` the W2C translation; returns the conventional 4x4 W2C in float32."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = np.asarray(R, dtype=np.float64).transpose()
+    Rt[:3, 3] = np.asarray(t, dtype=np.float64)
+    Rt[3, 3] = 1.0
+    C2W = np.linalg.inv(Rt)
+    C2W[:3, 3] = (C2W[:3, 3] + np.asarray(translate, dtype=np.float64)) * scale
+    return np.float32(np.linalg.inv(C2W))
+
+
+def projection_matrix(znear: float, zfar: float, fovX: float, fovY: float) -> torch.Tensor:
+    """utils/graphics_utils.py:51-71 (conventional, un-transposed; float32)."""
+    tanHalfFovY = math.tan(fovY / 2)
+    tanHalfFovX = math.tan(fovX / 2)
+    top = tanHalfFovY * znear
+    bottom = -top
+    right = tanHalfFovX * znear
+    left = -right
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * znear / (right - left)
+    P[1, 1] = 2.0 * znear / (top - bottom)
+    P[0, 2] = (right + left) / (right - left)
+    P[1, 2] = (top + bottom) / (top - bottom)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def fov2focal(fov: float, pixels: int) -> float:
+    return pixels / (2 * math.tan(fov / 2))
+
+
+def focal2fov(focal: float, pixels: int) -> float:
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+class Camera:
+    """Holds what render() and the loss block read from a reference Camera (scene/cameras.py:17-70)."""
+
+    zfar = 100.0
+    znear = 0.01
+
+    def __init__(self, R, T, FoVx, FoVy, width, height, image=None, gt_alpha_mask=None, uid=0,
+                 trans=np.array([0.0, 0.0, 0.0]), scale=1.0, device="cpu"):
+        self.uid = uid
+        self.R = np.asarray(R, dtype=np.float64)
+        self.T = np.asarray(T, dtype=np.float64)
+        self.FoVx = float(FoVx)
+        self.FoVy = float(FoVy)
+        self.image_width = int(width)
+        self.image_height = int(height)
+        self.trans = np.asarray(trans, dtype=np.float64)
+        self.scale = scale
+        self.device = torch.device(device)
+        self.original_image = None if image is None else image.clamp(0.0, 1.0).to(self.device)
+        self.gt_alpha_mask = None if gt_alpha_mask is None else gt_alpha_mask.to(self.device)
+        if self.original_image is not None and self.gt_alpha_mask is not None:
+            self.original_image = self.original_image * self.gt_alpha_mask
+        wvt = torch.tensor(world_to_view(self.R, self.T, self.trans, scale)).transpose(0, 1)
+        proj = projection_matrix(self.znear, self.zfar, self.FoVx, self.FoVy).transpose(0, 1)
+        self._set(wvt, proj)
+
+    def _set(self, wvt: torch.Tensor, proj_t: torch.Tensor):
+        self.world_view_transform = wvt.contiguous().to(self.device)
+        self.projection_matrix = proj_t.contiguous().to(self.device)
+        self.full_proj_transform = (self.world_view_transform.unsqueeze(0)
+                                    .bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
+        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
+
+    def get_focal(self):
+        return fov2focal(self.FoVx, self.image_width), fov2focal(self.FoVy, self.image_height)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center",
+                  "original_image", "gt_alpha_mask"):
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.to(self.device))
+        return self
+
+    def shifted(self, trans_dist: float) -> "Camera":
+        """Binocular partner: camera centre moved by `trans_dist` along the camera's own +x axis
+        (scene/__init__.py:96-115).  The reference rebuilds a Camera through two host-side 4x4
+        inversions and a device->host copy every iteration; in row-vector form the only entry that
+        changes is world_view_transform[3, 0] -= trans_dist, which is done here in place on the
+        device (golden vectors G4 check it against the reference's construction)."""
+        cam = Camera.__new__(Camera)
+        cam.__dict__.update(self.__dict__)
+        cam.original_image = None if self.original_image is None else torch.ones_like(self.original_image)
+        cam.gt_alpha_mask = None
+        wvt = self.world_view_transform.clone()
+        wvt[3, 0] -= float(trans_dist)
+        cam._set(wvt, self.projection_matrix)
+        return cam
+
+
+def look_at_orbit(yaw_deg: float, pivot=(0.0, 0.0, 6.0)):
+    """Camera that starts at the origin looking down +z and is rotated about `pivot` by `yaw_deg`
+    around the world y axis.  Returns (R, T) in the reference's convention:
+    R = camera-to-world rotation, T = world-to-camera translation."""
+    th = math.radians(yaw_deg)
+    Ry = np.array([[math.cos(th), 0.0, math.sin(th)], [0.0, 1.0, 0.0], [-math.sin(th), 0.0, math.cos(th)]])
+    pivot = np.asarray(pivot, dtype=np.float64)
+    center = pivot + Ry @ (np.zeros(3) - pivot)
+    R_c2w = Ry
+    T = -R_c2w.T @ center
+    return R_c2w, T

@@ -1,0 +1,266 @@
+// extern "C" entry points of libb3gs_raster.so (see include/b3gs_raster.h for the contract and
+// the reference call sites each one stands behind).  Host orchestration only: carve the opaque
+// buffers, enqueue the kernels of preprocess.hip / binning.hip / render.hip on the caller's
+// stream, perform the single num_rendered read-back of the synchronous forward.
+#include "b3gs_internal.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local B3gsKernelTimes* g_timing = nullptr;
+
+int fail(int code, const char* fmt, const char* detail) {
+  snprintf(g_err, sizeof(g_err), fmt, detail);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return fail(B3GS_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+int check_scene(const B3gsScene* sc) {
+  if (!sc) return fail(B3GS_ERR_ARG, "%s", "scene is NULL");
+  if (sc->P < 0 || sc->W <= 0 || sc->H <= 0) return fail(B3GS_ERR_ARG, "%s", "bad P/W/H");
+  if (sc->D < 0 || sc->D > 3) return fail(B3GS_ERR_ARG, "%s", "SH degree must be 0..3");
+  if ((sc->shs == nullptr) == (sc->colors_precomp == nullptr))
+    return fail(B3GS_ERR_ARG, "%s", "provide exactly one of shs / colors_precomp");
+  const bool has_sr = sc->scales != nullptr && sc->rotations != nullptr;
+  if (has_sr == (sc->cov3D_precomp != nullptr))
+    return fail(B3GS_ERR_ARG, "%s", "provide exactly one of (scales, rotations) / cov3D_precomp");
+  if (sc->shs && sc->M < (sc->D + 1) * (sc->D + 1)) return fail(B3GS_ERR_ARG, "%s", "M too small for SH degree");
+  if (((sc->W + B3GS_TILE - 1) / B3GS_TILE) > 65535 || ((sc->H + B3GS_TILE - 1) / B3GS_TILE) > 65535)
+    return fail(B3GS_ERR_ARG, "%s", "image too large for the packed tile rect");
+  if (!sc->background || !sc->viewmatrix || !sc->projmatrix || !sc->campos || (sc->P > 0 && (!sc->means3D || !sc->opacities)))
+    return fail(B3GS_ERR_ARG, "%s", "NULL required tensor");
+  return B3GS_OK;
+}
+
+// optional per-stage timing (bench only): events bracket each stage on the caller's stream
+struct StageTimer {
+  hipStream_t s;
+  hipEvent_t ev[8];
+  int n = 0;
+  bool on;
+  explicit StageTimer(hipStream_t st) : s(st), on(g_timing != nullptr) {
+    if (on) for (auto& e : ev) (void)hipEventCreate(&e);
+  }
+  void mark() {
+    if (on && n < 8) (void)hipEventRecord(ev[n++], s);
+  }
+  float ms(int a, int b) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, ev[a], ev[b]);
+    return t;
+  }
+  ~StageTimer() {
+    if (on) for (auto& e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+int debug_sync(const B3gsScene* sc, hipStream_t s, const char* what) {
+  if (!sc->debug) return B3GS_OK;
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "after %s: %s", what, hipGetErrorString(e));
+    return B3GS_ERR_HIP;
+  }
+  return B3GS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int b3gs_abi_version(void) { return B3GS_ABI_VERSION; }
+const char* b3gs_last_error(void) { return g_err; }
+void b3gs_set_timing(B3gsKernelTimes* sink) { g_timing = sink; }
+
+size_t b3gs_geometry_bytes(int32_t P) { return b3gs_geom_view(nullptr, P, nullptr); }
+size_t b3gs_image_bytes(int32_t W, int32_t H) { return b3gs_img_view(nullptr, W, H, nullptr); }
+size_t b3gs_binning_bytes(int32_t P, int64_t num_rendered) { return b3gs_bin_view(nullptr, P, num_rendered, nullptr); }
+
+int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geometry_user, b3gs_alloc_fn binning_alloc,
+                 void* binning_user, b3gs_alloc_fn image_alloc, void* image_user, float* out_color, float* out_depth,
+                 float* out_alpha, int32_t* radii, int32_t* host_num_rendered, b3gs_stream_t stream) {
+  int rc = check_scene(sc);
+  if (rc) return rc;
+  if (!geometry_alloc || !binning_alloc || !image_alloc || !out_color || !out_depth || !out_alpha ||
+      (sc->P > 0 && !radii))
+    return fail(B3GS_ERR_ARG, "%s", "NULL output / allocator");
+  hipStream_t s = (hipStream_t)stream;
+
+  char* gbuf = geometry_alloc(geometry_user, b3gs_geometry_bytes(sc->P));
+  char* ibuf = image_alloc(image_user, b3gs_image_bytes(sc->W, sc->H));
+  if (!gbuf || !ibuf) return fail(B3GS_ERR_ALLOC, "%s", "geometry/image allocation failed");
+  GeomView g;
+  ImgView im;
+  b3gs_geom_view(gbuf, sc->P, &g);
+  b3gs_img_view(ibuf, sc->W, sc->H, &im);
+
+  StageTimer tm(s);
+  tm.mark();
+  b3gs_launch_preprocess(*sc, g, radii, s);
+  if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
+  tm.mark();
+  b3gs_launch_depth_sort_and_scan(sc->P, g, s);
+  if ((rc = debug_sync(sc, s, "depth sort + scan"))) return rc;
+
+  // the one blocking read-back of the forward: N sizes the binning buffer
+  uint32_t hdr[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(hdr, g.header, sizeof(hdr), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int64_t N = (int64_t)hdr[0];
+  if (host_num_rendered) *host_num_rendered = (int32_t)N;
+  HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
+
+  char* bbuf = binning_alloc(binning_user, b3gs_binning_bytes(sc->P, N));
+  if (!bbuf) return fail(B3GS_ERR_ALLOC, "%s", "binning allocation failed");
+  BinView b;
+  b3gs_bin_view(bbuf, sc->P, N, &b);
+
+  b3gs_launch_binning(sc->P, sc->W, sc->H, N, g, b, im, s);
+  if ((rc = debug_sync(sc, s, "binning"))) return rc;
+  tm.mark();
+  b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
+  if ((rc = debug_sync(sc, s, "render forward"))) return rc;
+  tm.mark();
+  if (tm.on) {
+    HIP_TRY(hipStreamSynchronize(s));
+    g_timing->preprocess_ms += tm.ms(0, 1);
+    g_timing->sort_ms += tm.ms(1, 2);
+    g_timing->render_fwd_ms += tm.ms(2, 3);
+    g_timing->calls++;
+  }
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, int64_t binning_capacity, char* image,
+                          float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                          int32_t* device_num_rendered, b3gs_stream_t stream) {
+  int rc = check_scene(sc);
+  if (rc) return rc;
+  if (!geometry || !binning || !image || !out_color || !out_depth || !out_alpha || (sc->P > 0 && !radii) ||
+      binning_capacity <= 0 || binning_capacity > 0xFFFFFFFFll)
+    return fail(B3GS_ERR_ARG, "%s", "NULL buffer or bad capacity");
+  hipStream_t s = (hipStream_t)stream;
+  GeomView g;
+  ImgView im;
+  BinView b;
+  b3gs_geom_view(geometry, sc->P, &g);
+  b3gs_img_view(image, sc->W, sc->H, &im);
+  b3gs_bin_view(binning, sc->P, binning_capacity, &b);
+  StageTimer tm(s);
+  tm.mark();
+  b3gs_launch_preprocess(*sc, g, radii, s);
+  tm.mark();
+  b3gs_launch_depth_sort_and_scan(sc->P, g, s);
+  HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
+  if (device_num_rendered)
+    HIP_TRY(hipMemcpyAsync(device_num_rendered, g.header, 4, hipMemcpyDeviceToDevice, s));
+  // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
+  // list, which the caller detects from *device_num_rendered > capacity and repeats
+  b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
+  tm.mark();
+  b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
+  tm.mark();
+  if (tm.on) {
+    HIP_TRY(hipStreamSynchronize(s));
+    g_timing->preprocess_ms += tm.ms(0, 1);
+    g_timing->sort_ms += tm.ms(1, 2);
+    g_timing->render_fwd_ms += tm.ms(2, 3);
+    g_timing->calls++;
+  }
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radii, const char* geometry,
+                  const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
+                  const float* dL_dalpha, float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                  float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
+                  b3gs_stream_t stream) {
+  int rc = check_scene(sc);
+  if (rc) return rc;
+  if (sc->P == 0) return B3GS_OK;
+  if (!radii || !geometry || !image || !dL_dcolor || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D ||
+      !dL_dcov3D)
+    return fail(B3GS_ERR_ARG, "%s", "NULL required tensor in backward");
+  if (sc->shs && !dL_dsh) return fail(B3GS_ERR_ARG, "%s", "dL_dsh required when shs given");
+  if (sc->scales && (!dL_dscales || !dL_drotations)) return fail(B3GS_ERR_ARG, "%s", "dL_dscales/dL_drotations required");
+  if (num_rendered != 0 && !binning) return fail(B3GS_ERR_ARG, "%s", "binning buffer is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  GeomView g;
+  ImgView im;
+  BinView b;
+  b3gs_geom_view(const_cast<char*>(geometry), sc->P, &g);
+  b3gs_img_view(const_cast<char*>(image), sc->W, sc->H, &im);
+  // the binning views only depend on the capacity through the position of hist, which the
+  // backward never touches: key/val start at fixed offsets for a given element count
+  b3gs_bin_view(const_cast<char*>(binning), sc->P, num_rendered < 0 ? 1 : num_rendered, &b);
+
+  const size_t P = (size_t)sc->P;
+  StageTimer tm(s);
+  tm.mark();
+  // accumulation targets of the blend backward (dL_dcov3D doubles as conic/depth scratch)
+  HIP_TRY(hipMemsetAsync(dL_dmeans2D, 0, P * 3 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(dL_dcolors, 0, P * 3 * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
+  HIP_TRY(hipMemsetAsync(dL_dcov3D, 0, P * 6 * sizeof(float), s));
+  if (num_rendered != 0)
+    b3gs_launch_render_backward(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
+                                dL_dcov3D, s);
+  if ((rc = debug_sync(sc, s, "render backward"))) return rc;
+  tm.mark();
+  b3gs_launch_preprocess_backward(*sc, g, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                                  dL_dscales, dL_drotations, s);
+  if ((rc = debug_sync(sc, s, "preprocess backward"))) return rc;
+  tm.mark();
+  if (tm.on) {
+    HIP_TRY(hipStreamSynchronize(s));
+    g_timing->render_bwd_ms += tm.ms(0, 1);
+    g_timing->preprocess_bwd_ms += tm.ms(1, 2);
+  }
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, b3gs_stream_t stream) {
+  (void)projmatrix;
+  if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(B3GS_ERR_ARG, "%s", "bad arguments");
+  b3gs_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry, const char* binning,
+                     const char* image, B3gsDebugViews* out) {
+  if (!out || !geometry || !image) return fail(B3GS_ERR_ARG, "%s", "NULL argument");
+  GeomView g;
+  ImgView im;
+  BinView b;
+  b3gs_geom_view(const_cast<char*>(geometry), P, &g);
+  b3gs_img_view(const_cast<char*>(image), W, H, &im);
+  memset(out, 0, sizeof(*out));
+  out->tiles_touched = g.tiles_touched;
+  out->depths = reinterpret_cast<const float*>(g.depth_key);
+  out->records = reinterpret_cast<const float*>(g.rec);
+  if (binning) {
+    b3gs_bin_view(const_cast<char*>(binning), P, num_rendered, &b);
+    out->point_list = b.val[0];
+    out->tile_ids = b.key[0];
+  }
+  out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
+  out->final_T = im.final_T;
+  out->n_contrib = im.n_contrib;
+  return B3GS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP translation units of libb3gs_raster.so.
+// gfx950 / wave64 only: there is deliberately no other code path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/b3gs_raster.h"
+
+#define B3GS_WAVE 64
+#define B3GS_NEAR 0.2f
+#define B3GS_ALPHA_MIN (1.0f / 255.0f)
+#define B3GS_ALPHA_MAX 0.99f
+#define B3GS_T_EPS 0.0001f
+#define B3GS_REC_FLOATS 16 /* one 64-byte line per Gaussian */
+
+// ---- layout of the three opaque buffers --------------------------------------------------
+// Every sub-array starts on a 256-byte boundary.  All sizes are functions of (P), (W,H), (P,N)
+// only, so forward and backward carve identical views out of the caller's bytes.
+
+struct GeomView {       // sized by P
+  uint32_t* header;     // [64]  header[0] = N (tile instances), header[1] = V (visible)
+  float4* rec;          // [P*4] render record: x,y,cxx,cxy | cyy,op,r,g | b,depth,ext_x,ext_y | spare
+  uint32_t* depth_key;  // [P]   float bits of view z, 0xFFFFFFFF when culled
+  uint32_t* tiles_touched;  // [P]
+  uint2* rect;          // [P]   packed u16 (x0 | y0<<16, x1 | y1<<16)
+  uint32_t* clamped;    // [P]   bit c set: SH colour channel c clamped at 0
+  uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
+  uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
+  uint32_t* soffs;      // [P]   inclusive scan of tiles_touched in depth order
+  uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
+  uint32_t* scan_tmp;   // [4096] block sums for scans
+};
+
+struct BinView {        // sized by N (and P for the histogram)
+  uint32_t* key[2];     // [N] tile id ping/pong
+  uint32_t* val[2];     // [N] Gaussian index ping/pong
+  uint32_t* hist;       // 256 * nblk(N)
+};
+
+struct ImgView {        // sized by W*H
+  uint32_t* header;     // [64]  header[0] = N used by the forward that filled this buffer
+  float* final_T;       // [H*W]
+  uint32_t* n_contrib;  // [H*W]
+  uint2* ranges;        // [tiles]
+};
+
+#define B3GS_SORT_ITEMS 16                       /* keys per thread in a radix tile */
+#define B3GS_SORT_THREADS 256
+#define B3GS_SORT_TILE (B3GS_SORT_ITEMS * B3GS_SORT_THREADS) /* 4096 keys per workgroup */
+
+static inline size_t b3gs_align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline uint32_t b3gs_sort_blocks(int64_t n) { return (uint32_t)((n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE); }
+
+// carve: if base == nullptr only the size is computed
+template <typename T>
+static inline T* b3gs_carve(char*& cur, size_t count) {
+  T* p = reinterpret_cast<T*>(cur);
+  cur += b3gs_align256(count * sizeof(T));
+  return p;
+}
+
+static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
+  char* cur = base;
+  size_t p = (size_t)(P > 0 ? P : 1);
+  GeomView t;
+  t.header = b3gs_carve<uint32_t>(cur, 64);
+  t.rec = b3gs_carve<float4>(cur, p * 4);
+  t.depth_key = b3gs_carve<uint32_t>(cur, p);
+  t.tiles_touched = b3gs_carve<uint32_t>(cur, p);
+  t.rect = b3gs_carve<uint2>(cur, p);
+  t.clamped = b3gs_carve<uint32_t>(cur, p);
+  for (int i = 0; i < 2; i++) t.skey[i] = b3gs_carve<uint32_t>(cur, p);
+  for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
+  t.soffs = b3gs_carve<uint32_t>(cur, p);
+  t.hist = b3gs_carve<uint32_t>(cur, (size_t)256 * (b3gs_sort_blocks((int64_t)p) + 1));
+  t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
+  if (v) *v = t;
+  return (size_t)(cur - base);
+}
+
+static inline size_t b3gs_bin_view(char* base, int32_t P, int64_t N, BinView* v) {
+  char* cur = base;
+  size_t n = (size_t)(N > 0 ? N : 1);
+  BinView t;
+  // val[0] (the final point_list) sits at offset 0 so that consumers which do not know the
+  // capacity the buffer was carved with (backward of the sync-free forward) still find it
+  t.val[0] = b3gs_carve<uint32_t>(cur, n);
+  t.key[0] = b3gs_carve<uint32_t>(cur, n);
+  t.val[1] = b3gs_carve<uint32_t>(cur, n);
+  t.key[1] = b3gs_carve<uint32_t>(cur, n);
+  t.hist = b3gs_carve<uint32_t>(cur, (size_t)256 * (b3gs_sort_blocks((int64_t)n) + 1));
+  (void)P;
+  if (v) *v = t;
+  return (size_t)(cur - base);
+}
+
+static inline size_t b3gs_img_view(char* base, int32_t W, int32_t H, ImgView* v) {
+  char* cur = base;
+  size_t hw = (size_t)W * (size_t)H;
+  size_t tiles = (size_t)((W + B3GS_TILE - 1) / B3GS_TILE) * (size_t)((H + B3GS_TILE - 1) / B3GS_TILE);
+  ImgView t;
+  t.header = b3gs_carve<uint32_t>(cur, 64);
+  t.final_T = b3gs_carve<float>(cur, hw ? hw : 1);
+  t.n_contrib = b3gs_carve<uint32_t>(cur, hw ? hw : 1);
+  t.ranges = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
+  if (v) *v = t;
+  return (size_t)(cur - base);
+}
+
+// ---- launchers implemented in the individual .hip files -----------------------------------
+// (all enqueue on `s`, none synchronise)
+
+void b3gs_launch_preprocess(const B3gsScene& sc, const GeomView& g, int32_t* radii, hipStream_t s);
+void b3gs_launch_preprocess_backward(const B3gsScene& sc, const GeomView& g, const int32_t* radii,
+                                     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+                                     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+                                     float* dL_drotations, hipStream_t s);
+void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                              hipStream_t s);
+
+// depth sort of all P Gaussians (culled ones sink to the end), scan of tiles_touched in depth
+// order; leaves N in g.header[0] and V in g.header[1].  Result: sorted indices in g.sval[0].
+void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, hipStream_t s);
+// emit (tile, idx) instances in depth order, stable sort by tile id, tile ranges.
+// `n_bound` = number of instances the launch must cover (host-known N, or the capacity when N
+// lives only on the device; kernels clamp to the device-side N in g.header[0]).
+// Final lists end up in b.key[0] / b.val[0].
+void b3gs_launch_binning(int32_t P, int32_t W, int32_t H, int64_t n_bound, const GeomView& g, const BinView& b,
+                         const ImgView& im, hipStream_t s);
+
+void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
+                                float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
+void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
+                                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D,
+                                 hipStream_t s);

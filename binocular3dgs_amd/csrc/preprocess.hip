@@ -1,0 +1,466 @@
+// Per-Gaussian stages of the rasterizer: projection / culling / EWA splat / SH colour (forward)
+// and the chain rule back to means, scales, rotations and SH coefficients (backward).
+//
+// Replaces the `preprocess` stages of the un-vendored `diff_gaussian_rasterization` extension
+// the reference calls at gaussian_renderer/__init__.py:85-93; the in-tree Python duplicates of
+// two sub-steps pin the arithmetic: SH basis utils/sh_utils.py:57-112, covariance
+// utils/general_utils.py:78-110 + scene/gaussian_model.py:27-31.
+//
+// HBM-bound streaming kernels: one lane per Gaussian, consecutive lanes read consecutive
+// Gaussians (the [P,3]/[P,4]/[P,M,3] rows of a wave are one contiguous span), every visible
+// Gaussian leaves exactly one 64-byte render record.  Compiled with -ffp-contract=off: every
+// expression that feeds an integer decision (cull, radius, tile rect) is evaluated with the
+// same IEEE operations, in the same order, as oracle/tile_ref.c, so those integers are bit-exact.
+#include "b3gs_internal.h"
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                               -1.0925484305920792f, 0.5462742152960396f};
+__constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                               0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                               -0.5900435899266435f};
+
+struct Mat16 {
+  float m[16];
+};
+
+__device__ __forceinline__ Mat16 load_mat(const float* __restrict__ p) {
+  Mat16 r;
+#pragma unroll
+  for (int i = 0; i < 16; i++) r.m[i] = p[i];  // wave-uniform -> scalar loads
+  return r;
+}
+
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float R[9]) {
+  R[0] = 1.f - 2.f * (y * y + z * z);
+  R[1] = 2.f * (x * y - r * z);
+  R[2] = 2.f * (x * z + r * y);
+  R[3] = 2.f * (x * y + r * z);
+  R[4] = 1.f - 2.f * (x * x + z * z);
+  R[5] = 2.f * (y * z - r * x);
+  R[6] = 2.f * (x * z - r * y);
+  R[7] = 2.f * (y * z + r * x);
+  R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_of(const B3gsScene& sc, int i, float c6[6]) {
+  if (sc.cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = sc.cov3D_precomp[6 * (size_t)i + k];
+    return;
+  }
+  const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
+  const float* s = sc.scales + 3 * (size_t)i;
+  float R[9], L[9];
+  quat_to_R(q.x, q.y, q.z, q.w, R);
+  float sx = sc.scale_modifier * s[0], sy = sc.scale_modifier * s[1], sz = sc.scale_modifier * s[2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    L[3 * r + 0] = R[3 * r + 0] * sx;
+    L[3 * r + 1] = R[3 * r + 1] * sy;
+    L[3 * r + 2] = R[3 * r + 2] * sz;
+  }
+#define LL(a, b) ((L[3 * a] * L[3 * b] + L[3 * a + 1] * L[3 * b + 1]) + L[3 * a + 2] * L[3 * b + 2])
+  c6[0] = LL(0, 0);
+  c6[1] = LL(0, 1);
+  c6[2] = LL(0, 2);
+  c6[3] = LL(1, 1);
+  c6[4] = LL(1, 2);
+  c6[5] = LL(2, 2);
+#undef LL
+}
+
+// EWA: the 2x3 matrix T = J * Wr (third row of J is zero) and cov2D = T Sigma T^T
+struct Ewa {
+  float T0[3], T1[3];
+  float a, b, c;        // cov2D without the low-pass term
+  float tx, ty, tz;     // clamped view-space position
+  float xmul, ymul;     // 0 when the corresponding axis was clamped
+};
+
+__device__ __forceinline__ Ewa ewa_project(const float pv[3], float fx, float fy, float tanfovx, float tanfovy,
+                                           const float c6[6], const Mat16& vm) {
+  Ewa e;
+  float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+  float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+  e.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  e.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  e.tx = fminf(limx, fmaxf(-limx, txtz)) * pv[2];
+  e.ty = fminf(limy, fmaxf(-limy, tytz)) * pv[2];
+  e.tz = pv[2];
+  float J00 = fx / e.tz, J02 = -(fx * e.tx) / (e.tz * e.tz);
+  float J11 = fy / e.tz, J12 = -(fy * e.ty) / (e.tz * e.tz);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    e.T0[j] = J00 * vm.m[4 * j + 0] + J02 * vm.m[4 * j + 2];
+    e.T1[j] = J11 * vm.m[4 * j + 1] + J12 * vm.m[4 * j + 2];
+  }
+  float S00 = c6[0], S01 = c6[1], S02 = c6[2], S11 = c6[3], S12 = c6[4], S22 = c6[5];
+  float v0x = (S00 * e.T0[0] + S01 * e.T0[1]) + S02 * e.T0[2];
+  float v0y = (S01 * e.T0[0] + S11 * e.T0[1]) + S12 * e.T0[2];
+  float v0z = (S02 * e.T0[0] + S12 * e.T0[1]) + S22 * e.T0[2];
+  float v1x = (S00 * e.T1[0] + S01 * e.T1[1]) + S02 * e.T1[2];
+  float v1y = (S01 * e.T1[0] + S11 * e.T1[1]) + S12 * e.T1[2];
+  float v1z = (S02 * e.T1[0] + S12 * e.T1[1]) + S22 * e.T1[2];
+  e.a = (e.T0[0] * v0x + e.T0[1] * v0y) + e.T0[2] * v0z;
+  e.b = (e.T0[0] * v1x + e.T0[1] * v1y) + e.T0[2] * v1z;
+  e.c = (e.T1[0] * v1x + e.T1[1] * v1y) + e.T1[2] * v1z;
+  return e;
+}
+
+__device__ __forceinline__ int clampi_from_float(float v, int hi) {
+  return (int)fminf(fmaxf(v, 0.0f), (float)hi);
+}
+
+// SH -> RGB for one channel; sh points at coefficient 0 of this Gaussian, stride 3 floats
+__device__ __forceinline__ float sh_eval(int deg, const float* __restrict__ sh, int ch, float x, float y, float z) {
+#define SH(k) sh[3 * (k) + ch]
+  float r = SH_C0 * SH(0);
+  if (deg > 0) {
+    r = ((r - SH_C1 * y * SH(1)) + SH_C1 * z * SH(2)) - SH_C1 * x * SH(3);
+    if (deg > 1) {
+      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      r = ((((r + SH_C2[0] * xy * SH(4)) + SH_C2[1] * yz * SH(5)) + SH_C2[2] * (2.f * zz - xx - yy) * SH(6)) +
+           SH_C2[3] * xz * SH(7)) +
+          SH_C2[4] * (xx - yy) * SH(8);
+      if (deg > 2) {
+        r = ((((((r + SH_C3[0] * y * (3.f * xx - yy) * SH(9)) + SH_C3[1] * xy * z * SH(10)) +
+                SH_C3[2] * y * (4.f * zz - xx - yy) * SH(11)) +
+               SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * SH(12)) +
+              SH_C3[4] * x * (4.f * zz - xx - yy) * SH(13)) +
+             SH_C3[5] * z * (xx - yy) * SH(14)) +
+            SH_C3[6] * x * (xx - 3.f * yy) * SH(15);
+      }
+    }
+  }
+#undef SH
+  return r;
+}
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomView g, int32_t* __restrict__ radii) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc.P) return;
+  const Mat16 vm = load_mat(sc.viewmatrix);
+  const Mat16 pm = load_mat(sc.projmatrix);
+
+  int32_t radius_out = 0;
+  uint32_t touched = 0, dkey = 0xFFFFFFFFu, clamp_bits = 0;
+  uint2 rect = make_uint2(0, 0);
+
+  const float px3 = sc.means3D[3 * (size_t)i], py3 = sc.means3D[3 * (size_t)i + 1], pz3 = sc.means3D[3 * (size_t)i + 2];
+  float pv[3];
+  pv[0] = ((vm.m[0] * px3 + vm.m[4] * py3) + vm.m[8] * pz3) + vm.m[12];
+  pv[1] = ((vm.m[1] * px3 + vm.m[5] * py3) + vm.m[9] * pz3) + vm.m[13];
+  pv[2] = ((vm.m[2] * px3 + vm.m[6] * py3) + vm.m[10] * pz3) + vm.m[14];
+
+  if (sc.prefiltered || !(pv[2] <= B3GS_NEAR)) {  // same predicate form as the oracle (NaN passes)
+    float hx = ((pm.m[0] * px3 + pm.m[4] * py3) + pm.m[8] * pz3) + pm.m[12];
+    float hy = ((pm.m[1] * px3 + pm.m[5] * py3) + pm.m[9] * pz3) + pm.m[13];
+    float hw = ((pm.m[3] * px3 + pm.m[7] * py3) + pm.m[11] * pz3) + pm.m[15];
+    float pw = 1.0f / (hw + 0.0000001f);
+    float ppx = hx * pw, ppy = hy * pw;
+
+    float c6[6];
+    cov3d_of(sc, i, c6);
+    const float fx = (float)sc.W / (2.0f * sc.tan_fovx), fy = (float)sc.H / (2.0f * sc.tan_fovy);
+    Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
+    float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
+    float det = a * c - b * b;
+    if (det != 0.0f) {
+      float det_inv = 1.0f / det;
+      float cxx = c * det_inv, cxy = -b * det_inv, cyy = a * det_inv;
+      float mid = 0.5f * (a + c);
+      float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+      float l1 = mid + disc, l2 = mid - disc;
+      float rad_f = ceilf(3.0f * sqrtf(fmaxf(l1, l2)));
+      float mx = ((ppx + 1.0f) * (float)sc.W - 1.0f) * 0.5f;
+      float my = ((ppy + 1.0f) * (float)sc.H - 1.0f) * 0.5f;
+      const int gx = (sc.W + B3GS_TILE - 1) / B3GS_TILE, gy = (sc.H + B3GS_TILE - 1) / B3GS_TILE;
+      int x0 = clampi_from_float((mx - rad_f) / (float)B3GS_TILE, gx);
+      int y0 = clampi_from_float((my - rad_f) / (float)B3GS_TILE, gy);
+      int x1 = clampi_from_float((mx + rad_f + (float)(B3GS_TILE - 1)) / (float)B3GS_TILE, gx);
+      int y1 = clampi_from_float((my + rad_f + (float)(B3GS_TILE - 1)) / (float)B3GS_TILE, gy);
+      int area = (x1 - x0) * (y1 - y0);
+      if (area != 0) {
+        float rgb[3];
+        if (sc.colors_precomp) {
+          rgb[0] = sc.colors_precomp[3 * (size_t)i];
+          rgb[1] = sc.colors_precomp[3 * (size_t)i + 1];
+          rgb[2] = sc.colors_precomp[3 * (size_t)i + 2];
+        } else {
+          float dx = px3 - sc.campos[0], dy = py3 - sc.campos[1], dz = pz3 - sc.campos[2];
+          float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+          dx = dx * inv; dy = dy * inv; dz = dz * inv;
+          const float* sh = sc.shs + (size_t)3 * sc.M * i;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            float v = sh_eval(sc.D, sh, ch, dx, dy, dz) + 0.5f;
+            if (v < 0.0f) clamp_bits |= (1u << ch);
+            rgb[ch] = fmaxf(v, 0.0f);
+          }
+        }
+        const float op = sc.opacities[i];
+        // conservative half-extents of the region where op*G >= 1/255 (G <= 1): used by the blend
+        // kernels to skip whole 8x8 pixel quadrants; never changes which pixels contribute
+        float ext_x = -1.0e30f, ext_y = -1.0e30f;
+        if (op >= 0.0039f) {
+          float tau2 = 2.0f * logf(fmaxf(255.0f * op, 1.0f));
+          ext_x = sqrtf(tau2 * a) * 1.001f + 0.05f;
+          ext_y = sqrtf(tau2 * c) * 1.001f + 0.05f;
+        }
+        float4* rec = g.rec + 4 * (size_t)i;
+        rec[0] = make_float4(mx, my, cxx, cxy);
+        rec[1] = make_float4(cyy, op, rgb[0], rgb[1]);
+        rec[2] = make_float4(rgb[2], pv[2], ext_x, ext_y);
+        rec[3] = make_float4(a, b, c, 0.f);
+        radius_out = (int32_t)fminf(rad_f, 2147483520.0f);
+        touched = (uint32_t)area;
+        dkey = __float_as_uint(pv[2]);
+        rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
+      }
+    }
+  }
+  radii[i] = radius_out;
+  g.tiles_touched[i] = touched;
+  g.depth_key[i] = dkey;
+  g.rect[i] = rect;
+  g.clamped[i] = clamp_bits;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: one lane per Gaussian.  Inputs are the fp32 sums the blend backward accumulated:
+//   dL_dmeans2D[i] = (gx, gy, 0)   dL_dcolors[i]   dL_dopacity[i]
+//   dL_dcov3D[i]   = (g_conic_xx, g_conic_xy(half), g_conic_yy, g_depth, -, -)   (scratch use)
+// and every output row is overwritten with its final value.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    preprocess_bwd_kernel(B3gsScene sc, GeomView g, const int32_t* __restrict__ radii, float* __restrict__ dL_dmeans2D,
+                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                          float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc.P) return;
+  const size_t i3 = 3 * (size_t)i;
+  if (radii[i] <= 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dL_dmeans2D[i3 + k] = 0.f; dL_dcolors[i3 + k] = 0.f; dL_dmeans3D[i3 + k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.f;
+    dL_dopacity[i] = 0.f;
+    if (dL_dsh) for (int k = 0; k < 3 * sc.M; k++) dL_dsh[(size_t)3 * sc.M * i + k] = 0.f;
+    if (dL_dscales) { dL_dscales[i3] = 0.f; dL_dscales[i3 + 1] = 0.f; dL_dscales[i3 + 2] = 0.f; }
+    if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const Mat16 vm = load_mat(sc.viewmatrix);
+  const Mat16 pm = load_mat(sc.projmatrix);
+  const float mx3 = sc.means3D[i3], my3 = sc.means3D[i3 + 1], mz3 = sc.means3D[i3 + 2];
+
+  const float g2x = dL_dmeans2D[i3], g2y = dL_dmeans2D[i3 + 1];
+  dL_dmeans2D[i3 + 2] = 0.f;
+  const float gxx = dL_dcov3D[6 * (size_t)i + 0], gxy = dL_dcov3D[6 * (size_t)i + 1], gyy = dL_dcov3D[6 * (size_t)i + 2];
+  const float gdepth = dL_dcov3D[6 * (size_t)i + 3];
+  const float gcol[3] = {dL_dcolors[i3], dL_dcolors[i3 + 1], dL_dcolors[i3 + 2]};
+
+  float pv[3];
+  pv[0] = ((vm.m[0] * mx3 + vm.m[4] * my3) + vm.m[8] * mz3) + vm.m[12];
+  pv[1] = ((vm.m[1] * mx3 + vm.m[5] * my3) + vm.m[9] * mz3) + vm.m[13];
+  pv[2] = ((vm.m[2] * mx3 + vm.m[6] * my3) + vm.m[10] * mz3) + vm.m[14];
+
+  float c6[6];
+  cov3d_of(sc, i, c6);
+  const float fx = (float)sc.W / (2.0f * sc.tan_fovx), fy = (float)sc.H / (2.0f * sc.tan_fovy);
+  const Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
+  const float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
+
+  // conic = (c, -b, a)/den  ->  gradient w.r.t. (a, b, c); gxy holds HALF the true xy gradient
+  const float den = a * c - b * b;
+  const float k2 = 1.0f / (den * den + 0.0000001f);
+  const float dL_da = k2 * (-c * c * gxx + 2.f * b * c * gxy + (den - a * c) * gyy);
+  const float dL_dc = k2 * (-a * a * gyy + 2.f * a * b * gxy + (den - a * c) * gxx);
+  const float dL_db = k2 * 2.f * (b * c * gxx - (den + 2.f * b * b) * gxy + a * b * gyy);
+
+  const float* T0 = e.T0;
+  const float* T1 = e.T1;
+  float dS[6];
+  dS[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+  dS[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+  dS[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+  dS[1] = 2.f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.f * T1[0] * T1[1] * dL_dc;
+  dS[2] = 2.f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.f * T1[0] * T1[2] * dL_dc;
+  dS[4] = 2.f * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.f * T1[1] * T1[2] * dL_dc;
+#pragma unroll
+  for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+
+  // dL/dT, then through T = J Wr to the view-space position
+  const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+  float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float st0 = S[3 * r] * T0[0] + S[3 * r + 1] * T0[1] + S[3 * r + 2] * T0[2];
+    float st1 = S[3 * r] * T1[0] + S[3 * r + 1] * T1[1] + S[3 * r + 2] * T1[2];
+    float dT0 = 2.f * st0 * dL_da + st1 * dL_db;
+    float dT1 = 2.f * st1 * dL_dc + st0 * dL_db;
+    // Wr[row][r] = vm[4*r + row]
+    dJ00 += vm.m[4 * r + 0] * dT0;
+    dJ02 += vm.m[4 * r + 2] * dT0;
+    dJ11 += vm.m[4 * r + 1] * dT1;
+    dJ12 += vm.m[4 * r + 2] * dT1;
+  }
+  const float tz = 1.f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+  const float dtx = e.xmul * -fx * tz2 * dJ02;
+  const float dty = e.ymul * -fy * tz2 * dJ12;
+  const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.tx) * tz3 * dJ02 + (2.f * fy * e.ty) * tz3 * dJ12;
+  float dmean[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) dmean[k] = vm.m[4 * k + 0] * dtx + vm.m[4 * k + 1] * dty + vm.m[4 * k + 2] * dtz;
+
+  // pixel position -> mean (perspective divide); g2x/g2y already carry the 0.5*W / 0.5*H factor
+  {
+    float hx = ((pm.m[0] * mx3 + pm.m[4] * my3) + pm.m[8] * mz3) + pm.m[12];
+    float hy = ((pm.m[1] * mx3 + pm.m[5] * my3) + pm.m[9] * mz3) + pm.m[13];
+    float hw = ((pm.m[3] * mx3 + pm.m[7] * my3) + pm.m[11] * mz3) + pm.m[15];
+    float mw = 1.0f / (hw + 0.0000001f);
+    float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      dmean[k] += (pm.m[4 * k + 0] * mw - pm.m[4 * k + 3] * mul1) * g2x + (pm.m[4 * k + 1] * mw - pm.m[4 * k + 3] * mul2) * g2y;
+  }
+  // depth = view z
+#pragma unroll
+  for (int k = 0; k < 3; k++) dmean[k] += vm.m[4 * k + 2] * gdepth;
+
+  // colour: SH coefficients and view direction
+  if (!sc.colors_precomp && dL_dsh) {
+    const float* sh = sc.shs + (size_t)3 * sc.M * i;
+    float* dsh = dL_dsh + (size_t)3 * sc.M * i;
+    float ddx = mx3 - sc.campos[0], ddy = my3 - sc.campos[1], ddz = mz3 - sc.campos[2];
+    float inv = 1.0f / sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
+    const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
+    const uint32_t cb = g.clamped[i];
+    float gdir[3] = {0.f, 0.f, 0.f};
+    const int deg = sc.D;
+    const int nb = (deg + 1) * (deg + 1);
+    for (int k = nb; k < sc.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float gl = ((cb >> ch) & 1u) ? 0.f : gcol[ch];
+#define SH(k) sh[3 * (k) + ch]
+#define DSH(k) dsh[3 * (k) + ch]
+      DSH(0) = SH_C0 * gl;
+      float rx = 0.f, ry = 0.f, rz = 0.f;
+      if (deg > 0) {
+        DSH(1) = -SH_C1 * y * gl;
+        DSH(2) = SH_C1 * z * gl;
+        DSH(3) = -SH_C1 * x * gl;
+        rx = -SH_C1 * SH(3);
+        ry = -SH_C1 * SH(1);
+        rz = SH_C1 * SH(2);
+        if (deg > 1) {
+          float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          DSH(4) = SH_C2[0] * xy * gl;
+          DSH(5) = SH_C2[1] * yz * gl;
+          DSH(6) = SH_C2[2] * (2.f * zz - xx - yy) * gl;
+          DSH(7) = SH_C2[3] * xz * gl;
+          DSH(8) = SH_C2[4] * (xx - yy) * gl;
+          rx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
+          ry += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
+          rz += SH_C2[1] * y * SH(5) + SH_C2[2] * 4.f * z * SH(6) + SH_C2[3] * x * SH(7);
+          if (deg > 2) {
+            DSH(9) = SH_C3[0] * y * (3.f * xx - yy) * gl;
+            DSH(10) = SH_C3[1] * xy * z * gl;
+            DSH(11) = SH_C3[2] * y * (4.f * zz - xx - yy) * gl;
+            DSH(12) = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gl;
+            DSH(13) = SH_C3[4] * x * (4.f * zz - xx - yy) * gl;
+            DSH(14) = SH_C3[5] * z * (xx - yy) * gl;
+            DSH(15) = SH_C3[6] * x * (xx - 3.f * yy) * gl;
+            rx += SH_C3[0] * SH(9) * 6.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
+                  SH_C3[3] * SH(12) * -6.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                  SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
+            ry += SH_C3[0] * SH(9) * 3.f * (xx - yy) + SH_C3[1] * SH(10) * xz +
+                  SH_C3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12) * -6.f * yz +
+                  SH_C3[4] * SH(13) * -2.f * xy + SH_C3[5] * SH(14) * -2.f * yz + SH_C3[6] * SH(15) * -6.f * xy;
+            rz += SH_C3[1] * SH(10) * xy + SH_C3[2] * SH(11) * 8.f * yz + SH_C3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) +
+                  SH_C3[4] * SH(13) * 8.f * xz + SH_C3[5] * SH(14) * (xx - yy);
+          }
+        }
+      }
+#undef SH
+#undef DSH
+      gdir[0] += rx * gl;
+      gdir[1] += ry * gl;
+      gdir[2] += rz * gl;
+    }
+    // through n = d/|d|:  (I - n n^T)/|d|
+    float dot = gdir[0] * x + gdir[1] * y + gdir[2] * z;
+    dmean[0] += (gdir[0] - x * dot) * inv;
+    dmean[1] += (gdir[1] - y * dot) * inv;
+    dmean[2] += (gdir[2] - z * dot) * inv;
+  }
+  dL_dmeans3D[i3] = dmean[0];
+  dL_dmeans3D[i3 + 1] = dmean[1];
+  dL_dmeans3D[i3 + 2] = dmean[2];
+
+  // Sigma = L L^T, L = R diag(mod*s)
+  if (!sc.cov3D_precomp && dL_dscales && dL_drots) {
+    const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    float R[9];
+    quat_to_R(r, x, y, z, R);
+    const float sv[3] = {sc.scale_modifier * sc.scales[i3], sc.scale_modifier * sc.scales[i3 + 1],
+                         sc.scale_modifier * sc.scales[i3 + 2]};
+    const float G[9] = {dS[0], 0.5f * dS[1], 0.5f * dS[2], 0.5f * dS[1], dS[3], 0.5f * dS[4], 0.5f * dS[2], 0.5f * dS[4], dS[5]};
+    float dR[9];
+#pragma unroll
+    for (int bcol = 0; bcol < 3; bcol++) {
+      float ds = 0.f;
+#pragma unroll
+      for (int arow = 0; arow < 3; arow++) {
+        // dL/dL[a][b] = 2 * sum_k G[a][k] L[k][b],  L[k][b] = R[k][b] sv[b]
+        float dLab = 2.f * sv[bcol] * (G[3 * arow] * R[bcol] + G[3 * arow + 1] * R[3 + bcol] + G[3 * arow + 2] * R[6 + bcol]);
+        ds += dLab * R[3 * arow + bcol];
+        dR[3 * arow + bcol] = dLab * sv[bcol];
+      }
+      dL_dscales[i3 + bcol] = ds * sc.scale_modifier;
+    }
+    float4 dq;
+    dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+    dq.z = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+    dq.w = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    reinterpret_cast<float4*>(dL_drots)[i] = dq;
+  }
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ viewmatrix,
+                                    uint8_t* __restrict__ present) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float x = means3D[3 * (size_t)i], y = means3D[3 * (size_t)i + 1], z = means3D[3 * (size_t)i + 2];
+  float vz = ((viewmatrix[2] * x + viewmatrix[6] * y) + viewmatrix[10] * z) + viewmatrix[14];
+  present[i] = vz > B3GS_NEAR ? 1 : 0;
+}
+
+}  // namespace
+
+void b3gs_launch_preprocess(const B3gsScene& sc, const GeomView& g, int32_t* radii, hipStream_t s) {
+  if (sc.P <= 0) return;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((sc.P + 255) / 256), dim3(256), 0, s, sc, g, radii);
+}
+
+void b3gs_launch_preprocess_backward(const B3gsScene& sc, const GeomView& g, const int32_t* radii, float* dL_dmeans2D,
+                                     float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
+                                     float* dL_dsh, float* dL_dscales, float* dL_drotations, hipStream_t s) {
+  if (sc.P <= 0) return;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((sc.P + 255) / 256), dim3(256), 0, s, sc, g, radii, dL_dmeans2D,
+                     dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+}
+
+void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                              hipStream_t s) {
+  if (P <= 0) return;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}

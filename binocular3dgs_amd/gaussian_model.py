@@ -1,0 +1,86 @@
+"""Gaussian parameter store: the part of scene/gaussian_model.py the hot path reads.
+
+Same attribute and accessor names as the reference (`_xyz`, `_features_dc`, `_features_rest`,
+`_scaling`, `_rotation`, `_opacity`; `get_xyz`, `get_scaling`, `get_rotation`, `get_features`,
+`get_opacity`, `get_covariance`, `active_sh_degree`, `max_sh_degree`, `oneupSHdegree`:
+scene/gaussian_model.py:24-60,95-122), so render() accepts either class.  Densification, PLY I/O and
+the optimiser are "next" rows and deliberately absent.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+
+def build_rotation(r: torch.Tensor) -> torch.Tensor:
+    """utils/general_utils.py:78-99: normalise, then (w,x,y,z) -> 3x3."""
+    q = r / torch.sqrt((r * r).sum(dim=1, keepdim=True))
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation) -> torch.Tensor:
+    """scene/gaussian_model.py:27-31 + utils/general_utils.py:64-73,101-110:
+    L = R diag(mod*s); Sigma = L L^T; 6-vector (00,01,02,11,12,22)."""
+    L = build_rotation(rotation) * (scaling_modifier * scaling).unsqueeze(1)
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+class GaussianModel:
+    def __init__(self, sh_degree: int):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        e = torch.empty(0)
+        self._xyz, self._features_dc, self._features_rest = e, e, e
+        self._scaling, self._rotation, self._opacity = e, e, e
+
+    @classmethod
+    def from_tensors(cls, xyz, features_dc, features_rest, scaling, rotation, opacity, sh_degree=1,
+                     active_sh_degree=None, device=None, requires_grad=True):
+        m = cls(sh_degree)
+        for name, t in (("_xyz", xyz), ("_features_dc", features_dc), ("_features_rest", features_rest),
+                        ("_scaling", scaling), ("_rotation", rotation), ("_opacity", opacity)):
+            t = t.detach().clone().float()
+            if device is not None:
+                t = t.to(device)
+            setattr(m, name, nn.Parameter(t.contiguous().requires_grad_(requires_grad)))
+        m.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
+        return m
+
+    def parameters(self):
+        return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    def get_covariance(self, scaling_modifier=1):
+        return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
+
+    def oneupSHdegree(self):
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1

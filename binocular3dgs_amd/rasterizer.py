@@ -1,0 +1,276 @@
+"""Python surface of the rasterizer, name-for-name what the reference imports:
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+                                                        (gaussian_renderer/__init__.py:14)
+    GaussianRasterizationSettings(image_height=..., ..., debug=...)   (:36-49, 12 keywords)
+    rasterizer = GaussianRasterizer(raster_settings=...)               (:51)
+    color, radii, depth, alpha = rasterizer(means3D=, means2D=, shs=, colors_precomp=,
+                                            opacities=, scales=, rotations=, cov3D_precomp=)  (:85-93)
+
+and the two `_C` functions of the un-vendored extension:
+`_C.rasterize_gaussians(...)`, `_C.rasterize_gaussians_backward(...)` (+ `_C.mark_visible`).
+The arithmetic lives in libb3gs_raster.so (hand-written HIP for gfx950) behind the C ABI of
+include/b3gs_raster.h; this module only moves pointers.  No CPU / PyTorch fallback exists:
+CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise _lib.B3gsError(f"{name} is on {t.device}: the rasterizer runs on an MI355X (HIP) device only; "
+                             "there is no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug):
+    """Validate like the upstream binding and fill the C struct.  Returns (struct, keepalive)."""
+    means3D = _dev_f32(means3D, "means3D")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")
+    P = means3D.shape[0]
+    dev = means3D.device
+    keep = [means3D]
+
+    def opt(t, name, shape_tail):
+        if t is None or t.numel() == 0:
+            return None
+        t = _dev_f32(t, name)
+        if t.shape[0] != P or tuple(t.shape[1:]) not in shape_tail:
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected ({P}, {shape_tail})")
+        keep.append(t)
+        return t
+
+    sh_t = None
+    M = 0
+    if sh is not None and sh.numel() != 0:
+        sh_t = _dev_f32(sh, "sh")
+        if sh_t.dim() != 3 or sh_t.shape[0] != P or sh_t.shape[2] != 3:
+            raise ValueError("sh must have dimensions (num_points, K, 3)")
+        M = sh_t.shape[1]
+        keep.append(sh_t)
+    colors_t = opt(colors, "colors_precomp", [(3,)])
+    opacity_t = _dev_f32(opacity, "opacities").reshape(-1)
+    if opacity_t.numel() != P:
+        raise ValueError("opacities must have num_points elements")
+    scales_t = opt(scales, "scales", [(3,)])
+    rot_t = opt(rotations, "rotations", [(4,)])
+    cov_t = opt(cov3D_precomp, "cov3D_precomp", [(6,)])
+    bg = _dev_f32(background, "bg").reshape(-1)
+    vm = _dev_f32(viewmatrix, "viewmatrix").reshape(-1)
+    pm = _dev_f32(projmatrix, "projmatrix").reshape(-1)
+    cp = _dev_f32(campos, "campos").reshape(-1)
+    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
+        raise ValueError("bg/campos must have 3 and viewmatrix/projmatrix 16 elements")
+    keep += [opacity_t, bg, vm, pm, cp]
+    sc = _lib.B3gsScene(P, int(degree), int(M), int(image_width), int(image_height), float(tan_fovx),
+                        float(tan_fovy), float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
+                        _ptr(bg), _ptr(means3D), _ptr(sh_t), _ptr(colors_t), _ptr(opacity_t), _ptr(scales_t),
+                        _ptr(rot_t), _ptr(cov_t), _ptr(vm), _ptr(pm), _ptr(cp))
+    return sc, keep, dev, P, M
+
+
+class _CModule:
+    """Stands in for the `_C` torch-extension module of the upstream package."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                            campos, prefiltered, debug):
+        """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32,
+               geomBuffer, binningBuffer, imgBuffer)   (uint8 state tensors, opaque)"""
+        L = _lib.lib()
+        sc, keep, dev, P, _ = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                                     image_width, sh, degree, campos, prefiltered, debug)
+        H, W = int(image_height), int(image_width)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        bufs = {}
+
+        def mk(key):
+            def fn(_user, nbytes):
+                t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+                bufs[key] = t
+                return t.data_ptr()
+            return _lib.ALLOC_FN(fn)
+
+        cbs = [mk("geom"), mk("binning"), mk("img")]
+        n = C.c_int32(0)
+        with torch.cuda.device(dev):
+            rc = L.b3gs_forward(C.byref(sc), cbs[0], None, cbs[1], None, cbs[2], None, color.data_ptr(),
+                                depth.data_ptr(), alpha.data_ptr(), _ptr(radii), C.byref(n), _stream(dev))
+        _lib.check(rc, "b3gs_forward")
+        del keep
+        return (int(n.value), color, depth, alpha, radii, bufs["geom"],
+                bufs.get("binning", torch.empty(0, dtype=torch.uint8, device=dev)), bufs["img"])
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                     dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                     imageBuffer, alpha, debug, opacities=None):
+        """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
+               dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])
+
+        `opacities` is not part of the upstream signature (the kernels read opacity from the saved
+        geometry state); it is accepted so the scene struct can be validated the same way."""
+        L = _lib.lib()
+        P = means3D.shape[0]
+        dev = means3D.device
+        if opacities is None:
+            opacities = torch.empty((P, 1), dtype=torch.float32, device=dev)  # unused by the backward kernels
+        H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
+        sc, keep, dev, P, M = _scene(background, means3D, colors, opacities, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree,
+                                     campos, False, debug)
+        dC = _dev_f32(dL_dout_color, "dL_dout_color")
+        dD = None if dL_dout_depth is None or dL_dout_depth.numel() == 0 else _dev_f32(dL_dout_depth, "dL_dout_depth")
+        dA = None if dL_dout_alpha is None or dL_dout_alpha.numel() == 0 else _dev_f32(dL_dout_alpha, "dL_dout_alpha")
+        f = dict(dtype=torch.float32, device=dev)
+        dL_dmeans2D = torch.empty((P, 3), **f)
+        dL_dcolors = torch.empty((P, 3), **f)
+        dL_dopacity = torch.empty((P, 1), **f)
+        dL_dmeans3D = torch.empty((P, 3), **f)
+        dL_dcov3D = torch.empty((P, 6), **f)
+        dL_dsh = torch.empty((P, M, 3), **f)
+        has_sr = sc.scales is not None
+        dL_dscales = torch.empty((P, 3) if has_sr else (0, 3), **f)
+        dL_drot = torch.empty((P, 4) if has_sr else (0, 4), **f)
+        radii_i = radii.to(torch.int32).contiguous()
+        with torch.cuda.device(dev):
+            rc = L.b3gs_backward(C.byref(sc), int(R), _ptr(radii_i), _ptr(geomBuffer), _ptr(binningBuffer),
+                                 _ptr(imageBuffer), _ptr(dC), _ptr(dD), _ptr(dA), _ptr(dL_dmeans2D),
+                                 _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                                 _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _stream(dev))
+        _lib.check(rc, "b3gs_backward")
+        del keep
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        L = _lib.lib()
+        m = _dev_f32(means3D, "means3D")
+        vm = _dev_f32(viewmatrix, "viewmatrix")
+        pm = _dev_f32(projmatrix, "projmatrix")
+        present = torch.zeros((m.shape[0],), dtype=torch.bool, device=m.device)
+        with torch.cuda.device(m.device):
+            rc = L.b3gs_mark_visible(m.shape[0], _ptr(m), _ptr(vm), _ptr(pm), _ptr(present), _stream(m.device))
+        _lib.check(rc, "b3gs_mark_visible")
+        return present
+
+
+_C = _CModule()
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom,
+                              binning, img, alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = \
+            ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32,
+                                     device=means3D.device)
+        empty = torch.empty(0, device=means3D.device)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+         grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color,
+            empty if grad_depth is None else grad_depth, empty if grad_alpha is None else grad_alpha, sh,
+            rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, alpha, rs.debug)
+        needs = ctx.needs_input_grad
+
+        def pick(g, had_input, i):
+            return g if (had_input and needs[i]) else None
+
+        return (pick(grad_means3D, True, 0), pick(grad_means2D, True, 1), pick(grad_sh, sh.numel() != 0, 2),
+                pick(grad_colors_precomp, colors_precomp.numel() != 0, 3), pick(grad_opacities, True, 4),
+                pick(grad_scales, scales.numel() != 0, 5), pick(grad_rotations, rotations.numel() != 0, 6),
+                pick(grad_cov3Ds_precomp, cov3Ds_precomp.numel() != 0, 7), None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.Tensor([]).to(means3D.device)
+        shs = e if shs is None else shs
+        colors_precomp = e if colors_precomp is None else colors_precomp
+        scales = e if scales is None else scales
+        rotations = e if rotations is None else rotations
+        cov3D_precomp = e if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)

@@ -1,0 +1,148 @@
+/*
+ * b3gs_raster.h -- C ABI of libb3gs_raster.so, the MI355X-native differentiable Gaussian
+ * rasterizer that sits behind the reference's `diff_gaussian_rasterization._C` extension.
+ *
+ * Boundary it replaces (reference = hanl2010/Binocular3DGS; the extension's own source is an
+ * un-vendored submodule, .gitmodules:1-3, so the citations are the reference's call sites):
+ *   gaussian_renderer/__init__.py:36-49   GaussianRasterizationSettings  -> B3gsScene scalars/matrices
+ *   gaussian_renderer/__init__.py:85-93   rasterizer(means3D=..., ...)   -> b3gs_forward()
+ *   train.py:149 (total_loss.backward())  _RasterizeGaussians.backward   -> b3gs_backward()
+ *   (upstream `_C.mark_visible`, unused by the reference)                -> b3gs_mark_visible()
+ *
+ * Rules of the ABI:
+ *   - plain C: pointers, sizes, a stream handle; no torch / C++ types cross it
+ *   - every pointer is a DEVICE pointer unless the name says `host_`
+ *   - the caller owns all memory.  The three opaque state buffers (geometry / binning / image)
+ *     are obtained through caller-supplied allocation callbacks, exactly like the upstream
+ *     extension asks torch to resize three uint8 tensors; they must stay alive until
+ *     b3gs_backward() for the same view has been enqueued
+ *   - all work is enqueued on `stream`; b3gs_forward() blocks the calling host thread once
+ *     (to read back num_rendered) -- b3gs_forward_capacity() is the sync-free variant
+ *   - every function returns B3GS_OK or a negative B3gsStatus and never throws
+ *   - no global mutable state: re-entrant per stream / per device (one process per GPU)
+ */
+#ifndef B3GS_RASTER_H
+#define B3GS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B3GS_ABI_VERSION 1
+#define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
+
+typedef enum B3gsStatus {
+  B3GS_OK = 0,
+  B3GS_ERR_ARG = -1,      /* inconsistent arguments (exactly one of shs/colors_precomp, ...) */
+  B3GS_ERR_ALLOC = -2,    /* an allocation callback returned NULL */
+  B3GS_ERR_HIP = -3,      /* a HIP runtime call failed; see b3gs_last_error() */
+  B3GS_ERR_CAPACITY = -4, /* b3gs_forward_capacity: binning capacity too small */
+  B3GS_ERR_NO_DEVICE = -5
+} B3gsStatus;
+
+typedef void* b3gs_stream_t; /* hipStream_t */
+
+/* Allocation callback: return a device pointer to at least `bytes` bytes, 256-byte aligned,
+ * or NULL.  Mirrors the resize-a-uint8-tensor lambdas of the upstream torch binding. */
+typedef char* (*b3gs_alloc_fn)(void* user, size_t bytes);
+
+/* One view of one Gaussian cloud.  Field meaning = the 12 settings of
+ * gaussian_renderer/__init__.py:36-49 plus the 8 tensors of :85-93. */
+typedef struct B3gsScene {
+  int32_t P;           /* number of Gaussians */
+  int32_t D;           /* active SH degree, 0..3 (raster_settings.sh_degree) */
+  int32_t M;           /* SH coefficients per channel stored in `shs` (0 when shs == NULL) */
+  int32_t W, H;        /* image_width, image_height */
+  float tan_fovx, tan_fovy;
+  float scale_modifier;
+  int32_t prefiltered; /* reference always passes False */
+  int32_t debug;       /* sync + check after every kernel */
+  const float* background;     /* [3] */
+  const float* means3D;        /* [P,3] */
+  const float* shs;            /* [P,M,3] or NULL */
+  const float* colors_precomp; /* [P,3]   or NULL  (exactly one of shs / colors_precomp) */
+  const float* opacities;      /* [P,1] */
+  const float* scales;         /* [P,3]   or NULL */
+  const float* rotations;      /* [P,4] (w,x,y,z), used as given  or NULL */
+  const float* cov3D_precomp;  /* [P,6] (xx,xy,xz,yy,yz,zz) or NULL (exactly one of cov3D / scales+rotations) */
+  const float* viewmatrix;     /* [4,4] row-vector convention: [x y z 1] @ viewmatrix (scene/cameras.py:55) */
+  const float* projmatrix;     /* [4,4] full projection, same convention (scene/cameras.py:57) */
+  const float* campos;         /* [3] */
+} B3gsScene;
+
+/* Sizes of the opaque buffers (bytes).  geometry depends on P, image on W*H, binning on N. */
+size_t b3gs_geometry_bytes(int32_t P);
+size_t b3gs_image_bytes(int32_t W, int32_t H);
+size_t b3gs_binning_bytes(int32_t P, int64_t num_rendered);
+
+/* Forward: colour [3,H,W], depth [1,H,W] (= sum z a T, un-normalised), alpha [1,H,W] (= sum a T),
+ * radii [P] int32 (0 = culled).  *host_num_rendered receives N (tile instances). */
+int b3gs_forward(const B3gsScene* scene,
+                 b3gs_alloc_fn geometry_alloc, void* geometry_user,
+                 b3gs_alloc_fn binning_alloc, void* binning_user,
+                 b3gs_alloc_fn image_alloc, void* image_user,
+                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                 int32_t* host_num_rendered, b3gs_stream_t stream);
+
+/* Sync-free forward for callers that keep persistent scratch (the build's own training step):
+ * all three buffers are pre-sized by the caller; binning has room for `binning_capacity`
+ * instances.  N is written to *device_num_rendered (device int32) and nothing is read back.
+ * If N > binning_capacity the images are left untouched and *device_num_rendered still
+ * holds the required N (caller checks it at its next natural sync and retries). */
+int b3gs_forward_capacity(const B3gsScene* scene, char* geometry, char* binning, int64_t binning_capacity,
+                          char* image, float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                          int32_t* device_num_rendered, b3gs_stream_t stream);
+
+/* Backward.  Pixel gradients: dL_dcolor [3,H,W] (required), dL_ddepth / dL_dalpha [1,H,W] or NULL.
+ * Outputs (all fully overwritten, culled Gaussians get zeros):
+ *   dL_dmeans2D [P,3]  (x,y in the NDC-scaled units the densifier thresholds, z = 0)
+ *   dL_dcolors  [P,3]  gradient of the per-Gaussian RGB (= grad of colors_precomp)
+ *   dL_dopacity [P,1], dL_dmeans3D [P,3], dL_dcov3D [P,6]
+ *   dL_dsh [P,M,3] (NULL if colours were precomputed), dL_dscales [P,3], dL_drotations [P,4]
+ *   (NULL if cov3D was precomputed)
+ * num_rendered < 0 means "read N from the image buffer" (forward_capacity path). */
+int b3gs_backward(const B3gsScene* scene, int32_t num_rendered, const int32_t* radii,
+                  const char* geometry, const char* binning, const char* image,
+                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                  float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
+                  b3gs_stream_t stream);
+
+/* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
+int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, b3gs_stream_t stream);
+
+/* Read-only views into the opaque buffers, for parity tests (tile/bin indices must be
+ * bit-exact with the oracle).  Pointers are device pointers inside the caller's buffers. */
+typedef struct B3gsDebugViews {
+  const uint32_t* tiles_touched; /* [P] */
+  const float* depths;           /* [P] */
+  const float* records;          /* [P,16] x,y,cxx,cxy,cyy,opacity,r,g,b,depth,ext_x,ext_y,... */
+  const uint32_t* point_list;    /* [N] Gaussian index per instance, tile-major, depth-sorted */
+  const uint32_t* tile_ids;      /* [N] tile id per sorted instance */
+  const uint32_t* ranges;        /* [tiles,2] */
+  const float* final_T;          /* [H*W] */
+  const uint32_t* n_contrib;     /* [H*W] */
+} B3gsDebugViews;
+int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,
+                     const char* binning, const char* image, B3gsDebugViews* out);
+
+/* Per-kernel timing hook: when non-NULL, b3gs_forward/backward record HIP events around every
+ * kernel on `stream` and, at the end of the call, synchronise and add the elapsed milliseconds
+ * to the matching slot.  Used by bench.py for the roofline figure; never set in production. */
+typedef struct B3gsKernelTimes {
+  double preprocess_ms, sort_ms, render_fwd_ms, render_bwd_ms, preprocess_bwd_ms;
+  int64_t calls;
+} B3gsKernelTimes;
+void b3gs_set_timing(B3gsKernelTimes* sink);
+
+const char* b3gs_last_error(void); /* thread-local message of the last failure */
+int b3gs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B3GS_RASTER_H */

@@ -1,0 +1,245 @@
+"""GPU parity: the HIP path (through the C ABI) against oracle/tile_ref.c on seeded inputs.
+
+Tolerances (fp32; stated here as the contract):
+  * radii, tiles_touched, point_list (tile-major depth-sorted Gaussian ids), tile ranges: BIT-EXACT
+  * colour / depth / alpha: |err| <= 2e-5 * (1 + |x|)   (GPU exp2-based exp vs libm expf)
+  * n_contrib: identical except at borderline pixels (alpha ~ 1/255 or T ~ 1e-4): <= 0.1 % of pixels
+  * gradients: relative L2 error per tensor <= 2e-4 vs the oracle's double-accumulated sums
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_kwargs, rel_l2, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu(d):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+def _run_hip_forward(d, mode="sh_sr"):
+    from binocular3dgs_amd import _C
+    from binocular3dgs_amd.debug import state_views
+    g = _gpu(d)
+    e = torch.empty(0, device="cuda")
+    sh, colors, scales, rots, cov = g["shs"], e, g["scales"], g["rotations"], e
+    if "col" in mode:
+        sh, colors = e, g["colors_precomp"]
+    if "cov" in mode:
+        scales, rots, cov = e, e, g["cov3D_precomp"]
+    n, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
+        g["bg"], g["means3D"], colors, g["opacities"], scales, rots, d.get("scale_modifier", 1.0), cov,
+        g["viewmatrix"], g["projmatrix"], d["tanfovx"], d["tanfovy"], d["H"], d["W"], sh, d["sh_degree"], g["campos"],
+        False, True)
+    views = state_views(g["means3D"].shape[0], d["W"], d["H"], n, geom, binning, img)
+    return dict(n=n, color=color, depth=depth, alpha=alpha, radii=radii, geom=geom, binning=binning, img=img,
+                views=views, inputs=(g, sh, colors, scales, rots, cov))
+
+
+def _check_forward(d, st, out, px_tol=1e-3):
+    P = st.P
+    assert out["n"] == st.N
+    np.testing.assert_array_equal(out["radii"].cpu().numpy(), st.radii)
+    v = out["views"]
+    np.testing.assert_array_equal(v["tiles_touched"].cpu().numpy().astype(np.uint32), st.tiles_touched)
+    if st.N:
+        np.testing.assert_array_equal(v["point_list"].cpu().numpy().astype(np.uint32), st.point_list)
+        np.testing.assert_array_equal(v["tile_ids"].cpu().numpy().astype(np.uint64), st.keys >> np.uint64(32))
+    np.testing.assert_array_equal(v["ranges"].cpu().numpy().astype(np.uint32), st.ranges)
+    vis = st.radii > 0
+    rec = v["records"].cpu().numpy()
+    np.testing.assert_array_equal(rec[vis, 0:2], st.means2D[vis])          # pixel positions: same IEEE ops
+    np.testing.assert_array_equal(rec[vis][:, [2, 3, 4, 5]], st.conic_opacity[vis])
+    np.testing.assert_array_equal(rec[vis][:, [6, 7, 8]], st.rgb[vis])
+    np.testing.assert_array_equal(rec[vis, 9], st.depths[vis])
+    for name, ref in (("color", st.color), ("depth", st.depth), ("alpha", st.alpha)):
+        got = out[name].cpu().numpy()
+        err = np.abs(got - ref) / (1 + np.abs(ref))
+        assert err.max() <= 2e-5, f"{name}: max err {err.max():.3e}"
+    nc = v["n_contrib"].cpu().numpy().astype(np.uint32)
+    frac = float((nc != st.n_contrib).mean())
+    assert frac <= px_tol, f"n_contrib differs at {frac:.4%} of pixels"
+    np.testing.assert_allclose(v["final_T"].cpu().numpy(), st.final_T, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("seed,P,W,H", [(0, 500, 64, 48), (1, 3000, 200, 120), (2, 20000, 320, 240), (3, 257, 33, 17)])
+def test_forward_parity_sh_scale_rot(seed, P, W, H):
+    from oracle import tile_ref
+    d, _ = small_scene(P=P, W=W, H=H, seed=seed, near_frac=0.05)
+    st = tile_ref.forward(**oracle_kwargs(d))
+    out = _run_hip_forward(d)
+    _check_forward(d, st, out)
+
+
+@pytest.mark.parametrize("mode", ["col_sr", "sh_cov", "col_cov"])
+def test_forward_parity_precomputed_inputs(mode):
+    from oracle import tile_ref
+    from binocular3dgs_amd.gaussian_model import covariance_from_scaling_rotation
+    d, _ = small_scene(P=1500, W=160, H=96, seed=11)
+    g = torch.Generator().manual_seed(3)
+    d["colors_precomp"] = torch.rand(1500, 3, generator=g)
+    d["cov3D_precomp"] = covariance_from_scaling_rotation(d["scales"], 1.0, d["rotations"])
+    kw = oracle_kwargs(d)
+    if "col" in mode:
+        kw["shs"] = None
+    else:
+        kw["colors_precomp"] = None
+    if "cov" in mode:
+        kw["scales"] = kw["rotations"] = None
+    else:
+        kw["cov3D_precomp"] = None
+    st = tile_ref.forward(**kw)
+    out = _run_hip_forward(d, mode)
+    _check_forward(d, st, out)
+
+
+@pytest.mark.parametrize("deg,K", [(0, 1), (0, 4), (2, 9), (3, 16)])
+def test_forward_parity_sh_degrees(deg, K):
+    from oracle import tile_ref
+    d, _ = small_scene(P=800, W=96, H=64, seed=20 + deg, K=K, sh_degree=deg)
+    st = tile_ref.forward(**oracle_kwargs(d))
+    out = _run_hip_forward(d)
+    _check_forward(d, st, out)
+
+
+def _backward_both(d, mode="sh_sr", seed=0, use_depth=True, use_alpha=True):
+    from oracle import tile_ref
+    from binocular3dgs_amd import _C
+    kw = oracle_kwargs(d)
+    if "col" in mode:
+        kw["shs"] = None
+    else:
+        kw.pop("colors_precomp", None)
+    if "cov" in mode:
+        kw["scales"] = kw["rotations"] = None
+    else:
+        kw.pop("cov3D_precomp", None)
+    st = tile_ref.forward(**kw)
+    out = _run_hip_forward(d, mode)
+    H, W = d["H"], d["W"]
+    g = torch.Generator().manual_seed(100 + seed)
+    gc = torch.randn(3, H, W, generator=g)
+    gd = torch.randn(1, H, W, generator=g) if use_depth else None
+    ga = torch.randn(1, H, W, generator=g) if use_alpha else None
+    ref = tile_ref.backward(st, gc.numpy(), None if gd is None else gd.numpy(), None if ga is None else ga.numpy())
+    G, sh, colors, scales, rots, cov = out["inputs"]
+    e = torch.empty(0, device="cuda")
+    res = _C.rasterize_gaussians_backward(
+        G["bg"], G["means3D"], out["radii"], colors, scales, rots, d.get("scale_modifier", 1.0), cov, G["viewmatrix"],
+        G["projmatrix"], d["tanfovx"], d["tanfovy"], gc.cuda(), e if gd is None else gd.cuda(),
+        e if ga is None else ga.cuda(), sh, d["sh_degree"], G["campos"], out["geom"], out["n"], out["binning"],
+        out["img"], out["alpha"], True)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    return st, ref, dict(zip(names, res))
+
+
+@pytest.mark.parametrize("seed,P,W,H", [(0, 500, 64, 48), (1, 4000, 200, 120)])
+def test_backward_parity(seed, P, W, H):
+    d, _ = small_scene(P=P, W=W, H=H, seed=seed, near_frac=0.05)
+    st, ref, got = _backward_both(d, seed=seed)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+              "dL_drotations"):
+        e = rel_l2(got[k].cpu().numpy(), ref[k])
+        assert e <= 2e-4, f"{k}: rel L2 {e:.3e}"
+    # culled Gaussians receive exact zeros
+    culled = torch.from_numpy(st.radii <= 0)
+    for k in got:
+        assert float(got[k].cpu()[culled].abs().sum()) == 0.0, k
+
+
+@pytest.mark.parametrize("mode", ["col_sr", "sh_cov", "col_cov"])
+def test_backward_parity_precomputed_inputs(mode):
+    from binocular3dgs_amd.gaussian_model import covariance_from_scaling_rotation
+    d, _ = small_scene(P=1500, W=160, H=96, seed=31)
+    g = torch.Generator().manual_seed(3)
+    d["colors_precomp"] = torch.rand(1500, 3, generator=g)
+    d["cov3D_precomp"] = covariance_from_scaling_rotation(d["scales"], 1.0, d["rotations"])
+    st, ref, got = _backward_both(d, mode=mode, seed=4)
+    keys = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D"]
+    if "col" not in mode:
+        keys.append("dL_dsh")
+    if "cov" not in mode:
+        keys += ["dL_dscales", "dL_drotations"]
+    for k in keys:
+        e = rel_l2(got[k].cpu().numpy(), ref[k])
+        assert e <= 2e-4, f"{k}: rel L2 {e:.3e}"
+
+
+def test_backward_color_only_and_determinism_band():
+    d, _ = small_scene(P=2000, W=128, H=96, seed=41)
+    st, ref, a = _backward_both(d, seed=1, use_depth=False, use_alpha=False)
+    _, _, b = _backward_both(d, seed=1, use_depth=False, use_alpha=False)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_dsh"):
+        assert rel_l2(a[k].cpu().numpy(), ref[k]) <= 2e-4
+        # fp32 atomics: run-to-run differences stay at rounding level
+        assert rel_l2(a[k].cpu().numpy(), b[k].cpu().numpy()) <= 1e-5
+
+
+def test_autograd_function_and_render_surface():
+    """render() end to end: dict keys / shapes / dtypes of gaussian_renderer/__init__.py:97-103 and
+    means2D.grad populated (train.py:179 reads viewspace_points.grad[:, :2])."""
+    from oracle import tile_ref
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 160, 120
+    model = synth.synth_model(3000, seed=5, device="cuda", width=W, height=H)
+    cam = synth.synth_cameras(W, H, yaws=(4.0,), device="cuda")[0]
+    bg = torch.tensor([0.0, 0.0, 0.0], device="cuda")
+    grads = {}
+    for flags in [(False, False), (True, True)]:
+        pipe = PipelineParams(convert_SHs_python=flags[0], compute_cov3D_python=flags[1])
+        for p in model.parameters():
+            p.grad = None
+        pkg = render(cam, model, pipe, bg)
+        assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "rendered_depth", "rendered_alpha"}
+        assert pkg["render"].shape == (3, H, W) and pkg["rendered_depth"].shape == (1, H, W)
+        assert pkg["rendered_alpha"].shape == (1, H, W) and pkg["radii"].dtype == torch.int32
+        assert pkg["visibility_filter"].dtype == torch.bool
+        loss = pkg["render"].mean() + 0.1 * pkg["rendered_depth"].mean() + 0.2 * pkg["rendered_alpha"].mean()
+        loss.backward()
+        vg = pkg["viewspace_points"].grad
+        assert vg is not None and vg.shape == (3000, 3) and float(vg[:, 2].abs().sum()) == 0.0
+        assert float(vg[~pkg["visibility_filter"]].abs().sum()) == 0.0
+        grads[flags] = [p.grad.clone() for p in model.parameters()]
+    # the in-rasterizer SH / covariance paths and the PyTorch-side ones give the same parameter grads
+    for ga, gb in zip(grads[(False, False)], grads[(True, True)]):
+        assert rel_l2(ga.cpu().numpy(), gb.cpu().numpy()) <= 5e-4
+    # forward equals the oracle for the same activated inputs
+    st = tile_ref.forward(means3D=model.get_xyz.detach().cpu().numpy(), opacities=model.get_opacity.detach().cpu().numpy(),
+                          scales=model.get_scaling.detach().cpu().numpy(), rotations=model.get_rotation.detach().cpu().numpy(),
+                          shs=model.get_features.detach().cpu().numpy(), viewmatrix=cam.world_view_transform.cpu().numpy(),
+                          projmatrix=cam.full_proj_transform.cpu().numpy(), campos=cam.camera_center.cpu().numpy(),
+                          bg=bg.cpu().numpy(), W=W, H=H, tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2),
+                          sh_degree=1)
+    pkg = render(cam, model, PipelineParams(), bg)
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), st.radii)
+    assert np.abs(pkg["render"].detach().cpu().numpy() - st.color).max() <= 2e-5
+
+
+def test_cpu_tensors_are_rejected():
+    from binocular3dgs_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    d, _ = small_scene(P=10, W=16, H=16)
+    rs = GaussianRasterizationSettings(16, 16, d["tanfovx"], d["tanfovy"], d["bg"], 1.0, d["viewmatrix"],
+                                       d["projmatrix"], 1, d["campos"], False, False)
+    with pytest.raises(_lib.B3gsError):
+        GaussianRasterizer(rs)(means3D=d["means3D"], means2D=torch.zeros(10, 3), opacities=d["opacities"],
+                               shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+
+
+def test_empty_and_all_culled():
+    from binocular3dgs_amd import _C
+    d, _ = small_scene(P=64, W=48, H=32, seed=9)
+    d["means3D"] = d["means3D"].clone()
+    d["means3D"][:, 2] = -5.0          # everything behind the camera
+    out = _run_hip_forward(d)
+    assert out["n"] == 0 and int(out["radii"].abs().sum()) == 0
+    bg = d["bg"].reshape(3, 1, 1).expand(3, 32, 48)
+    np.testing.assert_allclose(out["color"].cpu().numpy(), bg.numpy(), rtol=0, atol=0)
+    assert float(out["alpha"].abs().sum()) == 0.0
+    vis = _C.mark_visible(d["means3D"].cuda(), d["viewmatrix"].cuda(), d["projmatrix"].cuda())
+    assert not bool(vis.any())
