@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path (BASELINE.json):
+
+    train iters/s (fwd+bwd) + Mpix/s, 1M Gaussians @ 800x600, 1/2/4/8 GPU
+
+One *iter* = 6 views = 3 input views + their 3 binocular-shifted partners, each rasterised forward
+and backward through the drop-in `render()` (activations and their autograd included), the
+per-Gaussian gradients of all views accumulated in one flat slab, all-reduced over RCCL when
+N > 1 (weak scaling: every rank renders its own 6 views, distinct yaw offsets), and one Adam step.
+Inputs are the seeded synthetic scene of BASELINE.md section 3, resident in HBM before the timed
+region; upstream pixel gradients are the seeded N(0,1)/(3HW), /HW, /HW tensors of SURVEY 8(d)
+(primary views: colour+depth+alpha; shifted views: colour only, as the loss block of
+train.py:123-149 produces).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (blend backward): algorithmic bytes / HIP-event duration vs 8 TB/s
+  roofline_view whole view fwd+bwd: SURVEY 8(d) byte model (R+W) / per-view kernel time
+  cpu_baseline  oracle/tile_ref.c (kind "port") on the host cores, one full-size view fwd+bwd
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def byte_model(P, V, N, HW, Tn, K=4, tiles_bits=None):
+    """SURVEY.md 8(d) algorithmic bytes per view, fwd+bwd, K SH coeffs, p radix byte-passes of the
+    reference's 64-bit sort (the model is the REFERENCE algorithm's traffic: what a perfect
+    implementation of that algorithm must move; our two-level sort moves less)."""
+    p = math.ceil((32 + max(1, math.ceil(math.log2(max(Tn, 2))))) / 8)
+    R = 12 * P + (32 + 12 * K) * V + 4 * P + 20 * V + (12 * p + 8) * N + 8 * N + 44 * N + 8 * Tn + 44 * N + 28 * HW + \
+        (44 + 12 * K + 76) * V
+    Wt = 8 * P + 68 * V + 4 * P + 12 * N + 12 * p * N + 8 * Tn + 28 * HW + 48 * P + 48 * V + (40 + 12 * K) * P
+    return R, Wt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists for the rasterizer)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.render import PipelineParams
+    from binocular3dgs_amd.step import ViewShardedStep
+
+    P, W, H = args.gaussians, args.width, args.height
+    model = synth.synth_model(P, seed=args.seed, device=dev, width=W, height=H)
+    # weak scaling: each rank owns 3 distinct pairs (yaw offsets 0, 1.5, 3.0 ... degrees apart)
+    pairs = synth.synth_view_set(W, H, device=dev, yaw_offset=1.5 * rank)
+    bg = torch.zeros(3, device=dev)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=rank, device=dev)
+    gc2 = synth.synth_pixel_grads(W, H, seed=100 + rank, device=dev)[0]
+    opt = None
+    if not args.no_optimizer:
+        # learning rates of arguments/__init__.py:75-82, eps of scene/gaussian_model.py:163
+        lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]
+        opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), lrs)], lr=0.0,
+                               eps=1e-15, fused=True)
+    stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt)
+
+    def grad_fn(i, pkg, spkg):
+        out = [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga)]
+        if spkg is not None:
+            out.append((spkg["render"], gc2))
+        return out
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        stepper.step(pair_grad_fn=grad_fn)
+
+    # stage timing: HIP events recorded by the library on the launch stream, no sync inside
+    L = _lib.lib()
+    times = _lib.B3gsKernelTimes()
+    barrier()
+    L.b3gs_set_timing(C.byref(times))
+    views = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        views += stepper.step(pair_grad_fn=grad_fn)
+    barrier()
+    t1 = time.perf_counter()
+    L.b3gs_timing_collect()
+    L.b3gs_set_timing(None)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # workload statistics of this rank's primary view 0 (V, N make the byte model concrete)
+    with torch.no_grad():
+        from binocular3dgs_amd.render import render
+        pkg = render(pairs[0][0], model, PipelineParams(), bg)
+        V = int((pkg["radii"] > 0).sum().item())
+    n_views = max(int(times.calls), 1)
+    # N: read back from one more forward through the C ABI surface
+    from binocular3dgs_amd import _C
+    with torch.no_grad():
+        cam = pairs[0][0]
+        N = _C.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity,
+                                   model.get_scaling, model.get_rotation, 1.0, torch.empty(0, device=dev),
+                                   cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx / 2),
+                                   math.tan(cam.FoVy / 2), H, W, model.get_features, model.active_sh_degree,
+                                   cam.camera_center, False, False)[0]
+
+    iters = args.steps * world
+    value = iters / elapsed
+    views_per_iter = 2 * len(pairs)
+    mpix = views_per_iter * W * H * iters / elapsed / 1e6
+
+    if rank == 0:
+        HW = W * H
+        Tn = ((W + 15) // 16) * ((H + 15) // 16)
+        ms = dict(preprocess=times.preprocess_ms / n_views, sort=times.sort_ms / n_views,
+                  render_fwd=times.render_fwd_ms / n_views, render_bwd=times.render_bwd_ms / n_views,
+                  preprocess_bwd=times.preprocess_bwd_ms / n_views)
+        # dominant kernel = the largest stage that is a single kernel launch
+        single = {"render_fwd": ms["render_fwd"], "render_bwd": ms["render_bwd"]}
+        dom = max(single, key=single.get)
+        # algorithmic bytes per launch (DESIGN.md "Kernels"): the blend kernels read one 44-byte record
+        # + 4-byte index per tile instance; fwd writes 28 B/pixel, bwd reads 28 B/pixel and updates
+        # 10 fp32 accumulators per visible Gaussian (read+write = 80 B)
+        dom_bytes = (48 * N + 28 * HW + 8 * Tn) if dom == "render_fwd" else (48 * N + 28 * HW + 8 * Tn + 80 * V)
+        dom_s = single[dom] / 1e3
+        achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+        R, Wt = byte_model(P, V, N, HW, Tn)
+        view_ms = sum(ms.values())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "train iters/s (fwd+bwd), 1M Gaussians @ 800x600, 6 views/iter",
+            "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mpix_per_s": round(mpix, 1),
+            "config": {"workload": f"synth(P={P}, seed={args.seed}) {W}x{H}, 3 input + 3 binocular-shifted views "
+                                   f"per rank per iter, fwd+bwd+grad all-reduce+Adam", "gaussians": P, "width": W,
+                       "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
+                       "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
+                       "optimizer_in_step": opt is not None, "parallelism": f"dp{world} (views sharded, params replicated)"},
+            "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
+            "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "bytes_per_launch": dom_bytes,
+                         "avg_launch_ms": round(single[dom], 4),
+                         "note": "blend kernels are VALU/LDS-bound (SURVEY 8d caveat); see pixgauss_evals_per_s"},
+            "roofline_view": {"bound": "hbm", "bytes_per_view": R + Wt, "read_bytes_per_view": R,
+                              "kernel_ms_per_view": round(view_ms, 4),
+                              "achieved": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
+                              "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, W, H, args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(P, W, H, seed):
+    """The oracle (C port, OpenMP) on the host cores: ONE full-size view, forward + backward, same
+    synthetic inputs (1/6 of an iteration).  Reported baseline only -- never on the product path."""
+    from binocular3dgs_amd import synth
+    from oracle import tile_ref
+    cores = os.cpu_count() or 1
+    model = synth.synth_model(P, seed=seed, device="cpu", width=W, height=H, requires_grad=False)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=0)
+    gc2 = synth.synth_pixel_grads(W, H, seed=100)[0]
+    with torch.no_grad():
+        base = dict(means3D=model.get_xyz.numpy(), opacities=model.get_opacity.numpy(),
+                    scales=model.get_scaling.numpy(), rotations=model.get_rotation.numpy(),
+                    shs=model.get_features.numpy(), bg=[0.0, 0.0, 0.0], W=W, H=H, sh_degree=1, threads=cores)
+    fwd_s = bwd_s = 0.0
+    nviews = 0
+    for cam, scam, _t in synth.synth_view_set(W, H):
+        for c, grads in ((cam, (gc.numpy(), gd.numpy(), ga.numpy())), (scam, (gc2.numpy(), None, None))):
+            kw = dict(base, viewmatrix=c.world_view_transform.numpy(), projmatrix=c.full_proj_transform.numpy(),
+                      campos=c.camera_center.numpy(), tanfovx=math.tan(c.FoVx / 2), tanfovy=math.tan(c.FoVy / 2))
+            t0 = time.perf_counter()
+            st = tile_ref.forward(**kw)
+            t1 = time.perf_counter()
+            tile_ref.backward(st, *grads)
+            t2 = time.perf_counter()
+            fwd_s += t1 - t0
+            bwd_s += t2 - t1
+            nviews += 1
+    it_s = fwd_s + bwd_s
+    return {"value": round(1.0 / it_s, 5), "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H} (no all-reduce, no Adam): "
+                      f"fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; oracle/tile_ref.c, OpenMP {cores} threads",
+            "ms_per_view": round(it_s / nviews * 1e3, 1)}
+
+
+if __name__ == "__main__":
+    main()

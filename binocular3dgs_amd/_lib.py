@@ -42,7 +42,7 @@ class B3gsKernelTimes(C.Structure):
 
 
 # every symbol include/b3gs_raster.h declares (tests/test_abi.py checks the .so exports all of them)
-EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_geometry_bytes", "b3gs_image_bytes",
+EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timing_collect", "b3gs_geometry_bytes", "b3gs_image_bytes",
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views")
 
@@ -66,6 +66,7 @@ def lib():
     L.b3gs_last_error.restype = C.c_char_p
     L.b3gs_set_timing.argtypes = [C.c_void_p]
     L.b3gs_set_timing.restype = None
+    L.b3gs_timing_collect.restype = C.c_int
     L.b3gs_geometry_bytes.argtypes = [C.c_int32]
     L.b3gs_geometry_bytes.restype = C.c_size_t
     L.b3gs_image_bytes.argtypes = [C.c_int32, C.c_int32]

@@ -6,11 +6,14 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local B3gsKernelTimes* g_timing = nullptr;
+// bench-only timing sink: process-wide (autograd runs the backward on its own thread)
+B3gsKernelTimes* g_timing = nullptr;
+std::mutex g_timing_mu;
 
 int fail(int code, const char* fmt, const char* detail) {
   snprintf(g_err, sizeof(g_err), fmt, detail);
@@ -40,25 +43,32 @@ int check_scene(const B3gsScene* sc) {
   return B3GS_OK;
 }
 
-// optional per-stage timing (bench only): events bracket each stage on the caller's stream
+// optional per-stage timing (bench only): events bracket each stage on the caller's stream.
+// Nothing synchronises inside the call: the events are parked in a thread-local list and turned
+// into milliseconds by b3gs_timing_collect() after the caller has synchronised the stream.
+struct PendingStage {
+  hipEvent_t a, b;
+  int slot;  // 0 preprocess, 1 sort, 2 render fwd, 3 render bwd, 4 preprocess bwd
+};
+PendingStage g_pending[4096];
+int g_npending = 0;
+
 struct StageTimer {
   hipStream_t s;
-  hipEvent_t ev[8];
-  int n = 0;
+  hipEvent_t prev = nullptr;
   bool on;
-  explicit StageTimer(hipStream_t st) : s(st), on(g_timing != nullptr) {
-    if (on) for (auto& e : ev) (void)hipEventCreate(&e);
-  }
-  void mark() {
-    if (on && n < 8) (void)hipEventRecord(ev[n++], s);
-  }
-  float ms(int a, int b) {
-    float t = 0.f;
-    (void)hipEventElapsedTime(&t, ev[a], ev[b]);
-    return t;
-  }
-  ~StageTimer() {
-    if (on) for (auto& e : ev) (void)hipEventDestroy(e);
+  explicit StageTimer(hipStream_t st) : s(st), on(g_timing != nullptr) {}
+  // close the stage that started at the previous mark (slot < 0: just open a new stage)
+  void mark(int slot) {
+    if (!on) return;
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, s);
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (slot >= 0 && prev && g_npending < 4096) {
+      g_pending[g_npending++] = PendingStage{prev, e, slot};
+    }
+    prev = e;  // events are destroyed in b3gs_timing_collect (shared between adjacent stages)
   }
 };
 
@@ -80,6 +90,29 @@ extern "C" {
 int b3gs_abi_version(void) { return B3GS_ABI_VERSION; }
 const char* b3gs_last_error(void) { return g_err; }
 void b3gs_set_timing(B3gsKernelTimes* sink) { g_timing = sink; }
+
+int b3gs_timing_collect(void) {
+  // caller has synchronised the stream(s): resolve parked events into the sink
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  int n = g_npending;
+  for (int i = 0; i < n; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_pending[i].a, g_pending[i].b) == hipSuccess && g_timing) {
+      double* slots[5] = {&g_timing->preprocess_ms, &g_timing->sort_ms, &g_timing->render_fwd_ms,
+                          &g_timing->render_bwd_ms, &g_timing->preprocess_bwd_ms};
+      *slots[g_pending[i].slot] += (double)ms;
+      if (g_pending[i].slot == 2) g_timing->calls++;
+    }
+  }
+  // an event may be the end of one stage and the start of the next: destroy each once
+  for (int i = 0; i < n; i++) {
+    bool a_shared = i > 0 && g_pending[i - 1].b == g_pending[i].a;
+    if (!a_shared) (void)hipEventDestroy(g_pending[i].a);
+    (void)hipEventDestroy(g_pending[i].b);
+  }
+  g_npending = 0;
+  return n;
+}
 
 size_t b3gs_geometry_bytes(int32_t P) { return b3gs_geom_view(nullptr, P, nullptr); }
 size_t b3gs_image_bytes(int32_t W, int32_t H) { return b3gs_img_view(nullptr, W, H, nullptr); }
@@ -104,10 +137,10 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   b3gs_img_view(ibuf, sc->W, sc->H, &im);
 
   StageTimer tm(s);
-  tm.mark();
+  tm.mark(-1);
   b3gs_launch_preprocess(*sc, g, radii, s);
   if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
-  tm.mark();
+  tm.mark(0);
   b3gs_launch_depth_sort_and_scan(sc->P, g, s);
   if ((rc = debug_sync(sc, s, "depth sort + scan"))) return rc;
 
@@ -126,17 +159,10 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
 
   b3gs_launch_binning(sc->P, sc->W, sc->H, N, g, b, im, s);
   if ((rc = debug_sync(sc, s, "binning"))) return rc;
-  tm.mark();
+  tm.mark(1);
   b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
   if ((rc = debug_sync(sc, s, "render forward"))) return rc;
-  tm.mark();
-  if (tm.on) {
-    HIP_TRY(hipStreamSynchronize(s));
-    g_timing->preprocess_ms += tm.ms(0, 1);
-    g_timing->sort_ms += tm.ms(1, 2);
-    g_timing->render_fwd_ms += tm.ms(2, 3);
-    g_timing->calls++;
-  }
+  tm.mark(2);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }
@@ -157,9 +183,9 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
   b3gs_img_view(image, sc->W, sc->H, &im);
   b3gs_bin_view(binning, sc->P, binning_capacity, &b);
   StageTimer tm(s);
-  tm.mark();
+  tm.mark(-1);
   b3gs_launch_preprocess(*sc, g, radii, s);
-  tm.mark();
+  tm.mark(0);
   b3gs_launch_depth_sort_and_scan(sc->P, g, s);
   HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
   if (device_num_rendered)
@@ -167,16 +193,9 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
   // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
   // list, which the caller detects from *device_num_rendered > capacity and repeats
   b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
-  tm.mark();
+  tm.mark(1);
   b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
-  tm.mark();
-  if (tm.on) {
-    HIP_TRY(hipStreamSynchronize(s));
-    g_timing->preprocess_ms += tm.ms(0, 1);
-    g_timing->sort_ms += tm.ms(1, 2);
-    g_timing->render_fwd_ms += tm.ms(2, 3);
-    g_timing->calls++;
-  }
+  tm.mark(2);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }
@@ -207,7 +226,7 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
 
   const size_t P = (size_t)sc->P;
   StageTimer tm(s);
-  tm.mark();
+  tm.mark(-1);
   // accumulation targets of the blend backward (dL_dcov3D doubles as conic/depth scratch)
   HIP_TRY(hipMemsetAsync(dL_dmeans2D, 0, P * 3 * sizeof(float), s));
   HIP_TRY(hipMemsetAsync(dL_dcolors, 0, P * 3 * sizeof(float), s));
@@ -217,16 +236,11 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
     b3gs_launch_render_backward(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
                                 dL_dcov3D, s);
   if ((rc = debug_sync(sc, s, "render backward"))) return rc;
-  tm.mark();
+  tm.mark(3);
   b3gs_launch_preprocess_backward(*sc, g, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                                   dL_dscales, dL_drotations, s);
   if ((rc = debug_sync(sc, s, "preprocess backward"))) return rc;
-  tm.mark();
-  if (tm.on) {
-    HIP_TRY(hipStreamSynchronize(s));
-    g_timing->render_bwd_ms += tm.ms(0, 1);
-    g_timing->preprocess_bwd_ms += tm.ms(1, 2);
-  }
+  tm.mark(4);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }

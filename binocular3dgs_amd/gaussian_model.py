@@ -51,7 +51,7 @@ class GaussianModel:
             t = t.detach().clone().float()
             if device is not None:
                 t = t.to(device)
-            setattr(m, name, nn.Parameter(t.contiguous().requires_grad_(requires_grad)))
+            setattr(m, name, nn.Parameter(t.contiguous(), requires_grad=requires_grad))
         m.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
         return m
 

@@ -1,0 +1,106 @@
+"""View-sharded training step: the data-parallel form of one `train.py` iteration.
+
+Reference semantics (train.py:92-149,196-198): one input view per iteration, optionally a second
+render of its binocular-shifted partner; the per-Gaussian gradients of the renders simply add up
+in autograd, then Adam steps.  Here every rank owns whole (input view, shifted view) PAIRS --
+the binocular loss couples the two members of a pair through the primary depth map, so a pair is
+never split -- the Gaussian parameters are replicated, and the only exchange is ONE all-reduce
+(sum) of a flat, pre-packed fp32 gradient slab (92 B per Gaussian at K=4) over RCCL/xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  There is no reference
+counterpart for the collective (the reference is single-GPU): semantics are defined in
+SURVEY.md section 8e / DESIGN.md "Multi-GPU".
+
+`views_per_step == 1` on one rank reproduces the reference schedule.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .render import PipelineParams, render
+
+
+class FlatGradSlab:
+    """All parameter gradients live in one contiguous fp32 buffer: `p.grad` of every parameter is
+    a view into it, so autograd accumulates the views of all renders in place, zeroing is one
+    memset and the data-parallel exchange is one all-reduce without a pack step."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.views: List[torch.Tensor] = []
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = v
+            self.views.append(v)
+            off += p.numel()
+
+    def rebind(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def zero(self):
+        self.flat.zero_()
+        self.rebind()
+
+    def all_reduce(self, average: bool = False, group=None):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.div_(dist.get_world_size(group))
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * 4
+
+
+def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment of view pairs to ranks (pair i -> rank i % world)."""
+    return [i for i in range(num_pairs) if i % world == rank]
+
+
+class ViewShardedStep:
+    """One optimisation step over this rank's view pairs.
+
+    pair_grad_fn(pair_index, primary_pkg, shifted_pkg_or_None) -> list of (output_tensor, grad_tensor)
+    supplies the upstream pixel gradients (bench: seeded synthetic gradients; training: autograd of
+    the loss block).  When `loss_fn` is given instead, it returns a scalar loss per pair and
+    ordinary autograd is used.
+    """
+
+    def __init__(self, model, pairs, bg: torch.Tensor, pipe: Optional[PipelineParams] = None, optimizer=None,
+                 average_over_world: bool = False, render_fn: Callable = render):
+        self.model = model
+        self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]
+        self.bg = bg
+        self.pipe = pipe or PipelineParams()
+        self.slab = FlatGradSlab(model.parameters())
+        self.optimizer = optimizer
+        self.average = average_over_world
+        self.render = render_fn
+        self.last_stats = {}
+
+    def step(self, pair_grad_fn=None, loss_fn=None):
+        assert (pair_grad_fn is None) != (loss_fn is None)
+        self.slab.zero()
+        n_rendered = 0
+        for i, (cam, scam, t) in enumerate(self.pairs):
+            pkg = self.render(cam, self.model, self.pipe, self.bg)
+            spkg = self.render(scam, self.model, self.pipe, self.bg) if scam is not None else None
+            n_rendered += 1 + (scam is not None)
+            if loss_fn is not None:
+                loss_fn(i, cam, pkg, spkg, t).backward()
+            else:
+                outs, grads = zip(*pair_grad_fn(i, pkg, spkg))
+                torch.autograd.backward(list(outs), list(grads))
+        self.slab.all_reduce(self.average)
+        if self.optimizer is not None:
+            self.slab.rebind()
+            self.optimizer.step()
+        self.last_stats = {"views": n_rendered}
+        return n_rendered

@@ -130,14 +130,17 @@ typedef struct B3gsDebugViews {
 int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,
                      const char* binning, const char* image, B3gsDebugViews* out);
 
-/* Per-kernel timing hook: when non-NULL, b3gs_forward/backward record HIP events around every
- * kernel on `stream` and, at the end of the call, synchronise and add the elapsed milliseconds
- * to the matching slot.  Used by bench.py for the roofline figure; never set in production. */
+/* Per-stage timing hook (thread-local): when non-NULL, b3gs_forward/backward record HIP events
+ * around every stage on `stream` WITHOUT synchronising.  After the caller has synchronised the
+ * stream, b3gs_timing_collect() adds the elapsed milliseconds of every parked stage to the sink
+ * and returns the number of stages resolved (at most 4096 may be parked).  Used by bench.py for
+ * the roofline figure; never set in production. */
 typedef struct B3gsKernelTimes {
   double preprocess_ms, sort_ms, render_fwd_ms, render_bwd_ms, preprocess_bwd_ms;
   int64_t calls;
 } B3gsKernelTimes;
 void b3gs_set_timing(B3gsKernelTimes* sink);
+int b3gs_timing_collect(void);
 
 const char* b3gs_last_error(void); /* thread-local message of the last failure */
 int b3gs_abi_version(void);

@@ -414,7 +414,9 @@ void orc_render_backward(const OrcScene* s, const OrcGeom* g, const uint32_t* po
   const int W = s->W, H = s->H;
   const int gx = (W + ORC_TILE - 1) / ORC_TILE, gy = (H + ORC_TILE - 1) / ORC_TILE;
   const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-  /* serial over tiles so that double accumulation order is deterministic */
+  /* tiles in parallel; the double accumulators are updated atomically (summation order then
+   * varies run to run at the 1e-16 level, far below the fp32 comparisons made against them) */
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
   for (int ty = 0; ty < gy; ty++)
     for (int tx = 0; tx < gx; tx++) {
       uint32_t r0 = ranges[2 * (ty * gx + tx)];
@@ -449,12 +451,14 @@ void orc_render_backward(const OrcScene* s, const OrcGeom* g, const uint32_t* po
               accum_c[ch] = fmaf(last_alpha, last_c[ch], (1.f - last_alpha) * accum_c[ch]);
               last_c[ch] = c;
               dL_dalpha = fmaf(c - accum_c[ch], dC[ch], dL_dalpha);
+              #pragma omp atomic
               o->dL_dcolor[3 * id + ch] += (double)(w * dC[ch]);
             }
             float dep = g->depths[id];
             accum_d = fmaf(last_alpha, last_d, (1.f - last_alpha) * accum_d);
             last_d = dep;
             dL_dalpha = fmaf(dep - accum_d, dD, dL_dalpha);
+            #pragma omp atomic
             o->dL_ddepth[id] += (double)(w * dD);
             accum_a = fmaf(last_alpha, 1.0f, (1.f - last_alpha) * accum_a);
             dL_dalpha = fmaf(1.0f - accum_a, dA, dL_dalpha);
@@ -467,11 +471,17 @@ void orc_render_backward(const OrcScene* s, const OrcGeom* g, const uint32_t* po
             float gdx = G * dx, gdy = G * dy;
             float dG_ddx = -gdx * co[0] - gdy * co[1];
             float dG_ddy = -gdy * co[2] - gdx * co[1];
+            #pragma omp atomic
             o->dL_dmean2D[2 * id + 0] += (double)(dL_dG * dG_ddx * ddelx_dx);
+            #pragma omp atomic
             o->dL_dmean2D[2 * id + 1] += (double)(dL_dG * dG_ddy * ddely_dy);
+            #pragma omp atomic
             o->dL_dconic[3 * id + 0] += (double)(-0.5f * gdx * dx * dL_dG);
+            #pragma omp atomic
             o->dL_dconic[3 * id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
+            #pragma omp atomic
             o->dL_dconic[3 * id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
+            #pragma omp atomic
             o->dL_dopacity[id] += (double)(G * dL_dalpha);
           }
         }
