@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
+                    help="fused: b3gs_forward_raw/backward_raw (activations in-kernel, persistent scratch, no host sync); "
+                         "dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
+    ap.add_argument("--graph", type=int, default=1, help="capture one whole iteration in a HIP graph (fused path only)")
     return ap.parse_args()
 
 
@@ -92,7 +96,11 @@ def main():
         lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]
         opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), lrs)], lr=0.0,
                                eps=1e-15, fused=True)
-    stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt)
+    fused = None
+    if args.path == "fused":
+        from binocular3dgs_amd.fused import FusedRasterizer
+        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs))
+    stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt, fused=fused)
 
     def grad_fn(i, pkg, spkg):
         out = [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga)]
@@ -106,23 +114,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         stepper.step(pair_grad_fn=grad_fn)
+    if fused is not None:
+        while fused.overflowed():          # persistent binning capacity too small: grow once, outside the timed region
+            fused.grow()
+            stepper.step(pair_grad_fn=grad_fn)
+    run_step = lambda: stepper.step(pair_grad_fn=grad_fn)  # noqa: E731
+    use_graph = bool(args.graph) and fused is not None and world == 1
+    if use_graph:
+        # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
+        # (6 views fwd+bwd, slab zero, Adam) is one hipGraph launch
+        if opt is not None:
+            for g_ in opt.param_groups:
+                g_["capturable"] = True
+            for st_ in opt.state.values():
+                if "step" in st_ and not st_["step"].is_cuda:
+                    st_["step"] = st_["step"].to(dev)
+        sg = torch.cuda.Stream()
+        sg.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(sg):
+            stepper.step(pair_grad_fn=grad_fn)
+        torch.cuda.current_stream().wait_stream(sg)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stepper.step(pair_grad_fn=grad_fn)
+        run_step = graph.replay
 
-    # stage timing: HIP events recorded by the library on the launch stream, no sync inside
+    # stage timing: HIP events recorded by the library on the launch stream, no sync inside.
+    # When the iteration is replayed from a HIP graph the library is not re-entered, so the events
+    # are taken from eager iterations of the same workload run right after the timed region.
     L = _lib.lib()
     times = _lib.B3gsKernelTimes()
     barrier()
-    L.b3gs_set_timing(C.byref(times))
+    if not use_graph:
+        L.b3gs_set_timing(C.byref(times))
     views = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        views += stepper.step(pair_grad_fn=grad_fn)
+        run_step()
+        views += 2 * len(pairs)
     barrier()
     t1 = time.perf_counter()
+    if use_graph:
+        L.b3gs_set_timing(C.byref(times))
+        for _ in range(min(args.steps, 5)):
+            stepper.step(pair_grad_fn=grad_fn)
+        barrier()
     L.b3gs_timing_collect()
     L.b3gs_set_timing(None)
     elapsed = t1 - t0
+    if fused is not None and fused.overflowed():
+        raise SystemExit("binning capacity overflow inside the timed region: result invalid")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +226,8 @@ def main():
                                    f"per rank per iter, fwd+bwd+grad all-reduce+Adam", "gaussians": P, "width": W,
                        "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
-                       "optimizer_in_step": opt is not None, "parallelism": f"dp{world} (views sharded, params replicated)"},
+                       "optimizer_in_step": opt is not None, "path": args.path, "hip_graph": bool(use_graph),
+                       "parallelism": f"dp{world} (views sharded, params replicated)"},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
             "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -30,6 +30,15 @@ class B3gsScene(C.Structure):
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
 
 
+class B3gsRawParams(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("features_dc", C.c_void_p), ("features_rest", C.c_void_p),
+                ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("opacity", C.c_void_p)]
+
+
+class B3gsRawGrads(C.Structure):
+    _fields_ = B3gsRawParams._fields_
+
+
 class B3gsDebugViews(C.Structure):
     _fields_ = [("tiles_touched", C.c_void_p), ("depths", C.c_void_p), ("records", C.c_void_p),
                 ("point_list", C.c_void_p), ("tile_ids", C.c_void_p), ("ranges", C.c_void_p),
@@ -44,7 +53,7 @@ class B3gsKernelTimes(C.Structure):
 # every symbol include/b3gs_raster.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timing_collect", "b3gs_geometry_bytes", "b3gs_image_bytes",
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
-           "b3gs_debug_views")
+           "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats")
 
 _lib = None
 
@@ -83,6 +92,15 @@ def lib():
     L.b3gs_backward.argtypes = [C.POINTER(B3gsScene), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]
     L.b3gs_backward.restype = C.c_int
+    L.b3gs_forward_raw.argtypes = [C.POINTER(B3gsScene), C.POINTER(B3gsRawParams), C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.b3gs_forward_raw.restype = C.c_int
+    L.b3gs_backward_scratch_floats.argtypes = [C.c_int32]
+    L.b3gs_backward_scratch_floats.restype = C.c_size_t
+    L.b3gs_backward_raw.argtypes = [C.POINTER(B3gsScene), C.POINTER(B3gsRawParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.POINTER(B3gsRawGrads), C.c_void_p, C.c_void_p]
+    L.b3gs_backward_raw.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int
     L.b3gs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

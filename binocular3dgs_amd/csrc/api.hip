@@ -43,6 +43,27 @@ int check_scene(const B3gsScene* sc) {
   return B3GS_OK;
 }
 
+SceneX wrap(const B3gsScene* sc) {
+  SceneX x;
+  x.sc = *sc;
+  x.raw = B3gsRawParams{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  x.raw_mode = 0;
+  return x;
+}
+
+int check_raw(const B3gsScene* sc, const B3gsRawParams* rp) {
+  if (!sc || !rp) return fail(B3GS_ERR_ARG, "%s", "scene / raw params NULL");
+  if (sc->P < 0 || sc->W <= 0 || sc->H <= 0) return fail(B3GS_ERR_ARG, "%s", "bad P/W/H");
+  if (sc->D < 0 || sc->D > 3 || sc->M < (sc->D + 1) * (sc->D + 1)) return fail(B3GS_ERR_ARG, "%s", "bad SH degree / M");
+  if (((sc->W + B3GS_TILE - 1) / B3GS_TILE) > 65535 || ((sc->H + B3GS_TILE - 1) / B3GS_TILE) > 65535)
+    return fail(B3GS_ERR_ARG, "%s", "image too large for the packed tile rect");
+  if (!sc->background || !sc->viewmatrix || !sc->projmatrix || !sc->campos) return fail(B3GS_ERR_ARG, "%s", "NULL camera tensor");
+  if (sc->P > 0 && (!rp->xyz || !rp->features_dc || (sc->M > 1 && !rp->features_rest) || !rp->scaling || !rp->rotation ||
+                    !rp->opacity))
+    return fail(B3GS_ERR_ARG, "%s", "NULL raw parameter tensor");
+  return B3GS_OK;
+}
+
 // optional per-stage timing (bench only): events bracket each stage on the caller's stream.
 // Nothing synchronises inside the call: the events are parked in a thread-local list and turned
 // into milliseconds by b3gs_timing_collect() after the caller has synchronised the stream.
@@ -138,7 +159,7 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
 
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(*sc, g, radii, s);
+  b3gs_launch_preprocess(wrap(sc), g, radii, s);
   if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
   tm.mark(0);
   b3gs_launch_depth_sort_and_scan(sc->P, g, s);
@@ -167,15 +188,13 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   return B3GS_OK;
 }
 
-int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, int64_t binning_capacity, char* image,
-                          float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                          int32_t* device_num_rendered, b3gs_stream_t stream) {
-  int rc = check_scene(sc);
-  if (rc) return rc;
+static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning, int64_t binning_capacity, char* image,
+                                 float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                                 int32_t* device_num_rendered, hipStream_t s) {
+  const B3gsScene* sc = &sx.sc;
   if (!geometry || !binning || !image || !out_color || !out_depth || !out_alpha || (sc->P > 0 && !radii) ||
       binning_capacity <= 0 || binning_capacity > 0xFFFFFFFFll)
     return fail(B3GS_ERR_ARG, "%s", "NULL buffer or bad capacity");
-  hipStream_t s = (hipStream_t)stream;
   GeomView g;
   ImgView im;
   BinView b;
@@ -184,7 +203,7 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
   b3gs_bin_view(binning, sc->P, binning_capacity, &b);
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(*sc, g, radii, s);
+  b3gs_launch_preprocess(sx, g, radii, s);
   tm.mark(0);
   b3gs_launch_depth_sort_and_scan(sc->P, g, s);
   HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
@@ -196,6 +215,69 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
   tm.mark(1);
   b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
   tm.mark(2);
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, int64_t binning_capacity, char* image,
+                          float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
+                          int32_t* device_num_rendered, b3gs_stream_t stream) {
+  int rc = check_scene(sc);
+  if (rc) return rc;
+  return forward_capacity_impl(wrap(sc), geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha,
+                               radii, device_num_rendered, (hipStream_t)stream);
+}
+
+int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
+                     int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
+                     int32_t* radii, int32_t* device_num_rendered, b3gs_stream_t stream) {
+  int rc = check_raw(view, params);
+  if (rc) return rc;
+  SceneX sx;
+  sx.sc = *view;
+  sx.raw = *params;
+  sx.raw_mode = 1;
+  return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
+                               device_num_rendered, (hipStream_t)stream);
+}
+
+size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)11 * (size_t)(P > 0 ? P : 0); }
+
+int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,
+                      const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
+                      const float* dL_dalpha, float* scratch, const B3gsRawGrads* grads, float* dL_dmeans2D,
+                      b3gs_stream_t stream) {
+  int rc = check_raw(view, params);
+  if (rc) return rc;
+  if (view->P == 0) return B3GS_OK;
+  if (!radii || !geometry || !binning || !image || !dL_dcolor || !scratch || !grads || !grads->xyz ||
+      !grads->features_dc || (view->M > 1 && !grads->features_rest) || !grads->scaling || !grads->rotation ||
+      !grads->opacity)
+    return fail(B3GS_ERR_ARG, "%s", "NULL required tensor in backward_raw");
+  hipStream_t s = (hipStream_t)stream;
+  SceneX sx;
+  sx.sc = *view;
+  sx.raw = *params;
+  sx.raw_mode = 1;
+  GeomView g;
+  ImgView im;
+  BinView b;
+  b3gs_geom_view(const_cast<char*>(geometry), view->P, &g);
+  b3gs_img_view(const_cast<char*>(image), view->W, view->H, &im);
+  b3gs_bin_view(const_cast<char*>(binning), view->P, 1, &b);  // only val[0] (offset 0) is read
+  // scratch layout (zero on entry, left zero on exit): conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
+  const size_t P = (size_t)view->P;
+  float* s_cov = scratch;
+  float* s_m2d = scratch + 4 * P;
+  float* s_col = scratch + 7 * P;
+  float* s_op = scratch + 10 * P;
+  StageTimer tm(s);
+  tm.mark(-1);
+  b3gs_launch_render_backward(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4, s);
+  tm.mark(3);
+  b3gs_launch_preprocess_backward(sx, g, radii, s_m2d, s_col, s_op, nullptr, s_cov, nullptr, nullptr, nullptr, grads,
+                                  dL_dmeans2D, s);
+  tm.mark(4);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }
@@ -234,11 +316,11 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
   HIP_TRY(hipMemsetAsync(dL_dcov3D, 0, P * 6 * sizeof(float), s));
   if (num_rendered != 0)
     b3gs_launch_render_backward(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
-                                dL_dcov3D, s);
+                                dL_dcov3D, 6, s);
   if ((rc = debug_sync(sc, s, "render backward"))) return rc;
   tm.mark(3);
-  b3gs_launch_preprocess_backward(*sc, g, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-                                  dL_dscales, dL_drotations, s);
+  b3gs_launch_preprocess_backward(wrap(sc), g, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
+                                  dL_dsh, dL_dscales, dL_drotations, nullptr, nullptr, s);
   if ((rc = debug_sync(sc, s, "preprocess backward"))) return rc;
   tm.mark(4);
   HIP_TRY(hipGetLastError());

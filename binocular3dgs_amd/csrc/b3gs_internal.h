@@ -107,14 +107,21 @@ static inline size_t b3gs_img_view(char* base, int32_t W, int32_t H, ImgView* v)
   return (size_t)(cur - base);
 }
 
+// scene + optional raw (pre-activation) parameters; raw_mode selects the fused-activation kernels
+struct SceneX {
+  B3gsScene sc;
+  B3gsRawParams raw;
+  int raw_mode;
+};
+
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
 
-void b3gs_launch_preprocess(const B3gsScene& sc, const GeomView& g, int32_t* radii, hipStream_t s);
-void b3gs_launch_preprocess_backward(const B3gsScene& sc, const GeomView& g, const int32_t* radii,
+void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, int32_t* radii, hipStream_t s);
+void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii,
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
-                                     float* dL_drotations, hipStream_t s);
+                                     float* dL_drotations, const B3gsRawGrads* rg, float* m2d_out, hipStream_t s);
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
                               hipStream_t s);
 
@@ -133,4 +140,4 @@ void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const Bi
 void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                  float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D,
-                                 hipStream_t s);
+                                 int cov_stride /* 6: [P,6] output doubles as scratch; 4: RAW scratch */, hipStream_t s);

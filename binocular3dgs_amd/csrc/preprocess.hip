@@ -46,16 +46,63 @@ __device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, fl
   R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
-__device__ __forceinline__ void cov3d_of(const B3gsScene& sc, int i, float c6[6]) {
-  if (sc.cov3D_precomp) {
+// RAW mode = the parameter accessors of scene/gaussian_model.py:95-115 fused into the kernels:
+// scales = exp(_scaling), rotations = normalize(_rotation) (F.normalize, eps 1e-12),
+// opacity = sigmoid(_opacity), features = cat(_features_dc, _features_rest).
+template <bool RAW>
+__device__ __forceinline__ void load_scale_rot(const SceneX& sx_, int i, float s[3], float q[4], float* inv_norm) {
+  if (RAW) {
+    const float* ls = sx_.raw.scaling + 3 * (size_t)i;
+    s[0] = expf(ls[0]); s[1] = expf(ls[1]); s[2] = expf(ls[2]);
+    const float4 r = reinterpret_cast<const float4*>(sx_.raw.rotation)[i];
+    const float n = sqrtf(((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w);
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    q[0] = r.x * inv; q[1] = r.y * inv; q[2] = r.z * inv; q[3] = r.w * inv;
+    *inv_norm = inv;
+  } else {
+    const float* ps = sx_.sc.scales + 3 * (size_t)i;
+    s[0] = ps[0]; s[1] = ps[1]; s[2] = ps[2];
+    const float4 r = reinterpret_cast<const float4*>(sx_.sc.rotations)[i];
+    q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w;
+    *inv_norm = 1.0f;
+  }
+}
+template <bool RAW>
+__device__ __forceinline__ float load_opacity(const SceneX& sx_, int i) {
+  if (RAW) return 1.0f / (1.0f + expf(-sx_.raw.opacity[i]));
+  return sx_.sc.opacities[i];
+}
+// SH coefficient k, channel ch: [M][3] rows; in RAW mode row 0 lives in features_dc, rows 1.. in features_rest
+struct ShView {
+  const float* dc;
+  const float* rest;
+  __device__ __forceinline__ float operator()(int k, int ch) const { return k == 0 ? dc[ch] : rest[3 * (k - 1) + ch]; }
+};
+template <bool RAW>
+__device__ __forceinline__ ShView sh_view(const SceneX& sx_, int i) {
+  ShView v;
+  if (RAW) {
+    v.dc = sx_.raw.features_dc + 3 * (size_t)i;
+    v.rest = sx_.raw.features_rest + (size_t)3 * (sx_.sc.M - 1) * i;
+  } else {
+    v.dc = sx_.sc.shs + (size_t)3 * sx_.sc.M * i;
+    v.rest = v.dc + 3;
+  }
+  return v;
+}
+
+template <bool RAW>
+__device__ __forceinline__ void cov3d_of(const SceneX& sx_, int i, float c6[6]) {
+  const B3gsScene& sc = sx_.sc;
+  if (!RAW && sc.cov3D_precomp) {
 #pragma unroll
     for (int k = 0; k < 6; k++) c6[k] = sc.cov3D_precomp[6 * (size_t)i + k];
     return;
   }
-  const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
-  const float* s = sc.scales + 3 * (size_t)i;
+  float s[3], q[4], inv_norm;
+  load_scale_rot<RAW>(sx_, i, s, q, &inv_norm);
   float R[9], L[9];
-  quat_to_R(q.x, q.y, q.z, q.w, R);
+  quat_to_R(q[0], q[1], q[2], q[3], R);
   float sx = sc.scale_modifier * s[0], sy = sc.scale_modifier * s[1], sz = sc.scale_modifier * s[2];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -116,8 +163,8 @@ __device__ __forceinline__ int clampi_from_float(float v, int hi) {
 }
 
 // SH -> RGB for one channel; sh points at coefficient 0 of this Gaussian, stride 3 floats
-__device__ __forceinline__ float sh_eval(int deg, const float* __restrict__ sh, int ch, float x, float y, float z) {
-#define SH(k) sh[3 * (k) + ch]
+__device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, float x, float y, float z) {
+#define SH(k) sh(k, ch)
   float r = SH_C0 * SH(0);
   if (deg > 0) {
     r = ((r - SH_C1 * y * SH(1)) + SH_C1 * z * SH(2)) - SH_C1 * x * SH(3);
@@ -140,9 +187,12 @@ __device__ __forceinline__ float sh_eval(int deg, const float* __restrict__ sh, 
   return r;
 }
 
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomView g, int32_t* __restrict__ radii) {
+template <bool RAW>
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(SceneX sx_, GeomView g, int32_t* __restrict__ radii) {
+  const B3gsScene& sc = sx_.sc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sc.P) return;
+  const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sc.means3D;
   const Mat16 vm = load_mat(sc.viewmatrix);
   const Mat16 pm = load_mat(sc.projmatrix);
 
@@ -150,7 +200,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
   uint32_t touched = 0, dkey = 0xFFFFFFFFu, clamp_bits = 0;
   uint2 rect = make_uint2(0, 0);
 
-  const float px3 = sc.means3D[3 * (size_t)i], py3 = sc.means3D[3 * (size_t)i + 1], pz3 = sc.means3D[3 * (size_t)i + 2];
+  const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
   float pv[3];
   pv[0] = ((vm.m[0] * px3 + vm.m[4] * py3) + vm.m[8] * pz3) + vm.m[12];
   pv[1] = ((vm.m[1] * px3 + vm.m[5] * py3) + vm.m[9] * pz3) + vm.m[13];
@@ -164,7 +214,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
     float ppx = hx * pw, ppy = hy * pw;
 
     float c6[6];
-    cov3d_of(sc, i, c6);
+    cov3d_of<RAW>(sx_, i, c6);
     const float fx = (float)sc.W / (2.0f * sc.tan_fovx), fy = (float)sc.H / (2.0f * sc.tan_fovy);
     Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
     float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
@@ -186,7 +236,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
       int area = (x1 - x0) * (y1 - y0);
       if (area != 0) {
         float rgb[3];
-        if (sc.colors_precomp) {
+        if (!RAW && sc.colors_precomp) {
           rgb[0] = sc.colors_precomp[3 * (size_t)i];
           rgb[1] = sc.colors_precomp[3 * (size_t)i + 1];
           rgb[2] = sc.colors_precomp[3 * (size_t)i + 2];
@@ -194,7 +244,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
           float dx = px3 - sc.campos[0], dy = py3 - sc.campos[1], dz = pz3 - sc.campos[2];
           float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
           dx = dx * inv; dy = dy * inv; dz = dz * inv;
-          const float* sh = sc.shs + (size_t)3 * sc.M * i;
+          const ShView sh = sh_view<RAW>(sx_, i);
 #pragma unroll
           for (int ch = 0; ch < 3; ch++) {
             float v = sh_eval(sc.D, sh, ch, dx, dy, dz) + 0.5f;
@@ -202,7 +252,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
             rgb[ch] = fmaxf(v, 0.0f);
           }
         }
-        const float op = sc.opacities[i];
+        const float op = load_opacity<RAW>(sx_, i);
         // conservative half-extents of the region where op*G >= 1/255 (G <= 1): used by the blend
         // kernels to skip whole 8x8 pixel quadrants; never changes which pixels contribute
         float ext_x = -1.0e30f, ext_y = -1.0e30f;
@@ -234,17 +284,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(B3gsScene sc, GeomV
 // backward: one lane per Gaussian.  Inputs are the fp32 sums the blend backward accumulated:
 //   dL_dmeans2D[i] = (gx, gy, 0)   dL_dcolors[i]   dL_dopacity[i]
 //   dL_dcov3D[i]   = (g_conic_xx, g_conic_xy(half), g_conic_yy, g_depth, -, -)   (scratch use)
-// and every output row is overwritten with its final value.
+// Standard mode: every output row is overwritten with its final value (culled rows = 0).
+// RAW mode: the four arrays above are a caller-owned scratch that is read and reset to zero here
+// (so it is clean for the next view without a memset), the chain rule continues through the
+// fused activations and the results are ACCUMULATED (+=) into the parameter-shaped gradient
+// buffers `rg` -- one owner thread per Gaussian, so plain read-modify-write; culled Gaussians
+// touch nothing.  `m2d_out` (optional, [P,3]) receives the screen-space mean gradient.
 // ------------------------------------------------------------------------------------------
+template <bool RAW>
 __global__ void __launch_bounds__(256)
-    preprocess_bwd_kernel(B3gsScene sc, GeomView g, const int32_t* __restrict__ radii, float* __restrict__ dL_dmeans2D,
+    preprocess_bwd_kernel(SceneX sx_, GeomView g, const int32_t* __restrict__ radii, float* __restrict__ dL_dmeans2D,
                           float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
                           float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots) {
+                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, B3gsRawGrads rg,
+                          float* __restrict__ m2d_out) {
+  const B3gsScene& sc = sx_.sc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sc.P) return;
   const size_t i3 = 3 * (size_t)i;
   if (radii[i] <= 0) {
+    if (RAW) {
+      if (m2d_out) { m2d_out[i3] = 0.f; m2d_out[i3 + 1] = 0.f; m2d_out[i3 + 2] = 0.f; }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) { dL_dmeans2D[i3 + k] = 0.f; dL_dcolors[i3 + k] = 0.f; dL_dmeans3D[i3 + k] = 0.f; }
 #pragma unroll
@@ -257,13 +319,25 @@ __global__ void __launch_bounds__(256)
   }
   const Mat16 vm = load_mat(sc.viewmatrix);
   const Mat16 pm = load_mat(sc.projmatrix);
-  const float mx3 = sc.means3D[i3], my3 = sc.means3D[i3 + 1], mz3 = sc.means3D[i3 + 2];
+  const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sc.means3D;
+  const float mx3 = means3D[i3], my3 = means3D[i3 + 1], mz3 = means3D[i3 + 2];
 
   const float g2x = dL_dmeans2D[i3], g2y = dL_dmeans2D[i3 + 1];
-  dL_dmeans2D[i3 + 2] = 0.f;
-  const float gxx = dL_dcov3D[6 * (size_t)i + 0], gxy = dL_dcov3D[6 * (size_t)i + 1], gyy = dL_dcov3D[6 * (size_t)i + 2];
-  const float gdepth = dL_dcov3D[6 * (size_t)i + 3];
+  // conic / depth sums: rows of 6 floats in standard mode (dL_dcov3D doubles as scratch), of 4 in RAW mode
+  const size_t cs = RAW ? 4 : 6;
+  const float gxx = dL_dcov3D[cs * i + 0], gxy = dL_dcov3D[cs * i + 1], gyy = dL_dcov3D[cs * i + 2];
+  const float gdepth = dL_dcov3D[cs * i + 3];
   const float gcol[3] = {dL_dcolors[i3], dL_dcolors[i3 + 1], dL_dcolors[i3 + 2]};
+  const float gop = dL_dopacity[i];
+  if (RAW) {  // leave the scratch clean for the next view
+    dL_dmeans2D[i3] = 0.f; dL_dmeans2D[i3 + 1] = 0.f;
+    dL_dcolors[i3] = 0.f; dL_dcolors[i3 + 1] = 0.f; dL_dcolors[i3 + 2] = 0.f;
+    dL_dopacity[i] = 0.f;
+    reinterpret_cast<float4*>(dL_dcov3D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // [P,4] in RAW mode
+    if (m2d_out) { m2d_out[i3] = g2x; m2d_out[i3 + 1] = g2y; m2d_out[i3 + 2] = 0.f; }
+  } else {
+    dL_dmeans2D[i3 + 2] = 0.f;
+  }
 
   float pv[3];
   pv[0] = ((vm.m[0] * mx3 + vm.m[4] * my3) + vm.m[8] * mz3) + vm.m[12];
@@ -271,7 +345,7 @@ __global__ void __launch_bounds__(256)
   pv[2] = ((vm.m[2] * mx3 + vm.m[6] * my3) + vm.m[10] * mz3) + vm.m[14];
 
   float c6[6];
-  cov3d_of(sc, i, c6);
+  cov3d_of<RAW>(sx_, i, c6);
   const float fx = (float)sc.W / (2.0f * sc.tan_fovx), fy = (float)sc.H / (2.0f * sc.tan_fovy);
   const Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
   const float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
@@ -292,8 +366,10 @@ __global__ void __launch_bounds__(256)
   dS[1] = 2.f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.f * T1[0] * T1[1] * dL_dc;
   dS[2] = 2.f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.f * T1[0] * T1[2] * dL_dc;
   dS[4] = 2.f * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.f * T1[1] * T1[2] * dL_dc;
+  if (!RAW) {
 #pragma unroll
-  for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dS[k];
+  }
 
   // dL/dT, then through T = J Wr to the view-space position
   const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
@@ -334,9 +410,10 @@ __global__ void __launch_bounds__(256)
   for (int k = 0; k < 3; k++) dmean[k] += vm.m[4 * k + 2] * gdepth;
 
   // colour: SH coefficients and view direction
-  if (!sc.colors_precomp && dL_dsh) {
-    const float* sh = sc.shs + (size_t)3 * sc.M * i;
-    float* dsh = dL_dsh + (size_t)3 * sc.M * i;
+  if (RAW || (!sc.colors_precomp && dL_dsh)) {
+    const ShView sh = sh_view<RAW>(sx_, i);
+    float* dsh_dc = RAW ? rg.features_dc + i3 : dL_dsh + (size_t)3 * sc.M * i;
+    float* dsh_rest = RAW ? rg.features_rest + (size_t)3 * (sc.M - 1) * i : dsh_dc + 3;
     float ddx = mx3 - sc.campos[0], ddy = my3 - sc.campos[1], ddz = mz3 - sc.campos[2];
     float inv = 1.0f / sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
     const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
@@ -344,39 +421,44 @@ __global__ void __launch_bounds__(256)
     float gdir[3] = {0.f, 0.f, 0.f};
     const int deg = sc.D;
     const int nb = (deg + 1) * (deg + 1);
-    for (int k = nb; k < sc.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+    if (!RAW)
+      for (int k = nb; k < sc.M; k++) { dsh_rest[3 * (k - 1)] = 0.f; dsh_rest[3 * (k - 1) + 1] = 0.f; dsh_rest[3 * (k - 1) + 2] = 0.f; }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       const float gl = ((cb >> ch) & 1u) ? 0.f : gcol[ch];
-#define SH(k) sh[3 * (k) + ch]
-#define DSH(k) dsh[3 * (k) + ch]
-      DSH(0) = SH_C0 * gl;
+#define SH(k) sh(k, ch)
+#define DSH(k, v)                                          \
+  do {                                                     \
+    float* dst_ = ((k) == 0) ? dsh_dc + ch : dsh_rest + 3 * ((k)-1) + ch; \
+    if (RAW) *dst_ += (v); else *dst_ = (v);               \
+  } while (0)
+      DSH(0, SH_C0 * gl);
       float rx = 0.f, ry = 0.f, rz = 0.f;
       if (deg > 0) {
-        DSH(1) = -SH_C1 * y * gl;
-        DSH(2) = SH_C1 * z * gl;
-        DSH(3) = -SH_C1 * x * gl;
+        DSH(1, -SH_C1 * y * gl);
+        DSH(2, SH_C1 * z * gl);
+        DSH(3, -SH_C1 * x * gl);
         rx = -SH_C1 * SH(3);
         ry = -SH_C1 * SH(1);
         rz = SH_C1 * SH(2);
         if (deg > 1) {
           float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-          DSH(4) = SH_C2[0] * xy * gl;
-          DSH(5) = SH_C2[1] * yz * gl;
-          DSH(6) = SH_C2[2] * (2.f * zz - xx - yy) * gl;
-          DSH(7) = SH_C2[3] * xz * gl;
-          DSH(8) = SH_C2[4] * (xx - yy) * gl;
+          DSH(4, SH_C2[0] * xy * gl);
+          DSH(5, SH_C2[1] * yz * gl);
+          DSH(6, SH_C2[2] * (2.f * zz - xx - yy) * gl);
+          DSH(7, SH_C2[3] * xz * gl);
+          DSH(8, SH_C2[4] * (xx - yy) * gl);
           rx += SH_C2[0] * y * SH(4) + SH_C2[2] * 2.f * -x * SH(6) + SH_C2[3] * z * SH(7) + SH_C2[4] * 2.f * x * SH(8);
           ry += SH_C2[0] * x * SH(4) + SH_C2[1] * z * SH(5) + SH_C2[2] * 2.f * -y * SH(6) + SH_C2[4] * 2.f * -y * SH(8);
           rz += SH_C2[1] * y * SH(5) + SH_C2[2] * 4.f * z * SH(6) + SH_C2[3] * x * SH(7);
           if (deg > 2) {
-            DSH(9) = SH_C3[0] * y * (3.f * xx - yy) * gl;
-            DSH(10) = SH_C3[1] * xy * z * gl;
-            DSH(11) = SH_C3[2] * y * (4.f * zz - xx - yy) * gl;
-            DSH(12) = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gl;
-            DSH(13) = SH_C3[4] * x * (4.f * zz - xx - yy) * gl;
-            DSH(14) = SH_C3[5] * z * (xx - yy) * gl;
-            DSH(15) = SH_C3[6] * x * (xx - 3.f * yy) * gl;
+            DSH(9, SH_C3[0] * y * (3.f * xx - yy) * gl);
+            DSH(10, SH_C3[1] * xy * z * gl);
+            DSH(11, SH_C3[2] * y * (4.f * zz - xx - yy) * gl);
+            DSH(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gl);
+            DSH(13, SH_C3[4] * x * (4.f * zz - xx - yy) * gl);
+            DSH(14, SH_C3[5] * z * (xx - yy) * gl);
+            DSH(15, SH_C3[6] * x * (xx - 3.f * yy) * gl);
             rx += SH_C3[0] * SH(9) * 6.f * xy + SH_C3[1] * SH(10) * yz + SH_C3[2] * SH(11) * -2.f * xy +
                   SH_C3[3] * SH(12) * -6.f * xz + SH_C3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
                   SH_C3[5] * SH(14) * 2.f * xz + SH_C3[6] * SH(15) * 3.f * (xx - yy);
@@ -400,20 +482,29 @@ __global__ void __launch_bounds__(256)
     dmean[1] += (gdir[1] - y * dot) * inv;
     dmean[2] += (gdir[2] - z * dot) * inv;
   }
-  dL_dmeans3D[i3] = dmean[0];
-  dL_dmeans3D[i3 + 1] = dmean[1];
-  dL_dmeans3D[i3 + 2] = dmean[2];
+  if (RAW) {
+    rg.xyz[i3] += dmean[0];
+    rg.xyz[i3 + 1] += dmean[1];
+    rg.xyz[i3 + 2] += dmean[2];
+    // opacity = sigmoid(o):  d/do = op (1 - op)
+    const float op = load_opacity<true>(sx_, i);
+    rg.opacity[i] += gop * op * (1.0f - op);
+  } else {
+    dL_dmeans3D[i3] = dmean[0];
+    dL_dmeans3D[i3 + 1] = dmean[1];
+    dL_dmeans3D[i3 + 2] = dmean[2];
+  }
 
   // Sigma = L L^T, L = R diag(mod*s)
-  if (!sc.cov3D_precomp && dL_dscales && dL_drots) {
-    const float4 q = reinterpret_cast<const float4*>(sc.rotations)[i];
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
+  if (RAW || (!sc.cov3D_precomp && dL_dscales && dL_drots)) {
+    float sraw[3], q[4], inv_norm;
+    load_scale_rot<RAW>(sx_, i, sraw, q, &inv_norm);
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
     float R[9];
     quat_to_R(r, x, y, z, R);
-    const float sv[3] = {sc.scale_modifier * sc.scales[i3], sc.scale_modifier * sc.scales[i3 + 1],
-                         sc.scale_modifier * sc.scales[i3 + 2]};
+    const float sv[3] = {sc.scale_modifier * sraw[0], sc.scale_modifier * sraw[1], sc.scale_modifier * sraw[2]};
     const float G[9] = {dS[0], 0.5f * dS[1], 0.5f * dS[2], 0.5f * dS[1], dS[3], 0.5f * dS[4], 0.5f * dS[2], 0.5f * dS[4], dS[5]};
-    float dR[9];
+    float dR[9], dscale[3];
 #pragma unroll
     for (int bcol = 0; bcol < 3; bcol++) {
       float ds = 0.f;
@@ -424,14 +515,32 @@ __global__ void __launch_bounds__(256)
         ds += dLab * R[3 * arow + bcol];
         dR[3 * arow + bcol] = dLab * sv[bcol];
       }
-      dL_dscales[i3 + bcol] = ds * sc.scale_modifier;
+      dscale[bcol] = ds * sc.scale_modifier;
     }
     float4 dq;
     dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
     dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
     dq.z = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
     dq.w = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
-    reinterpret_cast<float4*>(dL_drots)[i] = dq;
+    if (RAW) {
+      // scales = exp(s): d/ds = scale;   q = v/|v|: d/dv = (dq - q (q.dq)) / |v|
+      rg.scaling[i3] += dscale[0] * sraw[0];
+      rg.scaling[i3 + 1] += dscale[1] * sraw[1];
+      rg.scaling[i3 + 2] += dscale[2] * sraw[2];
+      const float qd = ((q[0] * dq.x + q[1] * dq.y) + q[2] * dq.z) + q[3] * dq.w;
+      float4* dst = reinterpret_cast<float4*>(rg.rotation) + i;
+      float4 cur = *dst;
+      cur.x += (dq.x - q[0] * qd) * inv_norm;
+      cur.y += (dq.y - q[1] * qd) * inv_norm;
+      cur.z += (dq.z - q[2] * qd) * inv_norm;
+      cur.w += (dq.w - q[3] * qd) * inv_norm;
+      *dst = cur;
+    } else {
+      dL_dscales[i3] = dscale[0];
+      dL_dscales[i3 + 1] = dscale[1];
+      dL_dscales[i3 + 2] = dscale[2];
+      reinterpret_cast<float4*>(dL_drots)[i] = dq;
+    }
   }
 }
 
@@ -446,17 +555,26 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
-void b3gs_launch_preprocess(const B3gsScene& sc, const GeomView& g, int32_t* radii, hipStream_t s) {
-  if (sc.P <= 0) return;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((sc.P + 255) / 256), dim3(256), 0, s, sc, g, radii);
+void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, int32_t* radii, hipStream_t s) {
+  if (sx.sc.P <= 0) return;
+  const dim3 grid((sx.sc.P + 255) / 256);
+  if (sx.raw_mode) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, grid, dim3(256), 0, s, sx, g, radii);
+  else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii);
 }
 
-void b3gs_launch_preprocess_backward(const B3gsScene& sc, const GeomView& g, const int32_t* radii, float* dL_dmeans2D,
+void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii, float* dL_dmeans2D,
                                      float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
-                                     float* dL_dsh, float* dL_dscales, float* dL_drotations, hipStream_t s) {
-  if (sc.P <= 0) return;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((sc.P + 255) / 256), dim3(256), 0, s, sc, g, radii, dL_dmeans2D,
-                     dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations);
+                                     float* dL_dsh, float* dL_dscales, float* dL_drotations, const B3gsRawGrads* rg,
+                                     float* m2d_out, hipStream_t s) {
+  if (sx.sc.P <= 0) return;
+  const dim3 grid((sx.sc.P + 255) / 256);
+  B3gsRawGrads none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (sx.raw_mode)
+    hipLaunchKernelGGL(preprocess_bwd_kernel<true>, grid, dim3(256), 0, s, sx, g, radii, dL_dmeans2D, dL_dcolors,
+                       dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, *rg, m2d_out);
+  else
+    hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii, dL_dmeans2D, dL_dcolors,
+                       dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, none, m2d_out);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

@@ -14,16 +14,16 @@
 //    The footprint test is conservative, so the per-pixel arithmetic, skip rules and
 //    n_contrib are exactly those of the sequential algorithm (oracle/tile_ref.c).
 //  * record fields are read from LDS with broadcast ds_read_b128 (all lanes, one address)
-//  * backward: lanes hold per-pixel partials; a 6-step DPP reduction folds the 64 lanes, the
-//    four quadrant waves merge in LDS (ds_add_f32) and each (tile, Gaussian) issues ONE set of
+//  * backward: lanes hold per-pixel partials; a 4-step DPP reduction folds each 16-lane row, rows and
+//    the four quadrant waves merge in LDS (ds_add_f32) and each (tile, Gaussian) issues ONE set of
 //    global atomics instead of one per pixel
 //  * workgroup -> tile map keeps raster-adjacent tiles (which share Gaussians) on one XCD's L2
 #include "b3gs_internal.h"
+#include <cstdlib>
 
 namespace {
 
 typedef unsigned long long u64;
-constexpr int CHUNK = 256;
 
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -46,32 +46,35 @@ __device__ __forceinline__ float dpp_add(float v) {
   int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
   return v + __int_as_float(t);
 }
-// sum over the 64 lanes; the total is valid in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+// sum within each row of 16 lanes (4 DPP steps, each folds into one v_add_f32_dpp); afterwards
+// EVERY lane holds its row's sum, so one lane per row (4 per wave) carries a partial total
+__device__ __forceinline__ float row16_sum(float v) {
   v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
   v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);  // row_mirror        -> every lane holds its row-of-16 sum
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 into rows 2,3 -> lane 63 = total
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror
   return v;
 }
 
+// CHUNK = Gaussians staged per round (a multiple of 64, at most the 256 threads of the workgroup)
+template <int CHUNK>
 struct TileShared {
   float4 A[CHUNK];  // x, y, cxx, cxy
   float4 B[CHUNK];  // cyy, opacity, r, g
   float4 C[CHUNK];  // b, depth, -, -
-  u64 mask[4][4];   // [quadrant][producer wave]
+  u64 mask[4][CHUNK / 64];   // [quadrant][producer wave]
 };
 
 // Stage one chunk: lane `tid` fetches list entry (first + tid); returns the Gaussian id (or -1).
-__device__ __forceinline__ int stage_chunk(TileShared& sh, const uint32_t* __restrict__ point_list,
+template <int CHUNK>
+__device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t* __restrict__ point_list,
                                            const float4* __restrict__ rec, uint32_t first, uint32_t last,
                                            float tile_px, float tile_py) {
   const unsigned tid = threadIdx.x;
   const uint32_t idx = first + tid;
   int id = -1;
   bool hit[4] = {false, false, false, false};
+  if (CHUNK < 256 && tid >= (unsigned)CHUNK) return id;  // whole waves: wave-uniform exit
   if (idx < last) {
     id = (int)point_list[idx];
     const float4* r = rec + 4 * (size_t)id;
@@ -104,12 +107,13 @@ __device__ __forceinline__ float blend_power(const float4& A, float cyy, float d
   return __builtin_fmaf(-A.w * dx, dy, -0.5f * q);
 }
 
+template <int CHUNK>
 __global__ void __launch_bounds__(256)
     render_fwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                       const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                       float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha) {
-  __shared__ TileShared sh;
+  __shared__ TileShared<CHUNK> sh;
   const int tile = tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(256)
     __syncthreads();
     if (__ballot(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
 #pragma unroll 1
-    for (int pw = 0; pw < 4; pw++) {
+    for (int pw = 0; pw < CHUNK / 64; pw++) {
       u64 m = uniform_u64(sh.mask[w][pw]);
       while (m) {
         const int j = __builtin_ctzll(m);
@@ -176,13 +180,74 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
+// ---- backward -------------------------------------------------------------------------------
+// Cross-lane reduction is THE cost of this kernel: on gfx950 a DPP add issues at ~8 cycles per wave
+// (tools/ubench/valu_rate.hip: v_add_f32_dpp 8 cyc, v_permlane32_swap 8, plain fma/mul/min 2), so
+// the textbook 6-step butterfly over 10 gradient components costs ~480 cycles per Gaussian -- more
+// than twice the per-pixel arithmetic.  The partials are therefore TRANSPOSED THROUGH LDS instead:
+//   10 x ds_write_b32   row k of a per-wave [10][68]-float scratch <- component k of every lane
+//    4 x ds_read_b128   lane (k,part) = (lane>>2, lane&3) reads elements [16 part, 16 part+16) of
+//                       row k  (row stride 68 dwords: the 16-lane groups of ds_read_b128 hit 64
+//                       distinct banks, and the row writes are conflict free)
+//   15 plain adds + 2 quad DPP adds -> lanes 4k..4k+3 hold component k summed over the 64 pixels
+//    1 x global_atomic_add_f32 with 10 active lanes (lane 4k adds component k of this Gaussian)
+// i.e. ~60 LDS-pipe clocks and ~70 VALU cycles per Gaussian instead of ~480 VALU cycles, and no
+// accumulator tile, no second barrier phase: LDS holds only the staged chunk + 2.7 KB per wave.
+constexpr int RED_STRIDE = 68;
+
+template <int CHUNK>
 struct TileSharedBwd {
-  TileShared f;
+  TileShared<CHUNK> f;
   int id[CHUNK];
-  float acc[10][CHUNK];   // mean2D.x, mean2D.y, conic xx, xy(half), yy, opacity, r, g, b, depth
-  uint32_t touched[CHUNK];
+  float red[4][10 * RED_STRIDE];
 };
 
+struct BwdPixel {
+  float fpx, fpy, T, T_final, bg_dot, dCr, dCg, dCb, dD, dA, Br, Bg, Bb, Bd, Ba, half_w, half_h;
+  uint32_t last;
+};
+
+// Per-pixel reverse step for one Gaussian; writes this lane's 10 partial gradients to p[].
+// Branch-free: a lane the Gaussian does not touch uses alpha = G = 0, which leaves T and the
+// "behind" composites unchanged and makes every partial an exact zero.
+__device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const float4& B, float col_b, float depth,
+                                         float G, float alpha, bool live, float (&p)[10]) {
+  G = live ? G : 0.0f;
+  alpha = live ? alpha : 0.0f;
+  const float dx = A.x - px.fpx, dy = A.y - px.fpy;
+  // 1/(1-alpha): hardware reciprocal (1 ulp); alpha <= 0.99 keeps it well conditioned
+  const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
+  px.T = px.T * inv_one_m_a;
+  const float wgt = alpha * px.T;
+  const float dr = B.z - px.Br, dg = B.w - px.Bg, db = col_b - px.Bb, dd = depth - px.Bd, da = 1.0f - px.Ba;
+  float dL_da = dr * px.dCr;
+  dL_da = __builtin_fmaf(dg, px.dCg, dL_da);
+  dL_da = __builtin_fmaf(db, px.dCb, dL_da);
+  dL_da = __builtin_fmaf(dd, px.dD, dL_da);
+  dL_da = __builtin_fmaf(da, px.dA, dL_da);
+  px.Br = __builtin_fmaf(alpha, dr, px.Br);
+  px.Bg = __builtin_fmaf(alpha, dg, px.Bg);
+  px.Bb = __builtin_fmaf(alpha, db, px.Bb);
+  px.Bd = __builtin_fmaf(alpha, dd, px.Bd);
+  px.Ba = __builtin_fmaf(alpha, da, px.Ba);
+  dL_da = dL_da * px.T;
+  dL_da = __builtin_fmaf(-px.T_final * inv_one_m_a, px.bg_dot, dL_da);
+  const float dL_dG = B.y * dL_da;
+  const float gdx = G * dx, gdy = G * dy;
+  p[0] = dL_dG * (-gdx * A.z - gdy * A.w) * px.half_w;
+  p[1] = dL_dG * (-gdy * B.x - gdx * A.w) * px.half_h;
+  const float hx = -0.5f * gdx * dL_dG, hy = -0.5f * gdy * dL_dG;
+  p[2] = hx * dx;
+  p[3] = hx * dy;
+  p[4] = hy * dy;
+  p[5] = G * dL_da;
+  p[6] = wgt * px.dCr;
+  p[7] = wgt * px.dCg;
+  p[8] = wgt * px.dCb;
+  p[9] = wgt * px.dD;
+}
+
+template <int CHUNK>
 __global__ void __launch_bounds__(256)
     render_bwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
@@ -190,139 +255,116 @@ __global__ void __launch_bounds__(256)
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_img,
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                      float* __restrict__ dL_dcov3D) {
-  __shared__ TileSharedBwd sh;
+                      float* __restrict__ dL_dcov3D, unsigned cov_stride) {
+  __shared__ TileSharedBwd<CHUNK> sh;
+  __shared__ uint32_t s_max_last[4];
   const int tile = tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int px = tile_x * B3GS_TILE + (int)((w & 1) * 8 + (lane & 7));
-  const int py = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
-  const bool inside = px < W && py < H;
-  const float fpx = (float)px, fpy = (float)py;
+  const int ipx = tile_x * B3GS_TILE + (int)((w & 1) * 8 + (lane & 7));
+  const int ipy = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
+  const bool inside = ipx < W && ipy < H;
   const uint2 range = ranges[tile];
-  const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
 
-  uint32_t last = 0;
-  float T_final = 0.f, dCr = 0.f, dCg = 0.f, dCb = 0.f, dD = 0.f, dA = 0.f;
+  BwdPixel px;
+  px.fpx = (float)ipx;
+  px.fpy = (float)ipy;
+  px.half_w = 0.5f * (float)W;
+  px.half_h = 0.5f * (float)H;
+  px.last = 0;
+  px.T_final = 0.f;
+  px.dCr = px.dCg = px.dCb = px.dD = px.dA = 0.f;
   if (inside) {
-    const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
-    last = n_contrib[pix];
-    T_final = final_T[pix];
-    dCr = dL_dcolor[pix];
-    dCg = dL_dcolor[hw + pix];
-    dCb = dL_dcolor[2 * hw + pix];
-    if (dL_ddepth) dD = dL_ddepth[pix];
-    if (dL_dalpha_img) dA = dL_dalpha_img[pix];
+    const size_t pix = (size_t)ipy * W + ipx, hw = (size_t)H * W;
+    px.last = n_contrib[pix];
+    px.T_final = final_T[pix];
+    px.dCr = dL_dcolor[pix];
+    px.dCg = dL_dcolor[hw + pix];
+    px.dCb = dL_dcolor[2 * hw + pix];
+    if (dL_ddepth) px.dD = dL_ddepth[pix];
+    if (dL_dalpha_img) px.dA = dL_dalpha_img[pix];
   }
-  const float bg_dot = (bg[0] * dCr + bg[1] * dCg) + bg[2] * dCb;
-  float T = T_final;
-  float Br = 0.f, Bg = 0.f, Bb = 0.f, Bd = 0.f, Ba = 0.f;  // composite "behind" the current Gaussian
+  px.bg_dot = (bg[0] * px.dCr + bg[1] * px.dCg) + bg[2] * px.dCb;
+  px.T = px.T_final;
+  px.Br = px.Bg = px.Bb = px.Bd = px.Ba = 0.f;  // composite "behind" the current Gaussian
 
-  // deepest list position any pixel of the tile used
-  __shared__ uint32_t s_max_last[4];
+  // deepest list position any pixel of the quadrant / tile used
   {
-    uint32_t m = last;
+    uint32_t m = px.last;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     if (lane == 0) s_max_last[w] = m;
   }
-#pragma unroll
-  for (int k = 0; k < 10; k++) sh.acc[k][tid] = 0.f;
-  sh.touched[tid] = 0;
   __syncthreads();
   const uint32_t max_last = max(max(s_max_last[0], s_max_last[1]), max(s_max_last[2], s_max_last[3]));
   if (max_last == 0) return;
   const uint32_t wave_last = __builtin_amdgcn_readfirstlane(s_max_last[w]);
 
+  // reduction role of this lane: component k = lane>>2 (valid for k < 10), part = lane&3; the
+  // component's destination array, row stride (floats) and column
+  const unsigned rk = lane >> 2, rpart = lane & 3;
+  float* red_base;
+  unsigned red_stride, red_col;
+  if (rk < 2) { red_base = dL_dmeans2D; red_stride = 3; red_col = rk; }
+  else if (rk < 5) { red_base = dL_dcov3D; red_stride = cov_stride; red_col = rk - 2; }
+  else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; red_col = 0; }
+  else if (rk < 9) { red_base = dL_dcolors; red_stride = 3; red_col = rk - 6; }
+  else { red_base = dL_dcov3D; red_stride = cov_stride; red_col = 3; }
+  const bool red_writer = (rk < 10) && (rpart == 0);
+  float* const red = sh.red[w];
+  const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
+
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
     const int id = stage_chunk(sh.f, point_list, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
                                (float)(tile_y * B3GS_TILE));
-    sh.id[tid] = id;
+    if (tid < (unsigned)CHUNK) sh.id[tid] = id;
     __syncthreads();
-    if ((uint32_t)(c * CHUNK) < wave_last) {
 #pragma unroll 1
-      for (int pw = 3; pw >= 0; pw--) {
-        u64 m = uniform_u64(sh.f.mask[w][pw]);
-        while (m) {
-          const int j = 63 - __builtin_clzll(m);
-          m &= ~(1ull << j);
-          const int gidx = pw * 64 + j;
-          const uint32_t pos = (uint32_t)(c * CHUNK + gidx);
-          if (pos >= wave_last) continue;
-          const float4 A = sh.f.A[gidx];
-          const float4 B = sh.f.B[gidx];
-          const float4 Cc = sh.f.C[gidx];
-          const float dx = A.x - fpx, dy = A.y - fpy;
-          const float power = blend_power(A, B.x, dx, dy);
-          const float G = __expf(power);
-          const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);
-          const bool live = (pos < last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-          if (__ballot(live) == 0) continue;
-          float p[10];
+    for (int pw = CHUNK / 64 - 1; pw >= 0; pw--) {
+      const uint32_t base = (uint32_t)(c * CHUNK + pw * 64);
+      if (base >= wave_last) continue;
+      u64 m = uniform_u64(sh.f.mask[w][pw]);
+      const uint32_t lim = wave_last - base;  // positions >= wave_last were never reached by this quadrant
+      if (lim < 64) m &= (1ull << lim) - 1ull;
+      while (m) {
+        const int j = 63 - __builtin_clzll(m);
+        m &= ~(1ull << j);
+        const int gidx = pw * 64 + j;
+        const float4 A = sh.f.A[gidx];
+        const float4 B = sh.f.B[gidx];
+        const float power = blend_power(A, B.x, A.x - px.fpx, A.y - px.fpy);
+        const float G = __expf(power);
+        const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);
+        const bool live = (base + (uint32_t)j < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
+        if (__ballot(live) == 0) continue;
+        const float4 Cc = sh.f.C[gidx];
+        float p[10];
+        bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
+        // transpose through LDS (see the header of this section)
 #pragma unroll
-          for (int k = 0; k < 10; k++) p[k] = 0.f;
-          if (live) {
-            const float one_m_a = 1.0f - alpha;
-            T = T / one_m_a;
-            const float wgt = alpha * T;
-            float dr = B.z - Br, dg = B.w - Bg, db = Cc.x - Bb, dd = Cc.y - Bd, da = 1.0f - Ba;
-            float dL_da = dr * dCr;
-            dL_da = __builtin_fmaf(dg, dCg, dL_da);
-            dL_da = __builtin_fmaf(db, dCb, dL_da);
-            dL_da = __builtin_fmaf(dd, dD, dL_da);
-            dL_da = __builtin_fmaf(da, dA, dL_da);
-            Br = __builtin_fmaf(alpha, dr, Br);
-            Bg = __builtin_fmaf(alpha, dg, Bg);
-            Bb = __builtin_fmaf(alpha, db, Bb);
-            Bd = __builtin_fmaf(alpha, dd, Bd);
-            Ba = __builtin_fmaf(alpha, da, Ba);
-            dL_da = dL_da * T;
-            dL_da = __builtin_fmaf(-T_final / one_m_a, bg_dot, dL_da);
-            const float dL_dG = B.y * dL_da;
-            const float gdx = G * dx, gdy = G * dy;
-            p[0] = dL_dG * (-gdx * A.z - gdy * A.w) * half_w;
-            p[1] = dL_dG * (-gdy * B.x - gdx * A.w) * half_h;
-            p[2] = -0.5f * gdx * dx * dL_dG;
-            p[3] = -0.5f * gdx * dy * dL_dG;
-            p[4] = -0.5f * gdy * dy * dL_dG;
-            p[5] = G * dL_da;
-            p[6] = wgt * dCr;
-            p[7] = wgt * dCg;
-            p[8] = wgt * dCb;
-            p[9] = wgt * dD;
-          }
-#pragma unroll
-          for (int k = 0; k < 10; k++) p[k] = wave_sum_to_lane63(p[k]);
-          if (lane == 63) {
-#pragma unroll
-            for (int k = 0; k < 10; k++) atomicAdd(&sh.acc[k][gidx], p[k]);
-            sh.touched[gidx] = 1;
-          }
+        for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float4 q0 = red_rd[0], q1 = red_rd[1], q2 = red_rd[2], q3 = red_rd[3];
+        float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+        v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
+        v = dpp_add<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
+        v = dpp_add<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]  -> the 4 parts of component rk summed
+        if (red_writer) {
+          const size_t g = (size_t)sh.id[gidx];
+          unsafeAtomicAdd(red_base + g * red_stride + red_col, v);
         }
+        __builtin_amdgcn_wave_barrier();  // next Gaussian's row writes stay behind these reads
       }
-    }
-    __syncthreads();
-    // one set of global atomics per (tile, Gaussian)
-    if (sh.touched[tid]) {
-      const size_t g = (size_t)sh.id[tid];
-      unsafeAtomicAdd(&dL_dmeans2D[3 * g + 0], sh.acc[0][tid]);
-      unsafeAtomicAdd(&dL_dmeans2D[3 * g + 1], sh.acc[1][tid]);
-      unsafeAtomicAdd(&dL_dcov3D[6 * g + 0], sh.acc[2][tid]);
-      unsafeAtomicAdd(&dL_dcov3D[6 * g + 1], sh.acc[3][tid]);
-      unsafeAtomicAdd(&dL_dcov3D[6 * g + 2], sh.acc[4][tid]);
-      unsafeAtomicAdd(&dL_dopacity[g], sh.acc[5][tid]);
-      unsafeAtomicAdd(&dL_dcolors[3 * g + 0], sh.acc[6][tid]);
-      unsafeAtomicAdd(&dL_dcolors[3 * g + 1], sh.acc[7][tid]);
-      unsafeAtomicAdd(&dL_dcolors[3 * g + 2], sh.acc[8][tid]);
-      unsafeAtomicAdd(&dL_dcov3D[6 * g + 3], sh.acc[9][tid]);
-#pragma unroll
-      for (int k = 0; k < 10; k++) sh.acc[k][tid] = 0.f;
-      sh.touched[tid] = 0;
     }
     __syncthreads();
   }
 }
+
+constexpr int FWD_CHUNK = 256;
+constexpr int BWD_CHUNK = 64;
 
 }  // namespace
 
@@ -332,19 +374,26 @@ void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const Bi
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const int nblocks = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, b.val[0],
+  hipLaunchKernelGGL(render_fwd_kernel<FWD_CHUNK>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, b.val[0],
                      g.rec, sc.background, im.final_T, im.n_contrib, out_color, out_depth, out_alpha);
 }
 
 void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
                                  const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                                  float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D,
-                                 hipStream_t s) {
+                                 int cov_stride, hipStream_t s) {
   const int gx = (sc.W + B3GS_TILE - 1) / B3GS_TILE, gy = (sc.H + B3GS_TILE - 1) / B3GS_TILE;
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const int nblocks = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, b.val[0],
-                     g.rec, sc.background, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D,
-                     dL_dcolors, dL_dopacity, dL_dcov3D);
+  // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
+  static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
+#define B3GS_LAUNCH_BWD(C)                                                                                          \
+  hipLaunchKernelGGL(render_bwd_kernel<C>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges,      \
+                     b.val[0], g.rec, sc.background, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,     \
+                     dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (unsigned)cov_stride)
+  if (bwd_chunk == 256) B3GS_LAUNCH_BWD(256);
+  else if (bwd_chunk == 128) B3GS_LAUNCH_BWD(128);
+  else B3GS_LAUNCH_BWD(64);
+#undef B3GS_LAUNCH_BWD
 }

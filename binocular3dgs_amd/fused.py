@@ -1,0 +1,149 @@
+"""Fast path of the build's own training step: fused activations, persistent scratch, no host sync.
+
+`FusedRasterizer.render()` returns the same dict as the drop-in `render()` (render.py /
+gaussian_renderer/__init__.py:97-103) but goes through b3gs_forward_raw / b3gs_backward_raw:
+  * the parameter accessors of scene/gaussian_model.py:95-115 (exp / normalize / sigmoid / cat) and
+    their backward run inside the per-Gaussian HIP kernels -- no PyTorch elementwise kernels,
+  * gradients are accumulated (+=) directly into the `.grad` views of the flat gradient slab
+    (step.FlatGradSlab): no per-view AccumulateGrad adds, nothing to pack before the all-reduce,
+  * geometry / binning / image state lives in persistent per-slot buffers sized once (288 GB of HBM
+    make over-allocation free), N stays on the device: zero allocations and zero host syncs per
+    view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph).
+Results equal the drop-in path up to activation rounding (tests/test_gpu_fused.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class _Slot:
+    def __init__(self, P, W, H, capacity, dev, want_means2D):
+        L = _lib.lib()
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
+        self.binning = torch.empty(L.b3gs_binning_bytes(P, capacity), **u8)
+        self.img = torch.empty(L.b3gs_image_bytes(W, H), **u8)
+        self.capacity = capacity
+        f = dict(dtype=torch.float32, device=dev)
+        self.color = torch.empty((3, H, W), **f)
+        self.depth = torch.empty((1, H, W), **f)
+        self.alpha = torch.empty((1, H, W), **f)
+        self.radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.means2D_grad = torch.zeros((P, 3), **f) if want_means2D else None
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, owner, slot_idx, view):
+        owner._forward(slot_idx, view)
+        s = owner.slots[slot_idx]
+        ctx.owner, ctx.slot_idx, ctx.view = owner, slot_idx, view
+        ctx.mark_non_differentiable(s.radii)
+        return s.color, s.radii, s.depth, s.alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        ctx.owner._backward(ctx.slot_idx, ctx.view, g_color, g_depth, g_alpha)
+        # gradients were accumulated in place into the parameters' .grad (flat slab views)
+        return (None,) * 9
+
+
+class FusedRasterizer:
+    def __init__(self, model, width: int, height: int, num_slots: int = 2, binning_capacity: Optional[int] = None,
+                 want_means2D: bool = True):
+        self.model = model
+        self.W, self.H = int(width), int(height)
+        p = model.get_xyz
+        if not p.is_cuda:
+            raise _lib.B3gsError("FusedRasterizer needs the model on an MI355X (HIP) device")
+        self.dev = p.device
+        self.P = p.shape[0]
+        self.K = model._features_dc.shape[1] + model._features_rest.shape[1]
+        self.capacity = int(binning_capacity) if binning_capacity else max(4_000_000, 12 * self.P)
+        self.slots = [_Slot(self.P, self.W, self.H, self.capacity, self.dev, want_means2D) for _ in range(num_slots)]
+        L = _lib.lib()
+        self.scratch = torch.zeros(max(L.b3gs_backward_scratch_floats(self.P), 1), dtype=torch.float32, device=self.dev)
+        self._params = _lib.B3gsRawParams()
+        self._grads = _lib.B3gsRawGrads()
+
+    # ---- C-ABI calls ------------------------------------------------------------------------
+    def _scene(self, view) -> _lib.B3gsScene:
+        cam, bg, scaling_modifier, debug = view
+        m = self.model
+        return _lib.B3gsScene(self.P, int(m.active_sh_degree), int(self.K), self.W, self.H,
+                              math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scaling_modifier), 0,
+                              int(bool(debug)), bg.data_ptr(), None, None, None, None, None, None, None,
+                              cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(),
+                              cam.camera_center.data_ptr())
+
+    def _bind_params(self):
+        m, rp = self.model, self._params
+        rp.xyz, rp.features_dc = m._xyz.data_ptr(), m._features_dc.data_ptr()
+        rp.features_rest = m._features_rest.data_ptr() if m._features_rest.numel() else None
+        rp.scaling, rp.rotation, rp.opacity = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
+        return rp
+
+    def _forward(self, slot_idx, view):
+        L, s = _lib.lib(), self.slots[slot_idx]
+        sc = self._scene(view)
+        rc = L.b3gs_forward_raw(C.byref(sc), C.byref(self._bind_params()), s.geom.data_ptr(), s.binning.data_ptr(),
+                                s.capacity, s.img.data_ptr(), s.color.data_ptr(), s.depth.data_ptr(),
+                                s.alpha.data_ptr(), s.radii.data_ptr(), s.n_dev.data_ptr(),
+                                torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "b3gs_forward_raw")
+
+    def _backward(self, slot_idx, view, g_color, g_depth, g_alpha):
+        L, s, m = _lib.lib(), self.slots[slot_idx], self.model
+        sc = self._scene(view)
+        gr = self._grads
+        for name, p in (("xyz", m._xyz), ("features_dc", m._features_dc), ("features_rest", m._features_rest),
+                        ("scaling", m._scaling), ("rotation", m._rotation), ("opacity", m._opacity)):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            setattr(gr, name, p.grad.data_ptr() if p.numel() else None)
+        if g_color is None:
+            g_color = torch.zeros((3, self.H, self.W), dtype=torch.float32, device=self.dev)
+        gc = g_color.contiguous()
+        gd = None if g_depth is None else g_depth.contiguous()
+        ga = None if g_alpha is None else g_alpha.contiguous()
+        rc = L.b3gs_backward_raw(C.byref(sc), C.byref(self._bind_params()), s.radii.data_ptr(), s.geom.data_ptr(),
+                                 s.binning.data_ptr(), s.img.data_ptr(), gc.data_ptr(),
+                                 None if gd is None else gd.data_ptr(), None if ga is None else ga.data_ptr(),
+                                 self.scratch.data_ptr(), C.byref(gr),
+                                 None if s.means2D_grad is None else s.means2D_grad.data_ptr(),
+                                 torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(rc, "b3gs_backward_raw")
+
+    # ---- public -----------------------------------------------------------------------------
+    def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
+               debug: bool = False) -> dict:
+        """Same keys as render(); `viewspace_points_grad` ([P,3], filled by backward) replaces the
+        `.grad` of the reference's dummy `viewspace_points` tensor."""
+        m = self.model
+        view = (viewpoint_camera, bg_color, scaling_modifier, debug)
+        color, radii, depth, alpha = _RasterizeRaw.apply(m._xyz, m._features_dc, m._features_rest, m._scaling,
+                                                         m._rotation, m._opacity, self, slot, view)
+        s = self.slots[slot]
+        return {"render": color, "viewspace_points_grad": s.means2D_grad, "visibility_filter": radii > 0,
+                "radii": radii, "rendered_depth": depth, "rendered_alpha": alpha}
+
+    def num_rendered(self):
+        """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered
+        from a truncated list: call grow() and repeat the step."""
+        return [int(s.n_dev.item()) for s in self.slots]
+
+    def overflowed(self) -> bool:
+        return any(n > self.capacity for n in self.num_rendered())
+
+    def grow(self, factor: float = 1.5):
+        need = max(self.num_rendered() + [self.capacity])
+        self.capacity = int(need * factor)
+        for i in range(len(self.slots)):
+            self.slots[i] = _Slot(self.P, self.W, self.H, self.capacity, self.dev, self.slots[i].means2D_grad is not None)

@@ -74,7 +74,7 @@ class ViewShardedStep:
     """
 
     def __init__(self, model, pairs, bg: torch.Tensor, pipe: Optional[PipelineParams] = None, optimizer=None,
-                 average_over_world: bool = False, render_fn: Callable = render):
+                 average_over_world: bool = False, render_fn: Callable = render, fused=None):
         self.model = model
         self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]
         self.bg = bg
@@ -82,6 +82,11 @@ class ViewShardedStep:
         self.slab = FlatGradSlab(model.parameters())
         self.optimizer = optimizer
         self.average = average_over_world
+        self.fused = fused                # FusedRasterizer: fused activations + persistent scratch
+        if fused is not None:
+            slot = iter(range(10 ** 9))
+            self._slots = [(next(slot), next(slot) if sc is not None else None) for _, sc, _ in self.pairs]
+            assert len(fused.slots) >= 2 * len(self.pairs), "FusedRasterizer needs one slot per view of the step"
         self.render = render_fn
         self.last_stats = {}
 
@@ -90,8 +95,13 @@ class ViewShardedStep:
         self.slab.zero()
         n_rendered = 0
         for i, (cam, scam, t) in enumerate(self.pairs):
-            pkg = self.render(cam, self.model, self.pipe, self.bg)
-            spkg = self.render(scam, self.model, self.pipe, self.bg) if scam is not None else None
+            if self.fused is not None:
+                a, b = self._slots[i]
+                pkg = self.fused.render(cam, self.bg, slot=a)
+                spkg = self.fused.render(scam, self.bg, slot=b) if scam is not None else None
+            else:
+                pkg = self.render(cam, self.model, self.pipe, self.bg)
+                spkg = self.render(scam, self.model, self.pipe, self.bg) if scam is not None else None
             n_rendered += 1 + (scam is not None)
             if loss_fn is not None:
                 loss_fn(i, cam, pkg, spkg, t).backward()

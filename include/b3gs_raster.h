@@ -111,6 +111,42 @@ int b3gs_backward(const B3gsScene* scene, int32_t num_rendered, const int32_t* r
                   float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drotations,
                   b3gs_stream_t stream);
 
+/* ---- fused-activation ("raw parameter") path ------------------------------------------------
+ * The reference computes the rasterizer's inputs with five small PyTorch kernels per view
+ * (scene/gaussian_model.py:95-115: exp, normalize, sigmoid, cat) and autograd adds five more in
+ * the backward plus one gradient-accumulation add per parameter per view.  These two entry
+ * points take the PRE-activation parameters, apply the activations inside the per-Gaussian
+ * kernels and accumulate (+=) the gradients straight into parameter-shaped buffers (e.g. views
+ * into one flat slab that is later all-reduced).  Same arithmetic, same outputs; not part of the
+ * reference's extension API -- used by the build's own training step. */
+typedef struct B3gsRawParams {
+  const float* xyz;            /* [P,3]                                   (GaussianModel._xyz) */
+  const float* features_dc;    /* [P,1,3]                                 (_features_dc) */
+  const float* features_rest;  /* [P,M-1,3] (may be NULL when M == 1)     (_features_rest) */
+  const float* scaling;        /* [P,3]  scales    = exp(scaling)         (_scaling) */
+  const float* rotation;       /* [P,4]  rotations = normalize(rotation)  (_rotation) */
+  const float* opacity;        /* [P,1]  opacity   = sigmoid(opacity)     (_opacity) */
+} B3gsRawParams;
+typedef struct B3gsRawGrads {  /* accumulated into (+=); same shapes as B3gsRawParams */
+  float* xyz; float* features_dc; float* features_rest; float* scaling; float* rotation; float* opacity;
+} B3gsRawGrads;
+
+/* Sync-free forward (see b3gs_forward_capacity) on raw parameters.  `view` supplies P, D, M (= total
+ * SH coefficients per channel), W, H, tan_fov*, scale_modifier, prefiltered, debug, background,
+ * viewmatrix, projmatrix, campos; its per-Gaussian tensor pointers are ignored. */
+int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
+                     int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
+                     int32_t* radii, int32_t* device_num_rendered, b3gs_stream_t stream);
+
+/* Backward of b3gs_forward_raw.  `scratch` holds b3gs_backward_scratch_floats(P) floats that must be
+ * ZERO on entry and are left zero on exit (persistent across views: no per-view memset).
+ * dL_dmeans2D ([P,3], optional) is overwritten with the screen-space mean gradients. */
+size_t b3gs_backward_scratch_floats(int32_t P);
+int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,
+                      const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
+                      const float* dL_dalpha, float* scratch, const B3gsRawGrads* grads, float* dL_dmeans2D,
+                      b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);
