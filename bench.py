@@ -226,6 +226,7 @@ def main():
                                    f"per rank per iter, fwd+bwd+grad all-reduce+Adam", "gaussians": P, "width": W,
                        "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
+                       "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
                        "optimizer_in_step": opt is not None, "path": args.path, "hip_graph": bool(use_graph),
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},

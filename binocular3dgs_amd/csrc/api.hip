@@ -5,6 +5,7 @@
 #include "b3gs_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -48,6 +49,7 @@ SceneX wrap(const B3gsScene* sc) {
   x.sc = *sc;
   x.raw = B3gsRawParams{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   x.raw_mode = 0;
+  x.tight = 0;
   return x;
 }
 
@@ -159,10 +161,10 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
 
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(wrap(sc), g, radii, s);
+  b3gs_launch_preprocess(wrap(sc), g, im, radii, s);
   if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
   tm.mark(0);
-  b3gs_launch_depth_sort_and_scan(sc->P, g, s);
+  b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, nullptr, s);
   if ((rc = debug_sync(sc, s, "depth sort + scan"))) return rc;
 
   // the one blocking read-back of the forward: N sizes the binning buffer
@@ -171,7 +173,6 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   HIP_TRY(hipStreamSynchronize(s));
   const int64_t N = (int64_t)hdr[0];
   if (host_num_rendered) *host_num_rendered = (int32_t)N;
-  HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
 
   char* bbuf = binning_alloc(binning_user, b3gs_binning_bytes(sc->P, N));
   if (!bbuf) return fail(B3GS_ERR_ALLOC, "%s", "binning allocation failed");
@@ -203,12 +204,9 @@ static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning
   b3gs_bin_view(binning, sc->P, binning_capacity, &b);
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(sx, g, radii, s);
+  b3gs_launch_preprocess(sx, g, im, radii, s);
   tm.mark(0);
-  b3gs_launch_depth_sort_and_scan(sc->P, g, s);
-  HIP_TRY(hipMemcpyAsync(im.header, g.header, 8, hipMemcpyDeviceToDevice, s));
-  if (device_num_rendered)
-    HIP_TRY(hipMemcpyAsync(device_num_rendered, g.header, 4, hipMemcpyDeviceToDevice, s));
+  b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, device_num_rendered, s);
   // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
   // list, which the caller detects from *device_num_rendered > capacity and repeats
   b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
@@ -237,6 +235,7 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
   sx.sc = *view;
   sx.raw = *params;
   sx.raw_mode = 1;
+  sx.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
   return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
                                device_num_rendered, (hipStream_t)stream);
 }
@@ -259,6 +258,7 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
   sx.sc = *view;
   sx.raw = *params;
   sx.raw_mode = 1;
+  sx.tight = 0;  // irrelevant in the backward
   GeomView g;
   ImgView im;
   BinView b;

@@ -51,6 +51,10 @@ struct ImgView {        // sized by W*H
 static inline size_t b3gs_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline uint32_t b3gs_sort_blocks(int64_t n) { return (uint32_t)((n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE); }
 
+// radix-sort scratch: 1280 header words (global digit histograms, tickets) + one status word per
+// (pass <= 4, workgroup, digit) for the chained scan; also covers the 3-launch variant's 256*(nblk+1)
+static inline size_t b3gs_sort_scratch_words(int64_t n) { return 1280 + (size_t)4 * 256 * (b3gs_sort_blocks(n) + 1); }
+
 // carve: if base == nullptr only the size is computed
 template <typename T>
 static inline T* b3gs_carve(char*& cur, size_t count) {
@@ -72,7 +76,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   for (int i = 0; i < 2; i++) t.skey[i] = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
   t.soffs = b3gs_carve<uint32_t>(cur, p);
-  t.hist = b3gs_carve<uint32_t>(cur, (size_t)256 * (b3gs_sort_blocks((int64_t)p) + 1));
+  t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
   if (v) *v = t;
   return (size_t)(cur - base);
@@ -88,7 +92,7 @@ static inline size_t b3gs_bin_view(char* base, int32_t P, int64_t N, BinView* v)
   t.key[0] = b3gs_carve<uint32_t>(cur, n);
   t.val[1] = b3gs_carve<uint32_t>(cur, n);
   t.key[1] = b3gs_carve<uint32_t>(cur, n);
-  t.hist = b3gs_carve<uint32_t>(cur, (size_t)256 * (b3gs_sort_blocks((int64_t)n) + 1));
+  t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)n));
   (void)P;
   if (v) *v = t;
   return (size_t)(cur - base);
@@ -112,12 +116,14 @@ struct SceneX {
   B3gsScene sc;
   B3gsRawParams raw;
   int raw_mode;
+  int tight;  // bin only the tiles the alpha >= 1/255 footprint can reach (fused path; see preprocess.hip)
 };
 
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
 
-void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, int32_t* radii, hipStream_t s);
+// also zeroes the tile ranges of `im` (the first `tiles` lanes of the launch do it)
+void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, const ImgView& im, int32_t* radii, hipStream_t s);
 void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii,
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
@@ -127,7 +133,9 @@ void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* view
 
 // depth sort of all P Gaussians (culled ones sink to the end), scan of tiles_touched in depth
 // order; leaves N in g.header[0] and V in g.header[1].  Result: sorted indices in g.sval[0].
-void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, hipStream_t s);
+// N is also written to img_header[0] and *n_out (device) when those are non-null.
+void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, uint32_t* img_header, int32_t* n_out,
+                                     hipStream_t s);
 // emit (tile, idx) instances in depth order, stable sort by tile id, tile ranges.
 // `n_bound` = number of instances the launch must cover (host-known N, or the capacity when N
 // lives only on the device; kernels clamp to the device-side N in g.header[0]).

@@ -188,9 +188,11 @@ __device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, floa
 }
 
 template <bool RAW>
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(SceneX sx_, GeomView g, int32_t* __restrict__ radii) {
+__global__ void __launch_bounds__(256)
+    preprocess_fwd_kernel(SceneX sx_, GeomView g, int32_t* __restrict__ radii, uint2* __restrict__ ranges, int ntiles) {
   const B3gsScene& sc = sx_.sc;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntiles) ranges[i] = make_uint2(0u, 0u);  // empty tiles keep [0,0): saves a memset launch
   if (i >= sc.P) return;
   const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sc.means3D;
   const Mat16 vm = load_mat(sc.viewmatrix);
@@ -260,6 +262,21 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(SceneX sx_, GeomVie
           float tau2 = 2.0f * logf(fmaxf(255.0f * op, 1.0f));
           ext_x = sqrtf(tau2 * a) * 1.001f + 0.05f;
           ext_y = sqrtf(tau2 * c) * 1.001f + 0.05f;
+        }
+        if (sx_.tight) {
+          // Tight binning (fused path): drop the tiles of the reference's 3-sigma square that the
+          // alpha >= 1/255 footprint cannot reach.  Tile t holds pixel centres [16t, 16t+15]; a
+          // dropped tile has no pixel inside the (conservative) footprint, so every one of its
+          // instances would have been skipped by the alpha < 1/255 rule: images and gradients are
+          // unchanged, only N and the lists shrink (order preserved).
+          const float T = (float)B3GS_TILE;
+          const int tx0 = clampi_from_float(ceilf((mx - ext_x - (T - 1.0f)) / T), gx);
+          const int tx1 = clampi_from_float(floorf((mx + ext_x) / T) + 1.0f, gx);
+          const int ty0 = clampi_from_float(ceilf((my - ext_y - (T - 1.0f)) / T), gy);
+          const int ty1 = clampi_from_float(floorf((my + ext_y) / T) + 1.0f, gy);
+          x0 = max(x0, tx0); x1 = max(x0, min(x1, tx1));
+          y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
+          area = (ext_x < 0.0f) ? 0 : (x1 - x0) * (y1 - y0);
         }
         float4* rec = g.rec + 4 * (size_t)i;
         rec[0] = make_float4(mx, my, cxx, cxy);
@@ -555,11 +572,13 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
-void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, int32_t* radii, hipStream_t s) {
-  if (sx.sc.P <= 0) return;
-  const dim3 grid((sx.sc.P + 255) / 256);
-  if (sx.raw_mode) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, grid, dim3(256), 0, s, sx, g, radii);
-  else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii);
+void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, const ImgView& im, int32_t* radii, hipStream_t s) {
+  const int ntiles = ((sx.sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sx.sc.H + B3GS_TILE - 1) / B3GS_TILE);
+  const int work = sx.sc.P > ntiles ? sx.sc.P : ntiles;
+  if (work <= 0) return;
+  const dim3 grid((work + 255) / 256);
+  if (sx.raw_mode) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, grid, dim3(256), 0, s, sx, g, radii, im.ranges, ntiles);
+  else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii, im.ranges, ntiles);
 }
 
 void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii, float* dL_dmeans2D,

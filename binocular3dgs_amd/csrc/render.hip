@@ -255,8 +255,11 @@ __global__ void __launch_bounds__(256)
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_img,
                       float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                      float* __restrict__ dL_dcov3D, unsigned cov_stride) {
+                      float* __restrict__ dL_dcov3D, unsigned cov_stride, unsigned long long* __restrict__ trace) {
   __shared__ TileSharedBwd<CHUNK> sh;
+  const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  unsigned n_iter = 0, n_live = 0;
   __shared__ uint32_t s_max_last[4];
   const int tile = tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
@@ -300,6 +303,11 @@ __global__ void __launch_bounds__(256)
   const uint32_t max_last = max(max(s_max_last[0], s_max_last[1]), max(s_max_last[2], s_max_last[3]));
   if (max_last == 0) return;
   const uint32_t wave_last = __builtin_amdgcn_readfirstlane(s_max_last[w]);
+  // Every wave of every tile is resident from the start and a wave is one serial chain, so the kernel
+  // ends with the longest chain: give waves with deeper lists issue priority over shorter ones.
+  if (wave_last > 400) __builtin_amdgcn_s_setprio(3);
+  else if (wave_last > 330) __builtin_amdgcn_s_setprio(2);
+  else if (wave_last > 260) __builtin_amdgcn_s_setprio(1);
 
   // reduction role of this lane: component k = lane>>2 (valid for k < 10), part = lane&3; the
   // component's destination array, row stride (floats) and column
@@ -315,6 +323,26 @@ __global__ void __launch_bounds__(256)
   float* const red = sh.red[w];
   const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
 
+  // Software pipeline across Gaussians (a wave is an in-order machine and every tile's waves are
+  // resident from the start, so the kernel's length is the longest wave's serial chain):
+  //   * the LDS row reads of Gaussian n's reduction are ISSUED right after its row writes but
+  //     CONSUMED (15 adds, 2 DPP, atomic) only after the evaluation of the next live Gaussian, so
+  //     the write->read round trip overlaps ~150 VALU instructions.  No double buffer is needed: a
+  //     wave's LDS operations complete in program order, so the pending reads capture their data
+  //     before the next Gaussian's row writes execute.
+  //   * the record of the next list entry is fetched before the current one is evaluated.
+  float4 q0, q1, q2, q3;      // pending reduction reads
+  size_t pend_g = 0;          // Gaussian they belong to
+  bool pending = false;
+#define B3GS_RETIRE_PENDING()                                                          \
+  do {                                                                                 \
+    float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));       \
+    v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));            \
+    v = dpp_add<0xB1, 0xF>(v); /* quad_perm [1,0,3,2] */                               \
+    v = dpp_add<0x4E, 0xF>(v); /* quad_perm [2,3,0,1] -> 4 parts of component rk */    \
+    if (red_writer) unsafeAtomicAdd(red_base + pend_g * red_stride + red_col, v);      \
+  } while (0)
+
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
     const int id = stage_chunk(sh.f, point_list, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
                                (float)(tile_y * B3GS_TILE));
@@ -327,43 +355,58 @@ __global__ void __launch_bounds__(256)
       u64 m = uniform_u64(sh.f.mask[w][pw]);
       const uint32_t lim = wave_last - base;  // positions >= wave_last were never reached by this quadrant
       if (lim < 64) m &= (1ull << lim) - 1ull;
-      while (m) {
-        const int j = 63 - __builtin_clzll(m);
-        m &= ~(1ull << j);
+      if (m == 0) continue;
+      int j = 63 - __builtin_clzll(m);
+      m &= ~(1ull << j);
+      float4 A = sh.f.A[pw * 64 + j], B = sh.f.B[pw * 64 + j];
+      while (true) {
+        // prefetch the next candidate of this round
+        const bool more = m != 0;
+        const int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
+        m &= ~(1ull << jn);
+        const float4 An = sh.f.A[pw * 64 + jn], Bn = sh.f.B[pw * 64 + jn];
         const int gidx = pw * 64 + j;
-        const float4 A = sh.f.A[gidx];
-        const float4 B = sh.f.B[gidx];
         const float power = blend_power(A, B.x, A.x - px.fpx, A.y - px.fpy);
         const float G = __expf(power);
         const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);
         const bool live = (base + (uint32_t)j < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-        if (__ballot(live) == 0) continue;
-        const float4 Cc = sh.f.C[gidx];
-        float p[10];
-        bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
-        // transpose through LDS (see the header of this section)
-#pragma unroll
-        for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float4 q0 = red_rd[0], q1 = red_rd[1], q2 = red_rd[2], q3 = red_rd[3];
-        float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
-        v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));
-        v = dpp_add<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
-        v = dpp_add<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]  -> the 4 parts of component rk summed
-        if (red_writer) {
+        n_iter++;
+        if (__ballot(live) != 0) {
+          n_live++;
+          const float4 Cc = sh.f.C[gidx];
           const size_t g = (size_t)sh.id[gidx];
-          unsafeAtomicAdd(red_base + g * red_stride + red_col, v);
+          float p[10];
+          bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
+#pragma unroll
+          for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
+          if (pending) B3GS_RETIRE_PENDING();
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];
+          pend_g = g;
+          pending = true;
         }
-        __builtin_amdgcn_wave_barrier();  // next Gaussian's row writes stay behind these reads
+        if (!more) break;
+        j = jn; A = An; B = Bn;
       }
     }
     __syncthreads();
   }
+  if (pending) B3GS_RETIRE_PENDING();
+#undef B3GS_RETIRE_PENDING
+  if (trace && lane == 0) {
+    unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
+    t[0] = __builtin_readcyclecounter() - t_start;            // shader cycles this wave lived
+    t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);  // 100 MHz wall clock: start | end
+    t[2] = n_iter;
+    t[3] = n_live;
+  }
 }
 
 constexpr int FWD_CHUNK = 256;
+unsigned long long* g_bwd_trace = nullptr;
+size_t g_bwd_trace_words = 0;
 constexpr int BWD_CHUNK = 64;
 
 }  // namespace
@@ -386,14 +429,29 @@ void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const B
   const int ntiles = gx * gy;
   if (ntiles <= 0) return;
   const int nblocks = ((ntiles + 7) / 8) * 8;
+  // B3GS_BWD_TRACE=1: per-wave {start, end, iterations, live iterations} cycle trace (tools/bwd_trace.py)
+  static const bool want_trace = getenv("B3GS_BWD_TRACE") != nullptr;
+  if (want_trace && !g_bwd_trace) {
+    (void)hipMalloc((void**)&g_bwd_trace, (size_t)nblocks * 16 * sizeof(unsigned long long));
+    g_bwd_trace_words = (size_t)nblocks * 16;
+  }
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
 #define B3GS_LAUNCH_BWD(C)                                                                                          \
   hipLaunchKernelGGL(render_bwd_kernel<C>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges,      \
                      b.val[0], g.rec, sc.background, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,     \
-                     dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (unsigned)cov_stride)
+                     dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (unsigned)cov_stride, g_bwd_trace)
   if (bwd_chunk == 256) B3GS_LAUNCH_BWD(256);
   else if (bwd_chunk == 128) B3GS_LAUNCH_BWD(128);
   else B3GS_LAUNCH_BWD(64);
 #undef B3GS_LAUNCH_BWD
+}
+
+// debug only: copy the last backward's per-wave cycle trace to the host (returns words copied)
+extern "C" size_t b3gs_debug_bwd_trace(unsigned long long* host, size_t max_words) {
+  if (!g_bwd_trace) return 0;
+  (void)hipDeviceSynchronize();
+  size_t n = g_bwd_trace_words < max_words ? g_bwd_trace_words : max_words;
+  (void)hipMemcpy(host, g_bwd_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  return n;
 }
