@@ -156,11 +156,18 @@ def main():
         views += 2 * len(pairs)
     barrier()
     t1 = time.perf_counter()
-    if use_graph:
+    if use_graph or (fused is not None and fused.concurrent):
+        # per-kernel durations need the kernels un-overlapped: a few eager iterations with the views
+        # rendered one after the other on one stream (same workload, same kernels), after the timed region
+        times = _lib.B3gsKernelTimes()
+        L.b3gs_timing_collect()
         L.b3gs_set_timing(C.byref(times))
+        was = fused.concurrent
+        fused.concurrent = False
         for _ in range(min(args.steps, 5)):
             stepper.step(pair_grad_fn=grad_fn)
         barrier()
+        fused.concurrent = was
     L.b3gs_timing_collect()
     L.b3gs_set_timing(None)
     elapsed = t1 - t0
@@ -228,6 +235,7 @@ def main():
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
                        "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
                        "optimizer_in_step": opt is not None, "path": args.path, "hip_graph": bool(use_graph),
+                       "view_streams": (len(fused.slots) if fused is not None and fused.concurrent else 1),
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
             "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),

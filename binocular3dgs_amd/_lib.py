@@ -99,7 +99,7 @@ def lib():
     L.b3gs_backward_scratch_floats.restype = C.c_size_t
     L.b3gs_backward_raw.argtypes = [C.POINTER(B3gsScene), C.POINTER(B3gsRawParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.POINTER(B3gsRawGrads), C.c_void_p, C.c_void_p]
+                                    C.POINTER(B3gsRawGrads), C.c_void_p, C.c_int, C.c_void_p]
     L.b3gs_backward_raw.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int

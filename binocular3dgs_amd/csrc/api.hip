@@ -245,7 +245,7 @@ size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)11 * (size_t)(P 
 int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,
                       const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
                       const float* dL_dalpha, float* scratch, const B3gsRawGrads* grads, float* dL_dmeans2D,
-                      b3gs_stream_t stream) {
+                      int phases, b3gs_stream_t stream) {
   int rc = check_raw(view, params);
   if (rc) return rc;
   if (view->P == 0) return B3GS_OK;
@@ -273,11 +273,16 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
   float* s_op = scratch + 10 * P;
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_render_backward(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4, s);
-  tm.mark(3);
-  b3gs_launch_preprocess_backward(sx, g, radii, s_m2d, s_col, s_op, nullptr, s_cov, nullptr, nullptr, nullptr, grads,
-                                  dL_dmeans2D, s);
-  tm.mark(4);
+  if (phases & 1) {
+    b3gs_launch_render_backward(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4, s);
+    tm.mark(3);
+  }
+  if (phases & 2) {
+    if (!(phases & 1)) tm.mark(-1);
+    b3gs_launch_preprocess_backward(sx, g, radii, s_m2d, s_col, s_op, nullptr, s_cov, nullptr, nullptr, nullptr, grads,
+                                    dL_dmeans2D, s);
+    tm.mark(4);
+  }
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }

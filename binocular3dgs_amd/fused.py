@@ -1,4 +1,5 @@
-"""Fast path of the build's own training step: fused activations, persistent scratch, no host sync.
+"""Fast path of the build's own training step: fused activations, persistent scratch, no host sync,
+views rendered concurrently on separate HIP streams.
 
 `FusedRasterizer.render()` returns the same dict as the drop-in `render()` (render.py /
 gaussian_renderer/__init__.py:97-103) but goes through b3gs_forward_raw / b3gs_backward_raw:
@@ -8,14 +9,19 @@ gaussian_renderer/__init__.py:97-103) but goes through b3gs_forward_raw / b3gs_b
     (step.FlatGradSlab): no per-view AccumulateGrad adds, nothing to pack before the all-reduce,
   * geometry / binning / image state lives in persistent per-slot buffers sized once (288 GB of HBM
     make over-allocation free), N stays on the device: zero allocations and zero host syncs per
-    view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph).
+    view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph),
+  * every slot owns a HIP stream: the views of an iteration are independent until their gradients
+    meet in the slab, and the binning kernels (a few hundred workgroups each) leave most of the 256
+    CUs idle, so running the 6 views of an iteration concurrently hides them behind other views'
+    blend kernels.  Autograd runs each view's backward on the stream its forward used; the
+    non-atomic `+=` into the shared slab is ordered across streams by an event chain.
 Results equal the drop-in path up to activation rounding (tests/test_gpu_fused.py).
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional
+from typing import List, Optional, Sequence
 
 import torch
 
@@ -23,7 +29,7 @@ from . import _lib
 
 
 class _Slot:
-    def __init__(self, P, W, H, capacity, dev, want_means2D):
+    def __init__(self, P, W, H, capacity, dev, want_means2D, scratch_floats, stream):
         L = _lib.lib()
         u8 = dict(dtype=torch.uint8, device=dev)
         self.geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
@@ -37,6 +43,8 @@ class _Slot:
         self.radii = torch.zeros((P,), dtype=torch.int32, device=dev)
         self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.means2D_grad = torch.zeros((P, 3), **f) if want_means2D else None
+        self.scratch = torch.zeros(max(scratch_floats, 1), **f)   # zero on entry / exit of every backward
+        self.stream = stream
 
 
 class _RasterizeRaw(torch.autograd.Function):
@@ -57,7 +65,7 @@ class _RasterizeRaw(torch.autograd.Function):
 
 class FusedRasterizer:
     def __init__(self, model, width: int, height: int, num_slots: int = 2, binning_capacity: Optional[int] = None,
-                 want_means2D: bool = True):
+                 want_means2D: bool = True, concurrent: bool = True):
         self.model = model
         self.W, self.H = int(width), int(height)
         p = model.get_xyz
@@ -67,11 +75,19 @@ class FusedRasterizer:
         self.P = p.shape[0]
         self.K = model._features_dc.shape[1] + model._features_rest.shape[1]
         self.capacity = int(binning_capacity) if binning_capacity else max(4_000_000, 12 * self.P)
-        self.slots = [_Slot(self.P, self.W, self.H, self.capacity, self.dev, want_means2D) for _ in range(num_slots)]
-        L = _lib.lib()
-        self.scratch = torch.zeros(max(L.b3gs_backward_scratch_floats(self.P), 1), dtype=torch.float32, device=self.dev)
+        self.concurrent = bool(concurrent)
+        self._want_m2d = want_means2D
+        self.slots: List[_Slot] = []
+        for _ in range(num_slots):
+            self.slots.append(self._new_slot(torch.cuda.Stream(self.dev) if self.concurrent else None))
+        self._acc_event: Optional[torch.cuda.Event] = None   # tail of the accumulate chain
         self._params = _lib.B3gsRawParams()
         self._grads = _lib.B3gsRawGrads()
+
+    def _new_slot(self, stream):
+        L = _lib.lib()
+        return _Slot(self.P, self.W, self.H, self.capacity, self.dev, self._want_m2d,
+                     L.b3gs_backward_scratch_floats(self.P), stream)
 
     # ---- C-ABI calls ------------------------------------------------------------------------
     def _scene(self, view) -> _lib.B3gsScene:
@@ -113,19 +129,30 @@ class FusedRasterizer:
         gc = g_color.contiguous()
         gd = None if g_depth is None else g_depth.contiguous()
         ga = None if g_alpha is None else g_alpha.contiguous()
-        rc = L.b3gs_backward_raw(C.byref(sc), C.byref(self._bind_params()), s.radii.data_ptr(), s.geom.data_ptr(),
-                                 s.binning.data_ptr(), s.img.data_ptr(), gc.data_ptr(),
-                                 None if gd is None else gd.data_ptr(), None if ga is None else ga.data_ptr(),
-                                 self.scratch.data_ptr(), C.byref(gr),
-                                 None if s.means2D_grad is None else s.means2D_grad.data_ptr(),
-                                 torch.cuda.current_stream(self.dev).cuda_stream)
-        _lib.check(rc, "b3gs_backward_raw")
+        stream = torch.cuda.current_stream(self.dev)   # autograd runs this node on the forward's stream
+
+        def call(phases):
+            rc = L.b3gs_backward_raw(C.byref(sc), C.byref(self._bind_params()), s.radii.data_ptr(), s.geom.data_ptr(),
+                                     s.binning.data_ptr(), s.img.data_ptr(), gc.data_ptr(),
+                                     None if gd is None else gd.data_ptr(), None if ga is None else ga.data_ptr(),
+                                     s.scratch.data_ptr(), C.byref(gr),
+                                     None if s.means2D_grad is None else s.means2D_grad.data_ptr(), phases,
+                                     stream.cuda_stream)
+            _lib.check(rc, "b3gs_backward_raw")
+
+        if not self.concurrent:
+            call(3)
+            return
+        call(1)                                   # blend backward: private scratch, runs concurrently
+        if self._acc_event is not None:
+            stream.wait_event(self._acc_event)    # the += into the shared slab is not atomic: one view at a time
+        call(2)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._acc_event = ev
 
     # ---- public -----------------------------------------------------------------------------
-    def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
-               debug: bool = False) -> dict:
-        """Same keys as render(); `viewspace_points_grad` ([P,3], filled by backward) replaces the
-        `.grad` of the reference's dummy `viewspace_points` tensor."""
+    def _render_on_current_stream(self, viewpoint_camera, bg_color, slot, scaling_modifier, debug) -> dict:
         m = self.model
         view = (viewpoint_camera, bg_color, scaling_modifier, debug)
         color, radii, depth, alpha = _RasterizeRaw.apply(m._xyz, m._features_dc, m._features_rest, m._scaling,
@@ -134,9 +161,43 @@ class FusedRasterizer:
         return {"render": color, "viewspace_points_grad": s.means2D_grad, "visibility_filter": radii > 0,
                 "radii": radii, "rendered_depth": depth, "rendered_alpha": alpha}
 
+    def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
+               debug: bool = False) -> dict:
+        """One view.  Same keys as render(); `viewspace_points_grad` ([P,3], filled by backward) replaces
+        the `.grad` of the reference's dummy `viewspace_points` tensor."""
+        return self.render_batch([(viewpoint_camera, slot)], bg_color, scaling_modifier, debug)[0]
+
+    def render_batch(self, views: Sequence, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
+                     debug: bool = False) -> List[dict]:
+        """Render [(camera, slot), ...] concurrently (one stream per slot); on return the current stream
+        has been made to wait for all of them, so the outputs can be consumed normally.  Calling
+        backward ONCE on a loss that depends on several of the views lets autograd run their backward
+        passes concurrently as well."""
+        if not self.concurrent:
+            return [self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug) for cam, slot in views]
+        main = torch.cuda.current_stream(self.dev)
+        out = []
+        self._acc_event = None
+        for cam, slot in views:
+            st = self.slots[slot].stream
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out.append(self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug))
+        for _, slot in views:
+            main.wait_stream(self.slots[slot].stream)
+        return out
+
+    def join(self):
+        """Make the current stream wait for every slot stream (call before consuming the slab)."""
+        if self.concurrent:
+            main = torch.cuda.current_stream(self.dev)
+            for s in self.slots:
+                main.wait_stream(s.stream)
+
     def num_rendered(self):
         """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered
         from a truncated list: call grow() and repeat the step."""
+        torch.cuda.synchronize(self.dev)
         return [int(s.n_dev.item()) for s in self.slots]
 
     def overflowed(self) -> bool:
@@ -146,4 +207,4 @@ class FusedRasterizer:
         need = max(self.num_rendered() + [self.capacity])
         self.capacity = int(need * factor)
         for i in range(len(self.slots)):
-            self.slots[i] = _Slot(self.P, self.W, self.H, self.capacity, self.dev, self.slots[i].means2D_grad is not None)
+            self.slots[i] = self._new_slot(self.slots[i].stream)

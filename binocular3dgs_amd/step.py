@@ -93,24 +93,51 @@ class ViewShardedStep:
     def step(self, pair_grad_fn=None, loss_fn=None):
         assert (pair_grad_fn is None) != (loss_fn is None)
         self.slab.zero()
-        n_rendered = 0
-        for i, (cam, scam, t) in enumerate(self.pairs):
-            if self.fused is not None:
-                a, b = self._slots[i]
-                pkg = self.fused.render(cam, self.bg, slot=a)
-                spkg = self.fused.render(scam, self.bg, slot=b) if scam is not None else None
-            else:
+        if self.fused is not None:
+            n_rendered = self._step_fused(pair_grad_fn, loss_fn)
+        else:
+            n_rendered = 0
+            for i, (cam, scam, t) in enumerate(self.pairs):
                 pkg = self.render(cam, self.model, self.pipe, self.bg)
                 spkg = self.render(scam, self.model, self.pipe, self.bg) if scam is not None else None
-            n_rendered += 1 + (scam is not None)
-            if loss_fn is not None:
-                loss_fn(i, cam, pkg, spkg, t).backward()
-            else:
-                outs, grads = zip(*pair_grad_fn(i, pkg, spkg))
-                torch.autograd.backward(list(outs), list(grads))
+                n_rendered += 1 + (scam is not None)
+                if loss_fn is not None:
+                    loss_fn(i, cam, pkg, spkg, t).backward()
+                else:
+                    outs, grads = zip(*pair_grad_fn(i, pkg, spkg))
+                    torch.autograd.backward(list(outs), list(grads))
         self.slab.all_reduce(self.average)
         if self.optimizer is not None:
             self.slab.rebind()
             self.optimizer.step()
         self.last_stats = {"views": n_rendered}
         return n_rendered
+
+    def _step_fused(self, pair_grad_fn, loss_fn):
+        """All views of the step are rendered concurrently (one stream per view), the loss / upstream
+        gradients of every pair are formed on the current stream, and ONE backward call lets autograd
+        run the per-view backward passes concurrently on the streams their forwards used."""
+        views = []
+        for i, (cam, scam, t) in enumerate(self.pairs):
+            a, b = self._slots[i]
+            views.append((cam, a))
+            if scam is not None:
+                views.append((scam, b))
+        pkgs = iter(self.fused.render_batch(views, self.bg))
+        outs, grads, total = [], [], None
+        for i, (cam, scam, t) in enumerate(self.pairs):
+            pkg = next(pkgs)
+            spkg = next(pkgs) if scam is not None else None
+            if loss_fn is not None:
+                li = loss_fn(i, cam, pkg, spkg, t)
+                total = li if total is None else total + li
+            else:
+                o, g = zip(*pair_grad_fn(i, pkg, spkg))
+                outs += list(o)
+                grads += list(g)
+        if loss_fn is not None:
+            total.backward()
+        else:
+            torch.autograd.backward(outs, grads)
+        self.fused.join()
+        return len(views)

@@ -140,12 +140,16 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
 
 /* Backward of b3gs_forward_raw.  `scratch` holds b3gs_backward_scratch_floats(P) floats that must be
  * ZERO on entry and are left zero on exit (persistent across views: no per-view memset).
- * dL_dmeans2D ([P,3], optional) is overwritten with the screen-space mean gradients. */
+ * dL_dmeans2D ([P,3], optional) is overwritten with the screen-space mean gradients.
+ * `phases`: bit 0 = blend backward (pixel gradients -> per-Gaussian sums in `scratch`), bit 1 = per-Gaussian
+ * chain rule + accumulation into `grads`; 3 = both.  Views rendered concurrently on several streams call
+ * phase 1 in parallel (own scratch each) and order their phase-2 calls with stream events, because phase 2
+ * read-modify-writes the shared gradient buffers without atomics. */
 size_t b3gs_backward_scratch_floats(int32_t P);
 int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,
                       const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
                       const float* dL_dalpha, float* scratch, const B3gsRawGrads* grads, float* dL_dmeans2D,
-                      b3gs_stream_t stream);
+                      int phases, b3gs_stream_t stream);
 
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
