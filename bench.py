@@ -220,7 +220,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(tpath)).get(dom.replace("_kernel", ""))
             except Exception:
                 traffic = None
         out = {
