@@ -39,6 +39,11 @@ class B3gsRawGrads(C.Structure):
     _fields_ = B3gsRawParams._fields_
 
 
+class B3gsFusedView(C.Structure):
+    _fields_ = [("view", C.POINTER(B3gsScene)), ("radii", C.c_void_p), ("geometry", C.c_void_p),
+                ("scratch", C.c_void_p), ("dL_dmeans2D", C.c_void_p)]
+
+
 class B3gsDebugViews(C.Structure):
     _fields_ = [("tiles_touched", C.c_void_p), ("depths", C.c_void_p), ("records", C.c_void_p),
                 ("point_list", C.c_void_p), ("tile_ids", C.c_void_p), ("ranges", C.c_void_p),
@@ -53,7 +58,8 @@ class B3gsKernelTimes(C.Structure):
 # every symbol include/b3gs_raster.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timing_collect", "b3gs_geometry_bytes", "b3gs_image_bytes",
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
-           "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats")
+           "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
+           "b3gs_backward_raw_accumulate")
 
 _lib = None
 
@@ -101,6 +107,9 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.POINTER(B3gsRawGrads), C.c_void_p, C.c_int, C.c_void_p]
     L.b3gs_backward_raw.restype = C.c_int
+    L.b3gs_backward_raw_accumulate.argtypes = [C.c_int32, C.POINTER(B3gsFusedView), C.POINTER(B3gsRawParams),
+                                               C.POINTER(B3gsRawGrads), C.c_int32, C.c_void_p]
+    L.b3gs_backward_raw_accumulate.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int
     L.b3gs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -332,6 +332,37 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
   return B3GS_OK;
 }
 
+int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
+                                 const B3gsRawGrads* grads, int32_t overwrite, b3gs_stream_t stream) {
+  if (nviews <= 0 || nviews > B3GS_MAX_FUSED_VIEWS || !views || !params || !grads)
+    return fail(B3GS_ERR_ARG, "%s", "bad view count / NULL argument (at most 8 views per call)");
+  const B3gsScene* v0 = views[0].view;
+  int rc = check_raw(v0, params);
+  if (rc) return rc;
+  if (v0->P == 0) return B3GS_OK;
+  if (!grads->xyz || !grads->features_dc || (v0->M > 1 && !grads->features_rest) || !grads->scaling ||
+      !grads->rotation || !grads->opacity)
+    return fail(B3GS_ERR_ARG, "%s", "NULL gradient buffer");
+  B3gsViewRef refs[B3GS_MAX_FUSED_VIEWS];
+  for (int k = 0; k < nviews; k++) {
+    const B3gsFusedView& fv = views[k];
+    if (!fv.view || !fv.radii || !fv.geometry || !fv.scratch) return fail(B3GS_ERR_ARG, "%s", "NULL view state");
+    if (fv.view->P != v0->P || fv.view->M != v0->M || fv.view->D != v0->D || fv.view->scale_modifier != v0->scale_modifier)
+      return fail(B3GS_ERR_ARG, "%s", "views of one call must share P, M, D and scale_modifier");
+    GeomView g;
+    b3gs_geom_view(const_cast<char*>(fv.geometry), v0->P, &g);
+    refs[k] = B3gsViewRef{fv.view->W, fv.view->H, fv.view->tan_fovx, fv.view->tan_fovy, fv.view->viewmatrix,
+                          fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  StageTimer tm(s);
+  tm.mark(-1);
+  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, s);
+  tm.mark(4);
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream) {
   (void)projmatrix;

@@ -128,6 +128,21 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, const B3gsRawGrads* rg, float* m2d_out, hipStream_t s);
+// one pass over the Gaussians for `nviews` views whose blend backward (phase 1) has completed
+#define B3GS_MAX_FUSED_VIEWS 8
+struct B3gsViewRef {
+  int32_t W, H;
+  float tan_fovx, tan_fovy;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  const int32_t* radii;
+  const uint32_t* clamped;   // inside the view's geometry buffer
+  float* scratch;            // the view's phase-1 sums (reset to zero here)
+  float* dL_dmeans2D;        // optional
+};
+void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
+                                  const B3gsRawGrads& rg, int overwrite, hipStream_t s);
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
                               hipStream_t s);
 

@@ -298,63 +298,51 @@ __global__ void __launch_bounds__(256)
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: one lane per Gaussian.  Inputs are the fp32 sums the blend backward accumulated:
-//   dL_dmeans2D[i] = (gx, gy, 0)   dL_dcolors[i]   dL_dopacity[i]
-//   dL_dcov3D[i]   = (g_conic_xx, g_conic_xy(half), g_conic_yy, g_depth, -, -)   (scratch use)
-// Standard mode: every output row is overwritten with its final value (culled rows = 0).
-// RAW mode: the four arrays above are a caller-owned scratch that is read and reset to zero here
-// (so it is clean for the next view without a memset), the chain rule continues through the
-// fused activations and the results are ACCUMULATED (+=) into the parameter-shaped gradient
-// buffers `rg` -- one owner thread per Gaussian, so plain read-modify-write; culled Gaussians
-// touch nothing.  `m2d_out` (optional, [P,3]) receives the screen-space mean gradient.
+// backward: one lane per Gaussian.
 // ------------------------------------------------------------------------------------------
-template <bool RAW>
-__global__ void __launch_bounds__(256)
-    preprocess_bwd_kernel(SceneX sx_, GeomView g, const int32_t* __restrict__ radii, float* __restrict__ dL_dmeans2D,
-                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                          float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, B3gsRawGrads rg,
-                          float* __restrict__ m2d_out) {
-  const B3gsScene& sc = sx_.sc;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sc.P) return;
-  const size_t i3 = 3 * (size_t)i;
-  if (radii[i] <= 0) {
-    if (RAW) {
-      if (m2d_out) { m2d_out[i3] = 0.f; m2d_out[i3 + 1] = 0.f; m2d_out[i3 + 2] = 0.f; }
-      return;
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) { dL_dmeans2D[i3 + k] = 0.f; dL_dcolors[i3 + k] = 0.f; dL_dmeans3D[i3 + k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.f;
-    dL_dopacity[i] = 0.f;
-    if (dL_dsh) for (int k = 0; k < 3 * sc.M; k++) dL_dsh[(size_t)3 * sc.M * i + k] = 0.f;
-    if (dL_dscales) { dL_dscales[i3] = 0.f; dL_dscales[i3 + 1] = 0.f; dL_dscales[i3 + 2] = 0.f; }
-    if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
+// the fp32 sums the blend backward accumulated for one Gaussian in one view
+struct PixSums {
+  float g2x, g2y;       // d/d(pixel position), already scaled by 0.5*W, 0.5*H
+  float gxx, gxy, gyy;  // d/d(conic); gxy is HALF the true xy gradient
+  float gdepth, gcol[3], gop;
+};
+// gradients w.r.t. the (activated) rasterizer inputs of one Gaussian
+struct GaussGrad {
+  float dmean[3], dS[6], dscale[3];
+  float4 dq;
+  float sraw[3], q[4], inv_norm;  // activated scale / rotation and 1/|raw quaternion| (RAW chain rule)
+};
+// where SH-coefficient gradients go: plain store (standard API), += in memory (one view, RAW),
+// or += in registers for the first REG coefficients (several views fused into one kernel)
+struct ShStore {
+  float* dc; float* rest;
+  __device__ __forceinline__ void put(int k, int ch, float v) { (k == 0 ? dc + ch : rest + 3 * (k - 1) + ch)[0] = v; }
+};
+struct ShAddMem {
+  float* dc; float* rest;
+  __device__ __forceinline__ void put(int k, int ch, float v) { (k == 0 ? dc + ch : rest + 3 * (k - 1) + ch)[0] += v; }
+};
+template <int REG>
+struct ShAddReg {
+  float acc[3 * REG];
+  float* dc; float* rest;
+  __device__ __forceinline__ void put(int k, int ch, float v) {
+    if (k < REG) acc[3 * k + ch] += v;   // k, ch are compile-time constants at every call site
+    else rest[3 * (k - 1) + ch] += v;
   }
-  const Mat16 vm = load_mat(sc.viewmatrix);
-  const Mat16 pm = load_mat(sc.projmatrix);
+};
+
+// Chain rule from the per-view sums to mean / covariance / scale / rotation / SH of Gaussian i.
+// Shared by the standard backward, the RAW single-view backward and the fused multi-view backward.
+template <bool RAW, class ShSink>
+__device__ __forceinline__ void gaussian_backward(const SceneX& sx_, const Mat16& vm, const Mat16& pm, int i,
+                                                  uint32_t clamp_bits, const PixSums& in, bool do_sh, bool do_sr,
+                                                  GaussGrad& o, ShSink& sink) {
+  const B3gsScene& sc = sx_.sc;
+  const size_t i3 = 3 * (size_t)i;
   const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sc.means3D;
   const float mx3 = means3D[i3], my3 = means3D[i3 + 1], mz3 = means3D[i3 + 2];
-
-  const float g2x = dL_dmeans2D[i3], g2y = dL_dmeans2D[i3 + 1];
-  // conic / depth sums: rows of 6 floats in standard mode (dL_dcov3D doubles as scratch), of 4 in RAW mode
-  const size_t cs = RAW ? 4 : 6;
-  const float gxx = dL_dcov3D[cs * i + 0], gxy = dL_dcov3D[cs * i + 1], gyy = dL_dcov3D[cs * i + 2];
-  const float gdepth = dL_dcov3D[cs * i + 3];
-  const float gcol[3] = {dL_dcolors[i3], dL_dcolors[i3 + 1], dL_dcolors[i3 + 2]};
-  const float gop = dL_dopacity[i];
-  if (RAW) {  // leave the scratch clean for the next view
-    dL_dmeans2D[i3] = 0.f; dL_dmeans2D[i3 + 1] = 0.f;
-    dL_dcolors[i3] = 0.f; dL_dcolors[i3 + 1] = 0.f; dL_dcolors[i3 + 2] = 0.f;
-    dL_dopacity[i] = 0.f;
-    reinterpret_cast<float4*>(dL_dcov3D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // [P,4] in RAW mode
-    if (m2d_out) { m2d_out[i3] = g2x; m2d_out[i3 + 1] = g2y; m2d_out[i3 + 2] = 0.f; }
-  } else {
-    dL_dmeans2D[i3 + 2] = 0.f;
-  }
+  const float g2x = in.g2x, g2y = in.g2y, gxx = in.gxx, gxy = in.gxy, gyy = in.gyy, gdepth = in.gdepth;
 
   float pv[3];
   pv[0] = ((vm.m[0] * mx3 + vm.m[4] * my3) + vm.m[8] * mz3) + vm.m[12];
@@ -367,7 +355,7 @@ __global__ void __launch_bounds__(256)
   const Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
   const float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
 
-  // conic = (c, -b, a)/den  ->  gradient w.r.t. (a, b, c); gxy holds HALF the true xy gradient
+  // conic = (c, -b, a)/den  ->  gradient w.r.t. (a, b, c)
   const float den = a * c - b * b;
   const float k2 = 1.0f / (den * den + 0.0000001f);
   const float dL_da = k2 * (-c * c * gxx + 2.f * b * c * gxy + (den - a * c) * gyy);
@@ -376,17 +364,13 @@ __global__ void __launch_bounds__(256)
 
   const float* T0 = e.T0;
   const float* T1 = e.T1;
-  float dS[6];
+  float* dS = o.dS;
   dS[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
   dS[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
   dS[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
   dS[1] = 2.f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.f * T1[0] * T1[1] * dL_dc;
   dS[2] = 2.f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.f * T1[0] * T1[2] * dL_dc;
   dS[4] = 2.f * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.f * T1[1] * T1[2] * dL_dc;
-  if (!RAW) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = dS[k];
-  }
 
   // dL/dT, then through T = J Wr to the view-space position
   const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
@@ -407,7 +391,7 @@ __global__ void __launch_bounds__(256)
   const float dtx = e.xmul * -fx * tz2 * dJ02;
   const float dty = e.ymul * -fy * tz2 * dJ12;
   const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.tx) * tz3 * dJ02 + (2.f * fy * e.ty) * tz3 * dJ12;
-  float dmean[3];
+  float* dmean = o.dmean;
 #pragma unroll
   for (int k = 0; k < 3; k++) dmean[k] = vm.m[4 * k + 0] * dtx + vm.m[4 * k + 1] * dty + vm.m[4 * k + 2] * dtz;
 
@@ -427,28 +411,18 @@ __global__ void __launch_bounds__(256)
   for (int k = 0; k < 3; k++) dmean[k] += vm.m[4 * k + 2] * gdepth;
 
   // colour: SH coefficients and view direction
-  if (RAW || (!sc.colors_precomp && dL_dsh)) {
+  if (do_sh) {
     const ShView sh = sh_view<RAW>(sx_, i);
-    float* dsh_dc = RAW ? rg.features_dc + i3 : dL_dsh + (size_t)3 * sc.M * i;
-    float* dsh_rest = RAW ? rg.features_rest + (size_t)3 * (sc.M - 1) * i : dsh_dc + 3;
     float ddx = mx3 - sc.campos[0], ddy = my3 - sc.campos[1], ddz = mz3 - sc.campos[2];
     float inv = 1.0f / sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
     const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
-    const uint32_t cb = g.clamped[i];
     float gdir[3] = {0.f, 0.f, 0.f};
     const int deg = sc.D;
-    const int nb = (deg + 1) * (deg + 1);
-    if (!RAW)
-      for (int k = nb; k < sc.M; k++) { dsh_rest[3 * (k - 1)] = 0.f; dsh_rest[3 * (k - 1) + 1] = 0.f; dsh_rest[3 * (k - 1) + 2] = 0.f; }
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-      const float gl = ((cb >> ch) & 1u) ? 0.f : gcol[ch];
+      const float gl = ((clamp_bits >> ch) & 1u) ? 0.f : in.gcol[ch];
 #define SH(k) sh(k, ch)
-#define DSH(k, v)                                          \
-  do {                                                     \
-    float* dst_ = ((k) == 0) ? dsh_dc + ch : dsh_rest + 3 * ((k)-1) + ch; \
-    if (RAW) *dst_ += (v); else *dst_ = (v);               \
-  } while (0)
+#define DSH(k, v) sink.put(k, ch, v)
       DSH(0, SH_C0 * gl);
       float rx = 0.f, ry = 0.f, rz = 0.f;
       if (deg > 0) {
@@ -499,29 +473,16 @@ __global__ void __launch_bounds__(256)
     dmean[1] += (gdir[1] - y * dot) * inv;
     dmean[2] += (gdir[2] - z * dot) * inv;
   }
-  if (RAW) {
-    rg.xyz[i3] += dmean[0];
-    rg.xyz[i3 + 1] += dmean[1];
-    rg.xyz[i3 + 2] += dmean[2];
-    // opacity = sigmoid(o):  d/do = op (1 - op)
-    const float op = load_opacity<true>(sx_, i);
-    rg.opacity[i] += gop * op * (1.0f - op);
-  } else {
-    dL_dmeans3D[i3] = dmean[0];
-    dL_dmeans3D[i3 + 1] = dmean[1];
-    dL_dmeans3D[i3 + 2] = dmean[2];
-  }
 
   // Sigma = L L^T, L = R diag(mod*s)
-  if (RAW || (!sc.cov3D_precomp && dL_dscales && dL_drots)) {
-    float sraw[3], q[4], inv_norm;
-    load_scale_rot<RAW>(sx_, i, sraw, q, &inv_norm);
-    const float r = q[0], x = q[1], y = q[2], z = q[3];
+  if (do_sr) {
+    load_scale_rot<RAW>(sx_, i, o.sraw, o.q, &o.inv_norm);
+    const float r = o.q[0], x = o.q[1], y = o.q[2], z = o.q[3];
     float R[9];
     quat_to_R(r, x, y, z, R);
-    const float sv[3] = {sc.scale_modifier * sraw[0], sc.scale_modifier * sraw[1], sc.scale_modifier * sraw[2]};
+    const float sv[3] = {sc.scale_modifier * o.sraw[0], sc.scale_modifier * o.sraw[1], sc.scale_modifier * o.sraw[2]};
     const float G[9] = {dS[0], 0.5f * dS[1], 0.5f * dS[2], 0.5f * dS[1], dS[3], 0.5f * dS[4], 0.5f * dS[2], 0.5f * dS[4], dS[5]};
-    float dR[9], dscale[3];
+    float dR[9];
 #pragma unroll
     for (int bcol = 0; bcol < 3; bcol++) {
       float ds = 0.f;
@@ -532,32 +493,233 @@ __global__ void __launch_bounds__(256)
         ds += dLab * R[3 * arow + bcol];
         dR[3 * arow + bcol] = dLab * sv[bcol];
       }
-      dscale[bcol] = ds * sc.scale_modifier;
+      o.dscale[bcol] = ds * sc.scale_modifier;
     }
-    float4 dq;
-    dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-    dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-    dq.z = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-    dq.w = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    o.dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+    o.dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+    o.dq.z = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+    o.dq.w = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+  }
+}
+
+// RAW chain rule of the fused activations: scales = exp(s) -> d/ds = scale; q = v/|v| ->
+// d/dv = (dq - q (q.dq))/|v|; opacity = sigmoid(o) -> d/do = op (1 - op)
+__device__ __forceinline__ void raw_chain(const GaussGrad& gg, float dscaling[3], float4& drot) {
+  dscaling[0] = gg.dscale[0] * gg.sraw[0];
+  dscaling[1] = gg.dscale[1] * gg.sraw[1];
+  dscaling[2] = gg.dscale[2] * gg.sraw[2];
+  const float qd = ((gg.q[0] * gg.dq.x + gg.q[1] * gg.dq.y) + gg.q[2] * gg.dq.z) + gg.q[3] * gg.dq.w;
+  drot.x = (gg.dq.x - gg.q[0] * qd) * gg.inv_norm;
+  drot.y = (gg.dq.y - gg.q[1] * qd) * gg.inv_norm;
+  drot.z = (gg.dq.z - gg.q[2] * qd) * gg.inv_norm;
+  drot.w = (gg.dq.w - gg.q[3] * qd) * gg.inv_norm;
+}
+
+// Per-view backward.  Inputs are the fp32 sums the blend backward accumulated:
+//   dL_dmeans2D[i] = (gx, gy, 0)   dL_dcolors[i]   dL_dopacity[i]
+//   dL_dcov3D[i]   = (g_conic_xx, g_conic_xy(half), g_conic_yy, g_depth, -, -)   (scratch use)
+// Standard mode: every output row is overwritten with its final value (culled rows = 0).
+// RAW mode: the four arrays above are a caller-owned scratch that is read and reset to zero here
+// (so it is clean for the next view without a memset), the chain rule continues through the
+// fused activations and the results are ACCUMULATED (+=) into the parameter-shaped gradient
+// buffers `rg` -- one owner thread per Gaussian, so plain read-modify-write; culled Gaussians
+// touch nothing.  `m2d_out` (optional, [P,3]) receives the screen-space mean gradient.
+template <bool RAW>
+__global__ void __launch_bounds__(256)
+    preprocess_bwd_kernel(SceneX sx_, GeomView g, const int32_t* __restrict__ radii, float* __restrict__ dL_dmeans2D,
+                          float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+                          float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+                          float* __restrict__ dL_dscales, float* __restrict__ dL_drots, B3gsRawGrads rg,
+                          float* __restrict__ m2d_out) {
+  const B3gsScene& sc = sx_.sc;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sc.P) return;
+  const size_t i3 = 3 * (size_t)i;
+  if (radii[i] <= 0) {
     if (RAW) {
-      // scales = exp(s): d/ds = scale;   q = v/|v|: d/dv = (dq - q (q.dq)) / |v|
-      rg.scaling[i3] += dscale[0] * sraw[0];
-      rg.scaling[i3 + 1] += dscale[1] * sraw[1];
-      rg.scaling[i3 + 2] += dscale[2] * sraw[2];
-      const float qd = ((q[0] * dq.x + q[1] * dq.y) + q[2] * dq.z) + q[3] * dq.w;
-      float4* dst = reinterpret_cast<float4*>(rg.rotation) + i;
-      float4 cur = *dst;
-      cur.x += (dq.x - q[0] * qd) * inv_norm;
-      cur.y += (dq.y - q[1] * qd) * inv_norm;
-      cur.z += (dq.z - q[2] * qd) * inv_norm;
-      cur.w += (dq.w - q[3] * qd) * inv_norm;
-      *dst = cur;
-    } else {
-      dL_dscales[i3] = dscale[0];
-      dL_dscales[i3 + 1] = dscale[1];
-      dL_dscales[i3 + 2] = dscale[2];
-      reinterpret_cast<float4*>(dL_drots)[i] = dq;
+      if (m2d_out) { m2d_out[i3] = 0.f; m2d_out[i3 + 1] = 0.f; m2d_out[i3 + 2] = 0.f; }
+      return;
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dL_dmeans2D[i3 + k] = 0.f; dL_dcolors[i3 + k] = 0.f; dL_dmeans3D[i3 + k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = 0.f;
+    dL_dopacity[i] = 0.f;
+    if (dL_dsh) for (int k = 0; k < 3 * sc.M; k++) dL_dsh[(size_t)3 * sc.M * i + k] = 0.f;
+    if (dL_dscales) { dL_dscales[i3] = 0.f; dL_dscales[i3 + 1] = 0.f; dL_dscales[i3 + 2] = 0.f; }
+    if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const Mat16 vm = load_mat(sc.viewmatrix);
+  const Mat16 pm = load_mat(sc.projmatrix);
+
+  PixSums in;
+  in.g2x = dL_dmeans2D[i3];
+  in.g2y = dL_dmeans2D[i3 + 1];
+  // conic / depth sums: rows of 6 floats in standard mode (dL_dcov3D doubles as scratch), of 4 in RAW mode
+  const size_t cs = RAW ? 4 : 6;
+  in.gxx = dL_dcov3D[cs * i + 0];
+  in.gxy = dL_dcov3D[cs * i + 1];
+  in.gyy = dL_dcov3D[cs * i + 2];
+  in.gdepth = dL_dcov3D[cs * i + 3];
+  in.gcol[0] = dL_dcolors[i3];
+  in.gcol[1] = dL_dcolors[i3 + 1];
+  in.gcol[2] = dL_dcolors[i3 + 2];
+  in.gop = dL_dopacity[i];
+  if (RAW) {  // leave the scratch clean for the next view
+    dL_dmeans2D[i3] = 0.f; dL_dmeans2D[i3 + 1] = 0.f;
+    dL_dcolors[i3] = 0.f; dL_dcolors[i3 + 1] = 0.f; dL_dcolors[i3 + 2] = 0.f;
+    dL_dopacity[i] = 0.f;
+    reinterpret_cast<float4*>(dL_dcov3D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // [P,4] in RAW mode
+    if (m2d_out) { m2d_out[i3] = in.g2x; m2d_out[i3 + 1] = in.g2y; m2d_out[i3 + 2] = 0.f; }
+  } else {
+    dL_dmeans2D[i3 + 2] = 0.f;
+  }
+
+  GaussGrad gg;
+  const uint32_t cb = g.clamped[i];
+  if (RAW) {
+    ShAddMem sink{rg.features_dc + i3, rg.features_rest + (size_t)3 * (sc.M - 1) * i};
+    gaussian_backward<true>(sx_, vm, pm, i, cb, in, true, true, gg, sink);
+    rg.xyz[i3] += gg.dmean[0];
+    rg.xyz[i3 + 1] += gg.dmean[1];
+    rg.xyz[i3 + 2] += gg.dmean[2];
+    const float op = load_opacity<true>(sx_, i);
+    rg.opacity[i] += in.gop * op * (1.0f - op);
+    float dsc[3];
+    float4 drot;
+    raw_chain(gg, dsc, drot);
+    rg.scaling[i3] += dsc[0];
+    rg.scaling[i3 + 1] += dsc[1];
+    rg.scaling[i3 + 2] += dsc[2];
+    float4* dst = reinterpret_cast<float4*>(rg.rotation) + i;
+    float4 cur = *dst;
+    cur.x += drot.x; cur.y += drot.y; cur.z += drot.z; cur.w += drot.w;
+    *dst = cur;
+  } else {
+    const bool do_sh = !sc.colors_precomp && dL_dsh;
+    const bool do_sr = !sc.cov3D_precomp && dL_dscales && dL_drots;
+    float* dsh = do_sh ? dL_dsh + (size_t)3 * sc.M * i : nullptr;
+    if (do_sh) {
+      const int nb = (sc.D + 1) * (sc.D + 1);
+      for (int k = nb; k < sc.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+    }
+    ShStore sink{dsh, dsh ? dsh + 3 : nullptr};
+    gaussian_backward<false>(sx_, vm, pm, i, cb, in, do_sh, do_sr, gg, sink);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)i + k] = gg.dS[k];
+    dL_dmeans3D[i3] = gg.dmean[0];
+    dL_dmeans3D[i3 + 1] = gg.dmean[1];
+    dL_dmeans3D[i3 + 2] = gg.dmean[2];
+    if (do_sr) {
+      dL_dscales[i3] = gg.dscale[0];
+      dL_dscales[i3 + 1] = gg.dscale[1];
+      dL_dscales[i3 + 2] = gg.dscale[2];
+      reinterpret_cast<float4*>(dL_drots)[i] = gg.dq;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused multi-view backward (RAW): ONE pass over the Gaussians for all views of an iteration.
+// The per-view kernel above moves ~400 B per visible Gaussian per view (parameters read, gradient
+// read-modify-write); here the parameters are read once, every view contributes its 11 sums
+// (read + reset), the gradients live in registers across the view loop and are written once:
+// ~130 B per Gaussian per view at 6 views, no ordering between views, no zero-fill of the
+// gradient buffers (`overwrite`).  One lane per Gaussian, the view loop is wave-uniform.
+// ------------------------------------------------------------------------------------------
+struct MultiViews {
+  int n;
+  B3gsViewRef v[B3GS_MAX_FUSED_VIEWS];
+};
+
+__global__ void __launch_bounds__(256)
+    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= base.P) return;
+  const size_t i3 = 3 * (size_t)i;
+  const size_t P = (size_t)base.P;
+  SceneX sx_;
+  sx_.sc = base;
+  sx_.raw = raw;
+  sx_.raw_mode = 1;
+  sx_.tight = 0;
+  float dxyz[3] = {0.f, 0.f, 0.f}, dscaling[3] = {0.f, 0.f, 0.f}, dop = 0.f;
+  float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+  ShAddReg<4> sink;
+#pragma unroll
+  for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
+  sink.dc = rg.features_dc + i3;
+  sink.rest = rg.features_rest + (size_t)3 * (base.M - 1) * i;
+  if (overwrite && base.M > 4)  // coefficients beyond the register window accumulate in memory
+    for (int k = 9; k < 3 * (base.M - 1); k++) sink.rest[k] = 0.f;
+  bool any = false;
+  for (int v = 0; v < mv.n; v++) {
+    const B3gsViewRef& vr = mv.v[v];
+    float* m2d = vr.dL_dmeans2D;
+    if (vr.radii[i] <= 0) {
+      if (m2d) { m2d[i3] = 0.f; m2d[i3 + 1] = 0.f; m2d[i3 + 2] = 0.f; }
+      continue;
+    }
+    any = true;
+    sx_.sc.W = vr.W; sx_.sc.H = vr.H;
+    sx_.sc.tan_fovx = vr.tan_fovx; sx_.sc.tan_fovy = vr.tan_fovy;
+    sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
+    const Mat16 vm = load_mat(vr.viewmatrix);
+    const Mat16 pm = load_mat(vr.projmatrix);
+    // scratch layout of b3gs_backward_raw: conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
+    float* s_cov = vr.scratch;
+    float* s_m2d = vr.scratch + 4 * P;
+    float* s_col = vr.scratch + 7 * P;
+    float* s_op = vr.scratch + 10 * P;
+    const float4 cv = reinterpret_cast<float4*>(s_cov)[i];
+    PixSums in;
+    in.gxx = cv.x; in.gxy = cv.y; in.gyy = cv.z; in.gdepth = cv.w;
+    in.g2x = s_m2d[i3]; in.g2y = s_m2d[i3 + 1];
+    in.gcol[0] = s_col[i3]; in.gcol[1] = s_col[i3 + 1]; in.gcol[2] = s_col[i3 + 2];
+    in.gop = s_op[i];
+    reinterpret_cast<float4*>(s_cov)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_m2d[i3] = 0.f; s_m2d[i3 + 1] = 0.f;
+    s_col[i3] = 0.f; s_col[i3 + 1] = 0.f; s_col[i3 + 2] = 0.f;
+    s_op[i] = 0.f;
+    if (m2d) { m2d[i3] = in.g2x; m2d[i3 + 1] = in.g2y; m2d[i3 + 2] = 0.f; }
+    GaussGrad gg;
+    gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
+    dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
+    float dsc[3];
+    float4 dr;
+    raw_chain(gg, dsc, dr);
+    dscaling[0] += dsc[0]; dscaling[1] += dsc[1]; dscaling[2] += dsc[2];
+    drot.x += dr.x; drot.y += dr.y; drot.z += dr.z; drot.w += dr.w;
+    dop += in.gop;
+  }
+  if (!any && !overwrite) return;
+  const float op = load_opacity<true>(sx_, i);
+  dop = dop * op * (1.0f - op);
+  const int nreg = base.M < 4 ? base.M : 4;
+  float4* rot_dst = reinterpret_cast<float4*>(rg.rotation) + i;
+  if (overwrite) {
+    rg.xyz[i3] = dxyz[0]; rg.xyz[i3 + 1] = dxyz[1]; rg.xyz[i3 + 2] = dxyz[2];
+    rg.scaling[i3] = dscaling[0]; rg.scaling[i3 + 1] = dscaling[1]; rg.scaling[i3 + 2] = dscaling[2];
+    *rot_dst = drot;
+    rg.opacity[i] = dop;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) sink.dc[ch] = sink.acc[ch];
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if (k < nreg) { sink.rest[3 * (k - 1)] = sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] = sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] = sink.acc[3 * k + 2]; }
+  } else {
+    rg.xyz[i3] += dxyz[0]; rg.xyz[i3 + 1] += dxyz[1]; rg.xyz[i3 + 2] += dxyz[2];
+    rg.scaling[i3] += dscaling[0]; rg.scaling[i3 + 1] += dscaling[1]; rg.scaling[i3 + 2] += dscaling[2];
+    float4 cur = *rot_dst;
+    cur.x += drot.x; cur.y += drot.y; cur.z += drot.z; cur.w += drot.w;
+    *rot_dst = cur;
+    rg.opacity[i] += dop;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) sink.dc[ch] += sink.acc[ch];
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+      if (k < nreg) { sink.rest[3 * (k - 1)] += sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] += sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] += sink.acc[3 * k + 2]; }
   }
 }
 
@@ -594,6 +756,15 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
   else
     hipLaunchKernelGGL(preprocess_bwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii, dL_dmeans2D, dL_dcolors,
                        dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, none, m2d_out);
+}
+
+void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
+                                  const B3gsRawGrads& rg, int overwrite, hipStream_t s) {
+  if (base.P <= 0 || nviews <= 0) return;
+  MultiViews mv;
+  mv.n = nviews;
+  for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
+  hipLaunchKernelGGL(accumulate_views_kernel, dim3((base.P + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

@@ -81,6 +81,7 @@ class FusedRasterizer:
         for _ in range(num_slots):
             self.slots.append(self._new_slot(torch.cuda.Stream(self.dev) if self.concurrent else None))
         self._acc_event: Optional[torch.cuda.Event] = None   # tail of the accumulate chain
+        self._deferred = None   # list of (slot_idx, B3gsScene) while a deferred-accumulate section is open
         self._params = _lib.B3gsRawParams()
         self._grads = _lib.B3gsRawGrads()
 
@@ -140,6 +141,10 @@ class FusedRasterizer:
                                      stream.cuda_stream)
             _lib.check(rc, "b3gs_backward_raw")
 
+        if self._deferred is not None:            # phase 2 of all views is fused into finish_deferred()
+            call(1)
+            self._deferred.append((slot_idx, sc))
+            return
         if not self.concurrent:
             call(3)
             return
@@ -186,6 +191,44 @@ class FusedRasterizer:
         for _, slot in views:
             main.wait_stream(self.slots[slot].stream)
         return out
+
+    def begin_deferred(self):
+        """Open a section in which every view's backward only runs the blend backward (phase 1, own
+        scratch, own stream); finish_deferred() then does the per-Gaussian chain rule of ALL those
+        views in one kernel (b3gs_backward_raw_accumulate)."""
+        self._deferred = []
+
+    def finish_deferred(self, overwrite: bool = True):
+        """Join the view streams and accumulate every deferred view in one pass over the Gaussians.
+        overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them."""
+        pend, self._deferred = self._deferred, None
+        self.join()
+        if not pend:
+            if overwrite:
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+            return
+        L, m = _lib.lib(), self.model
+        gr = self._grads
+        for name, p in (("xyz", m._xyz), ("features_dc", m._features_dc), ("features_rest", m._features_rest),
+                        ("scaling", m._scaling), ("rotation", m._rotation), ("opacity", m._opacity)):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            setattr(gr, name, p.grad.data_ptr() if p.numel() else None)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        for c0 in range(0, len(pend), 8):
+            chunk = pend[c0:c0 + 8]
+            arr = (_lib.B3gsFusedView * len(chunk))()
+            for k, (slot_idx, sc) in enumerate(chunk):
+                sl = self.slots[slot_idx]
+                arr[k].view = C.pointer(sc)
+                arr[k].radii, arr[k].geometry = sl.radii.data_ptr(), sl.geom.data_ptr()
+                arr[k].scratch = sl.scratch.data_ptr()
+                arr[k].dL_dmeans2D = None if sl.means2D_grad is None else sl.means2D_grad.data_ptr()
+            rc = L.b3gs_backward_raw_accumulate(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
+                                                int(bool(overwrite) and c0 == 0), stream)
+            _lib.check(rc, "b3gs_backward_raw_accumulate")
 
     def join(self):
         """Make the current stream wait for every slot stream (call before consuming the slab)."""

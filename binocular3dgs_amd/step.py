@@ -92,10 +92,12 @@ class ViewShardedStep:
 
     def step(self, pair_grad_fn=None, loss_fn=None):
         assert (pair_grad_fn is None) != (loss_fn is None)
-        self.slab.zero()
         if self.fused is not None:
+            # the fused multi-view accumulate STORES the gradients: no zero-fill of the slab
+            self.slab.rebind()
             n_rendered = self._step_fused(pair_grad_fn, loss_fn)
         else:
+            self.slab.zero()
             n_rendered = 0
             for i, (cam, scam, t) in enumerate(self.pairs):
                 pkg = self.render(cam, self.model, self.pipe, self.bg)
@@ -123,6 +125,7 @@ class ViewShardedStep:
             views.append((cam, a))
             if scam is not None:
                 views.append((scam, b))
+        self.fused.begin_deferred()
         pkgs = iter(self.fused.render_batch(views, self.bg))
         outs, grads, total = [], [], None
         for i, (cam, scam, t) in enumerate(self.pairs):
@@ -139,5 +142,5 @@ class ViewShardedStep:
             total.backward()
         else:
             torch.autograd.backward(outs, grads)
-        self.fused.join()
+        self.fused.finish_deferred(overwrite=True)
         return len(views)

@@ -151,6 +151,21 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
                       const float* dL_dalpha, float* scratch, const B3gsRawGrads* grads, float* dL_dmeans2D,
                       int phases, b3gs_stream_t stream);
 
+/* Phase 2 for SEVERAL views in one pass over the Gaussians (at most 8 per call): parameters are read
+ * once, each view contributes its phase-1 sums (read and reset), the gradients are written once --
+ * `overwrite` != 0 stores them (culled-everywhere Gaussians get zeros: no zero-fill of `grads` needed),
+ * 0 accumulates (+=).  Every view must have completed b3gs_backward_raw(..., phases = 1) with its OWN
+ * scratch on a stream that `stream` has been made to wait for.  All views share P, M, D, scale_modifier. */
+typedef struct B3gsFusedView {
+  const B3gsScene* view;     /* camera fields as passed to b3gs_forward_raw */
+  const int32_t* radii;
+  const char* geometry;
+  float* scratch;            /* that view's phase-1 sums; left zero */
+  float* dL_dmeans2D;        /* optional [P,3] */
+} B3gsFusedView;
+int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
+                                 const B3gsRawGrads* grads, int32_t overwrite, b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);
