@@ -112,8 +112,12 @@ __global__ void __launch_bounds__(256)
     render_fwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                       const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+                      unsigned long long* __restrict__ trace) {
   __shared__ TileShared<CHUNK> sh;
+  const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  unsigned n_iter = 0, n_chunks = 0;
   const int tile = tile_of_block(blockIdx.x, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
@@ -133,11 +137,13 @@ __global__ void __launch_bounds__(256)
     if (__syncthreads_and(done)) break;
     stage_chunk(sh, point_list, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
+    n_chunks++;
     if (__ballot(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
 #pragma unroll 1
     for (int pw = 0; pw < CHUNK / 64; pw++) {
       u64 m = uniform_u64(sh.mask[w][pw]);
       while (m) {
+        n_iter++;
         const int j = __builtin_ctzll(m);
         m &= m - 1;
         const int gidx = pw * 64 + j;
@@ -147,19 +153,21 @@ __global__ void __launch_bounds__(256)
         const float dx = A.x - fpx, dy = A.y - fpy;
         const float power = blend_power(A, B.x, dx, dy);
         const float alpha = fminf(B3GS_ALPHA_MAX, B.y * __expf(power));
-        const float test_T = T * (1.0f - alpha);
+        // branch-free: a pixel this Gaussian does not touch (or a finished pixel) blends alpha = 0,
+        // which leaves T, the sums and last_contributor unchanged
         const bool live = !done && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-        if (live && test_T < B3GS_T_EPS) done = true;
-        if (live && !done) {
-          const float wgt = alpha * T;
-          Cr = __builtin_fmaf(B.z, wgt, Cr);
-          Cg = __builtin_fmaf(B.w, wgt, Cg);
-          Cb = __builtin_fmaf(Cc.x, wgt, Cb);
-          Dp = __builtin_fmaf(Cc.y, wgt, Dp);
-          Ac += wgt;
-          T = test_T;
-          last_contributor = (uint32_t)(c * CHUNK + gidx + 1);
-        }
+        float a = live ? alpha : 0.0f;
+        const bool stop = live && (T * (1.0f - a) < B3GS_T_EPS);  // would saturate: not blended, pixel done
+        done = done || stop;
+        a = stop ? 0.0f : a;
+        const float wgt = a * T;
+        Cr = __builtin_fmaf(B.z, wgt, Cr);
+        Cg = __builtin_fmaf(B.w, wgt, Cg);
+        Cb = __builtin_fmaf(Cc.x, wgt, Cb);
+        Dp = __builtin_fmaf(Cc.y, wgt, Dp);
+        Ac += wgt;
+        T = T * (1.0f - a);
+        last_contributor = (a > 0.0f) ? (uint32_t)(c * CHUNK + gidx + 1) : last_contributor;
         if (__ballot(!done) == 0) break;
       }
       if (__ballot(!done) == 0) break;
@@ -174,6 +182,13 @@ __global__ void __launch_bounds__(256)
     out_color[2 * hw + pix] = __builtin_fmaf(T, bg[2], Cb);
     out_depth[pix] = Dp;
     out_alpha[pix] = Ac;
+  }
+  if (trace && lane == 0) {
+    unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
+    t[0] = __builtin_readcyclecounter() - t_start;
+    t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
+    t[2] = n_iter;
+    t[3] = n_chunks;
   }
 }
 
@@ -407,6 +422,13 @@ __global__ void __launch_bounds__(256)
 constexpr int FWD_CHUNK = 256;
 unsigned long long* g_bwd_trace = nullptr;
 size_t g_bwd_trace_words = 0;
+unsigned long long* fwd_trace_buffer(int nblocks) {  // B3GS_FWD_TRACE=1: same per-wave trace for the forward
+  if (!g_bwd_trace) {
+    (void)hipMalloc((void**)&g_bwd_trace, (size_t)nblocks * 16 * sizeof(unsigned long long));
+    g_bwd_trace_words = (size_t)nblocks * 16;
+  }
+  return g_bwd_trace;
+}
 constexpr int BWD_CHUNK = 64;
 
 }  // namespace
@@ -418,7 +440,8 @@ void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const Bi
   if (ntiles <= 0) return;
   const int nblocks = ((ntiles + 7) / 8) * 8;
   hipLaunchKernelGGL(render_fwd_kernel<FWD_CHUNK>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, b.val[0],
-                     g.rec, sc.background, im.final_T, im.n_contrib, out_color, out_depth, out_alpha);
+                     g.rec, sc.background, im.final_T, im.n_contrib, out_color, out_depth, out_alpha,
+                     getenv("B3GS_FWD_TRACE") ? fwd_trace_buffer(nblocks) : nullptr);
 }
 
 void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,

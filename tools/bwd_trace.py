@@ -4,7 +4,8 @@ throughput (all waves long) or by its longest serial chains (tail)?"""
 import ctypes as C
 import os
 import sys
-os.environ["B3GS_BWD_TRACE"] = "1"
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "bwd"
+os.environ["B3GS_BWD_TRACE" if WHICH == "bwd" else "B3GS_FWD_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -17,7 +18,8 @@ bg = torch.zeros(3, device="cuda")
 gc, gd, ga = synth.synth_pixel_grads(W, H, seed=0, device="cuda")
 for _ in range(3):
     pkg = render(cam, model, PipelineParams(), bg)
-    torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+    if WHICH == "bwd":
+        torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
 torch.cuda.synchronize()
 L = _lib.lib()
 L.b3gs_debug_bwd_trace.restype = C.c_size_t
