@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
                     help="fused: b3gs_forward_raw/backward_raw (activations in-kernel, persistent scratch, no host sync); "
                          "dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
+    ap.add_argument("--serial-views", action="store_true",
+                    help="render the views one after the other on one stream (un-overlapped kernel times, for profiles)")
+    ap.add_argument("--dp-path", action="store_true",
+                    help="single-GPU check of the N>1 code path: 1-rank RCCL group, graph + eager all-reduce")
     ap.add_argument("--graph", type=int, default=1, help="capture one whole iteration in a HIP graph (fused path only)")
     return ap.parse_args()
 
@@ -74,10 +78,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the rasterizer)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dp = world > 1 or args.dp_path
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from binocular3dgs_amd import _lib, synth
     from binocular3dgs_amd.render import PipelineParams
@@ -99,8 +105,9 @@ def main():
     fused = None
     if args.path == "fused":
         from binocular3dgs_amd.fused import FusedRasterizer
-        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs))
+        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), concurrent=not args.serial_views)
     stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt, fused=fused)
+    stepper.slab.force_collective = bool(args.dp_path)
 
     def grad_fn(i, pkg, spkg):
         out = [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga)]
@@ -110,7 +117,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -121,8 +128,29 @@ def main():
             fused.grow()
             stepper.step(pair_grad_fn=grad_fn)
     run_step = lambda: stepper.step(pair_grad_fn=grad_fn)  # noqa: E731
-    use_graph = bool(args.graph) and fused is not None and world == 1
-    if use_graph:
+    use_graph = bool(args.graph) and fused is not None
+    if use_graph and dp:
+        # data parallel: the rendering part of the iteration is one hipGraph; the RCCL all-reduce of
+        # the gradient slab and the (single-kernel) fused Adam are issued eagerly after each replay
+        try:
+            sg = torch.cuda.Stream()
+            sg.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sg):
+                stepper.compute_grads(pair_grad_fn=grad_fn)
+            torch.cuda.current_stream().wait_stream(sg)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                stepper.compute_grads(pair_grad_fn=grad_fn)
+
+            def run_step():
+                graph.replay()
+                stepper.reduce_and_update()
+        except Exception as exc:  # capture unsupported in this environment: stay eager
+            if rank == 0:
+                print(f"[bench] graph capture failed ({exc!r}); running eager", file=sys.stderr)
+            use_graph = False
+            run_step = lambda: stepper.step(pair_grad_fn=grad_fn)  # noqa: E731
+    elif use_graph:
         # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
         # (6 views fwd+bwd, slab zero, Adam) is one hipGraph launch
         if opt is not None:
@@ -173,7 +201,7 @@ def main():
     elapsed = t1 - t0
     if fused is not None and fused.overflowed():
         raise SystemExit("binning capacity overflow inside the timed region: result invalid")
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -251,10 +279,17 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, W, H, args.seed)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON is the LAST line
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(result_line, flush=True)
 
 
 def cpu_baseline(P, W, H, seed):

@@ -29,6 +29,7 @@ class FlatGradSlab:
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
         self.params = list(params)
+        self.force_collective = False   # issue the all-reduce even in a 1-rank group (path check)
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -50,7 +51,8 @@ class FlatGradSlab:
         self.rebind()
 
     def all_reduce(self, average: bool = False, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and \
+                (dist.get_world_size(group) > 1 or self.force_collective):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
@@ -91,6 +93,20 @@ class ViewShardedStep:
         self.last_stats = {}
 
     def step(self, pair_grad_fn=None, loss_fn=None):
+        n = self.compute_grads(pair_grad_fn, loss_fn)
+        self.reduce_and_update()
+        return n
+
+    def reduce_and_update(self):
+        """The exchange step of the data-parallel path (one all-reduce of the flat slab) + optimiser."""
+        self.slab.all_reduce(self.average)
+        if self.optimizer is not None:
+            self.slab.rebind()
+            self.optimizer.step()
+
+    def compute_grads(self, pair_grad_fn=None, loss_fn=None):
+        """Render this rank's views forward+backward; leaves the summed gradients in the slab.  Contains
+        no collective, no host sync and (fused path) no allocation: capturable as one HIP graph."""
         assert (pair_grad_fn is None) != (loss_fn is None)
         if self.fused is not None:
             # the fused multi-view accumulate STORES the gradients: no zero-fill of the slab
@@ -108,10 +124,6 @@ class ViewShardedStep:
                 else:
                     outs, grads = zip(*pair_grad_fn(i, pkg, spkg))
                     torch.autograd.backward(list(outs), list(grads))
-        self.slab.all_reduce(self.average)
-        if self.optimizer is not None:
-            self.slab.rebind()
-            self.optimizer.step()
         self.last_stats = {"views": n_rendered}
         return n_rendered
 
