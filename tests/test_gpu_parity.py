@@ -243,3 +243,32 @@ def test_empty_and_all_culled():
     assert float(out["alpha"].abs().sum()) == 0.0
     vis = _C.mark_visible(d["means3D"].cuda(), d["viewmatrix"].cuda(), d["projmatrix"].cuda())
     assert not bool(vis.any())
+
+
+def test_huge_gaussians_scale_modifier_and_single_point():
+    """Edge cases: splats covering the whole image (rect = every tile, long lists in every tile),
+    scale_modifier != 1, and P = 1."""
+    from oracle import tile_ref
+    d, _ = small_scene(P=300, W=100, H=70, seed=51, scale_mu=1.5)
+    d["scale_modifier"] = 0.8
+    st = tile_ref.forward(**oracle_kwargs(d))
+    assert int(st.tiles_touched.max()) == 7 * 5          # some splats cover all 35 tiles
+    out = _run_hip_forward(d)
+    _check_forward(d, st, out)
+    st2, ref, got = _backward_both(d, seed=3)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dopacity"):
+        assert rel_l2(got[k].cpu().numpy(), ref[k]) <= 2e-4, k
+    one, _ = small_scene(P=1, W=40, H=40, seed=52, scale_mu=0.3)
+    one["means3D"] = torch.tensor([[0.0, 0.0, 5.0]])
+    st1 = tile_ref.forward(**oracle_kwargs(one))
+    _check_forward(one, st1, _run_hip_forward(one))
+
+
+def test_tile_bits_beyond_one_byte_and_two_bytes():
+    """More than 256 tiles needs 2 byte-passes of the tile sort (both test sizes do); a tall, narrow
+    image exercises grid_x = 1."""
+    from oracle import tile_ref
+    for (W, H) in ((16, 400), (720, 16)):
+        d, _ = small_scene(P=2000, W=W, H=H, seed=60 + W, scale_mu=0.05)
+        st = tile_ref.forward(**oracle_kwargs(d))
+        _check_forward(d, st, _run_hip_forward(d))
