@@ -187,8 +187,9 @@ def main():
     if use_graph or (fused is not None and fused.concurrent):
         # per-kernel durations need the kernels un-overlapped: a few eager iterations with the views
         # rendered one after the other on one stream (same workload, same kernels), after the timed region
+        L.b3gs_timing_collect()            # resolve (and discard) stages parked during the overlapped region
+        L.b3gs_set_timing(None)
         times = _lib.B3gsKernelTimes()
-        L.b3gs_timing_collect()
         L.b3gs_set_timing(C.byref(times))
         was = fused.concurrent
         fused.concurrent = False

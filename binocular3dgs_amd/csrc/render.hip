@@ -225,6 +225,9 @@ struct BwdPixel {
 // Per-pixel reverse step for one Gaussian; writes this lane's 10 partial gradients to p[].
 // Branch-free: a lane the Gaussian does not touch uses alpha = G = 0, which leaves T and the
 // "behind" composites unchanged and makes every partial an exact zero.
+// DA = the view has depth and/or alpha pixel gradients (primary views); shifted binocular views only
+// carry colour gradients (train.py:129), so their depth/alpha terms and the 10th component vanish.
+template <bool DA>
 __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const float4& B, float col_b, float depth,
                                          float G, float alpha, bool live, float (&p)[10]) {
   G = live ? G : 0.0f;
@@ -234,17 +237,20 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
   px.T = px.T * inv_one_m_a;
   const float wgt = alpha * px.T;
-  const float dr = B.z - px.Br, dg = B.w - px.Bg, db = col_b - px.Bb, dd = depth - px.Bd, da = 1.0f - px.Ba;
+  const float dr = B.z - px.Br, dg = B.w - px.Bg, db = col_b - px.Bb;
   float dL_da = dr * px.dCr;
   dL_da = __builtin_fmaf(dg, px.dCg, dL_da);
   dL_da = __builtin_fmaf(db, px.dCb, dL_da);
-  dL_da = __builtin_fmaf(dd, px.dD, dL_da);
-  dL_da = __builtin_fmaf(da, px.dA, dL_da);
   px.Br = __builtin_fmaf(alpha, dr, px.Br);
   px.Bg = __builtin_fmaf(alpha, dg, px.Bg);
   px.Bb = __builtin_fmaf(alpha, db, px.Bb);
-  px.Bd = __builtin_fmaf(alpha, dd, px.Bd);
-  px.Ba = __builtin_fmaf(alpha, da, px.Ba);
+  if (DA) {
+    const float dd = depth - px.Bd, da = 1.0f - px.Ba;
+    dL_da = __builtin_fmaf(dd, px.dD, dL_da);
+    dL_da = __builtin_fmaf(da, px.dA, dL_da);
+    px.Bd = __builtin_fmaf(alpha, dd, px.Bd);
+    px.Ba = __builtin_fmaf(alpha, da, px.Ba);
+  }
   dL_da = dL_da * px.T;
   dL_da = __builtin_fmaf(-px.T_final * inv_one_m_a, px.bg_dot, dL_da);
   const float dL_dG = B.y * dL_da;
@@ -259,10 +265,10 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[6] = wgt * px.dCr;
   p[7] = wgt * px.dCg;
   p[8] = wgt * px.dCb;
-  p[9] = wgt * px.dD;
+  p[9] = DA ? wgt * px.dD : 0.0f;
 }
 
-template <int CHUNK>
+template <int CHUNK, bool DA>
 __global__ void __launch_bounds__(256)
     render_bwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(256)
   else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; red_col = 0; }
   else if (rk < 9) { red_base = dL_dcolors; red_stride = 3; red_col = rk - 6; }
   else { red_base = dL_dcov3D; red_stride = cov_stride; red_col = 3; }
-  const bool red_writer = (rk < 10) && (rpart == 0);
+  const bool red_writer = (rk < (DA ? 10u : 9u)) && (rpart == 0);
   float* const red = sh.red[w];
   const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
 
@@ -391,9 +397,9 @@ __global__ void __launch_bounds__(256)
           const float4 Cc = sh.f.C[gidx];
           const size_t g = (size_t)sh.id[gidx];
           float p[10];
-          bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
+          bwd_eval<DA>(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
 #pragma unroll
-          for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
+          for (int k = 0; k < (DA ? 10 : 9); k++) red[k * RED_STRIDE + lane] = p[k];
           if (pending) B3GS_RETIRE_PENDING();
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -460,13 +466,14 @@ void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const B
   }
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
-#define B3GS_LAUNCH_BWD(C)                                                                                          \
-  hipLaunchKernelGGL(render_bwd_kernel<C>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges,      \
+  const bool da = dL_ddepth != nullptr || dL_dalpha != nullptr;
+#define B3GS_LAUNCH_BWD(C, DA_)                                                                                     \
+  hipLaunchKernelGGL((render_bwd_kernel<C, DA_>), dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, \
                      b.val[0], g.rec, sc.background, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,     \
                      dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (unsigned)cov_stride, g_bwd_trace)
-  if (bwd_chunk == 256) B3GS_LAUNCH_BWD(256);
-  else if (bwd_chunk == 128) B3GS_LAUNCH_BWD(128);
-  else B3GS_LAUNCH_BWD(64);
+  if (bwd_chunk == 256) { if (da) B3GS_LAUNCH_BWD(256, true); else B3GS_LAUNCH_BWD(256, false); }
+  else if (bwd_chunk == 128) { if (da) B3GS_LAUNCH_BWD(128, true); else B3GS_LAUNCH_BWD(128, false); }
+  else { if (da) B3GS_LAUNCH_BWD(64, true); else B3GS_LAUNCH_BWD(64, false); }
 #undef B3GS_LAUNCH_BWD
 }
 

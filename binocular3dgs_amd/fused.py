@@ -47,6 +47,17 @@ class _Slot:
         self.stream = stream
 
 
+class _ViewOutputs(dict):
+    """render() dict whose `visibility_filter` (= radii > 0, gaussian_renderer/__init__.py:99) is only
+    materialised when somebody reads it (one elementwise kernel per view otherwise wasted)."""
+
+    def __missing__(self, key):
+        if key == "visibility_filter":
+            self[key] = self["radii"] > 0
+            return self[key]
+        raise KeyError(key)
+
+
 class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, owner, slot_idx, view):
@@ -163,8 +174,8 @@ class FusedRasterizer:
         color, radii, depth, alpha = _RasterizeRaw.apply(m._xyz, m._features_dc, m._features_rest, m._scaling,
                                                          m._rotation, m._opacity, self, slot, view)
         s = self.slots[slot]
-        return {"render": color, "viewspace_points_grad": s.means2D_grad, "visibility_filter": radii > 0,
-                "radii": radii, "rendered_depth": depth, "rendered_alpha": alpha}
+        return _ViewOutputs({"render": color, "viewspace_points_grad": s.means2D_grad, "radii": radii,
+                             "rendered_depth": depth, "rendered_alpha": alpha})
 
     def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
                debug: bool = False) -> dict:
