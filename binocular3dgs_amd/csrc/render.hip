@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(256)
 // i.e. ~60 LDS-pipe clocks and ~70 VALU cycles per Gaussian instead of ~480 VALU cycles, and no
 // accumulator tile, no second barrier phase: LDS holds only the staged chunk + 2.7 KB per wave.
 constexpr int RED_STRIDE = 68;
+#ifndef B3GS_BWD_WAVES
+#define B3GS_BWD_WAVES 6  /* waves per SIMD the register allocator must leave room for */
+#endif
 
 template <int CHUNK>
 struct TileSharedBwd {
@@ -269,7 +272,7 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
 }
 
 template <int CHUNK, bool DA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     render_bwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                       const float* __restrict__ bg, const float* __restrict__ final_T,
