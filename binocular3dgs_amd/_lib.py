@@ -41,7 +41,11 @@ class B3gsRawGrads(C.Structure):
 
 class B3gsFusedView(C.Structure):
     _fields_ = [("view", C.POINTER(B3gsScene)), ("radii", C.c_void_p), ("geometry", C.c_void_p),
-                ("scratch", C.c_void_p), ("dL_dmeans2D", C.c_void_p)]
+                ("scratch", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("densify_stats", C.c_int32)]
+
+
+class B3gsDensifyStats(C.Structure):
+    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
 
 
 class B3gsDebugViews(C.Structure):
@@ -108,7 +112,8 @@ def lib():
                                     C.POINTER(B3gsRawGrads), C.c_void_p, C.c_int, C.c_void_p]
     L.b3gs_backward_raw.restype = C.c_int
     L.b3gs_backward_raw_accumulate.argtypes = [C.c_int32, C.POINTER(B3gsFusedView), C.POINTER(B3gsRawParams),
-                                               C.POINTER(B3gsRawGrads), C.c_int32, C.c_void_p]
+                                               C.POINTER(B3gsRawGrads), C.c_int32, C.POINTER(B3gsDensifyStats),
+                                               C.c_void_p]
     L.b3gs_backward_raw_accumulate.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int

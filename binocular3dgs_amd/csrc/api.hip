@@ -333,7 +333,8 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
 }
 
 int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
-                                 const B3gsRawGrads* grads, int32_t overwrite, b3gs_stream_t stream) {
+                                 const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
+                                 b3gs_stream_t stream) {
   if (nviews <= 0 || nviews > B3GS_MAX_FUSED_VIEWS || !views || !params || !grads)
     return fail(B3GS_ERR_ARG, "%s", "bad view count / NULL argument (at most 8 views per call)");
   const B3gsScene* v0 = views[0].view;
@@ -352,12 +353,15 @@ int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, con
     GeomView g;
     b3gs_geom_view(const_cast<char*>(fv.geometry), v0->P, &g);
     refs[k] = B3gsViewRef{fv.view->W, fv.view->H, fv.view->tan_fovx, fv.view->tan_fovy, fv.view->viewmatrix,
-                          fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D};
+                          fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D,
+                          fv.densify_stats};
   }
+  if (stats && (!stats->xyz_gradient_accum || !stats->denom || !stats->max_radii2D))
+    return fail(B3GS_ERR_ARG, "%s", "densify stats need all three arrays");
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, s);
+  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, stats, s);
   tm.mark(4);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;

@@ -140,9 +140,10 @@ struct B3gsViewRef {
   const uint32_t* clamped;   // inside the view's geometry buffer
   float* scratch;            // the view's phase-1 sums (reset to zero here)
   float* dL_dmeans2D;        // optional
+  int32_t densify_stats;
 };
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
-                                  const B3gsRawGrads& rg, int overwrite, hipStream_t s);
+                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s);
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
                               hipStream_t s);
 

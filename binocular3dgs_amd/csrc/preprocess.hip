@@ -634,7 +634,8 @@ struct MultiViews {
 };
 
 __global__ void __launch_bounds__(256)
-    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite) {
+    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite,
+                            B3gsDensifyStats ds) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= base.P) return;
   const size_t i3 = 3 * (size_t)i;
@@ -654,10 +655,13 @@ __global__ void __launch_bounds__(256)
   if (overwrite && base.M > 4)  // coefficients beyond the register window accumulate in memory
     for (int k = 9; k < 3 * (base.M - 1); k++) sink.rest[k] = 0.f;
   bool any = false;
+  float st_norm = 0.f, st_cnt = 0.f;
+  int st_rad = 0;
   for (int v = 0; v < mv.n; v++) {
     const B3gsViewRef& vr = mv.v[v];
     float* m2d = vr.dL_dmeans2D;
-    if (vr.radii[i] <= 0) {
+    const int rad = vr.radii[i];
+    if (rad <= 0) {
       if (m2d) { m2d[i3] = 0.f; m2d[i3 + 1] = 0.f; m2d[i3 + 2] = 0.f; }
       continue;
     }
@@ -683,6 +687,11 @@ __global__ void __launch_bounds__(256)
     s_col[i3] = 0.f; s_col[i3 + 1] = 0.f; s_col[i3 + 2] = 0.f;
     s_op[i] = 0.f;
     if (m2d) { m2d[i3] = in.g2x; m2d[i3 + 1] = in.g2y; m2d[i3 + 2] = 0.f; }
+    if (vr.densify_stats) {
+      st_norm += sqrtf(in.g2x * in.g2x + in.g2y * in.g2y);
+      st_cnt += 1.0f;
+      st_rad = max(st_rad, rad);
+    }
     GaussGrad gg;
     gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
     dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
@@ -692,6 +701,11 @@ __global__ void __launch_bounds__(256)
     dscaling[0] += dsc[0]; dscaling[1] += dsc[1]; dscaling[2] += dsc[2];
     drot.x += dr.x; drot.y += dr.y; drot.z += dr.z; drot.w += dr.w;
     dop += in.gop;
+  }
+  if (ds.denom && st_cnt > 0.f) {
+    ds.xyz_gradient_accum[i] += st_norm;
+    ds.denom[i] += st_cnt;
+    ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
   }
   if (!any && !overwrite) return;
   const float op = load_opacity<true>(sx_, i);
@@ -759,12 +773,14 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
 }
 
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
-                                  const B3gsRawGrads& rg, int overwrite, hipStream_t s) {
+                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s) {
   if (base.P <= 0 || nviews <= 0) return;
   MultiViews mv;
   mv.n = nviews;
   for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
-  hipLaunchKernelGGL(accumulate_views_kernel, dim3((base.P + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite);
+  const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(accumulate_views_kernel, dim3((base.P + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite,
+                     ds);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

@@ -103,7 +103,7 @@ class FusedRasterizer:
 
     # ---- C-ABI calls ------------------------------------------------------------------------
     def _scene(self, view) -> _lib.B3gsScene:
-        cam, bg, scaling_modifier, debug = view
+        cam, bg, scaling_modifier, debug = view[:4]
         m = self.model
         return _lib.B3gsScene(self.P, int(m.active_sh_degree), int(self.K), self.W, self.H,
                               math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scaling_modifier), 0,
@@ -154,7 +154,7 @@ class FusedRasterizer:
 
         if self._deferred is not None:            # phase 2 of all views is fused into finish_deferred()
             call(1)
-            self._deferred.append((slot_idx, sc))
+            self._deferred.append((slot_idx, sc, bool(view[4]) if len(view) > 4 else False))
             return
         if not self.concurrent:
             call(3)
@@ -168,9 +168,10 @@ class FusedRasterizer:
         self._acc_event = ev
 
     # ---- public -----------------------------------------------------------------------------
-    def _render_on_current_stream(self, viewpoint_camera, bg_color, slot, scaling_modifier, debug) -> dict:
+    def _render_on_current_stream(self, viewpoint_camera, bg_color, slot, scaling_modifier, debug,
+                                  densify_stats=False) -> dict:
         m = self.model
-        view = (viewpoint_camera, bg_color, scaling_modifier, debug)
+        view = (viewpoint_camera, bg_color, scaling_modifier, debug, densify_stats)
         color, radii, depth, alpha = _RasterizeRaw.apply(m._xyz, m._features_dc, m._features_rest, m._scaling,
                                                          m._rotation, m._opacity, self, slot, view)
         s = self.slots[slot]
@@ -185,21 +186,25 @@ class FusedRasterizer:
 
     def render_batch(self, views: Sequence, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
                      debug: bool = False) -> List[dict]:
-        """Render [(camera, slot), ...] concurrently (one stream per slot); on return the current stream
+        """Render [(camera, slot[, densify_stats]), ...] concurrently (one stream per slot); views with
+        densify_stats=True feed the model's densification statistics (init_densification_stats) in
+        finish_deferred(), as the primary view does at train.py:178-179.  On return the current stream
         has been made to wait for all of them, so the outputs can be consumed normally.  Calling
         backward ONCE on a loss that depends on several of the views lets autograd run their backward
         passes concurrently as well."""
+        views = [(v[0], v[1], (v[2] if len(v) > 2 else False)) for v in views]
         if not self.concurrent:
-            return [self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug) for cam, slot in views]
+            return [self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug, ds)
+                    for cam, slot, ds in views]
         main = torch.cuda.current_stream(self.dev)
         out = []
         self._acc_event = None
-        for cam, slot in views:
+        for cam, slot, ds in views:
             st = self.slots[slot].stream
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                out.append(self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug))
-        for _, slot in views:
+                out.append(self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug, ds))
+        for _, slot, _ds in views:
             main.wait_stream(self.slots[slot].stream)
         return out
 
@@ -227,18 +232,23 @@ class FusedRasterizer:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             setattr(gr, name, p.grad.data_ptr() if p.numel() else None)
+        stats = None
+        if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
+            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr())
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         for c0 in range(0, len(pend), 8):
             chunk = pend[c0:c0 + 8]
             arr = (_lib.B3gsFusedView * len(chunk))()
-            for k, (slot_idx, sc) in enumerate(chunk):
+            for k, (slot_idx, sc, want_stats) in enumerate(chunk):
                 sl = self.slots[slot_idx]
+                arr[k].densify_stats = int(want_stats and stats is not None)
                 arr[k].view = C.pointer(sc)
                 arr[k].radii, arr[k].geometry = sl.radii.data_ptr(), sl.geom.data_ptr()
                 arr[k].scratch = sl.scratch.data_ptr()
                 arr[k].dL_dmeans2D = None if sl.means2D_grad is None else sl.means2D_grad.data_ptr()
             rc = L.b3gs_backward_raw_accumulate(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
-                                                int(bool(overwrite) and c0 == 0), stream)
+                                                int(bool(overwrite) and c0 == 0),
+                                                None if stats is None else C.byref(stats), stream)
             _lib.check(rc, "b3gs_backward_raw_accumulate")
 
     def join(self):

@@ -55,6 +55,25 @@ class GaussianModel:
         m.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
         return m
 
+    # ---- densification statistics (the consumers of radii / means2D gradients) ----
+    def init_densification_stats(self):
+        """scene/gaussian_model.py:147-152: max_radii2D [P], xyz_gradient_accum [P,1], denom [P,1]."""
+        P, dev = self._xyz.shape[0], self._xyz.device
+        self.max_radii2D = torch.zeros((P,), device=dev)
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+
+    def add_densification_stats(self, viewspace_point_grad, update_filter):
+        """scene/gaussian_model.py:409-411 (takes the gradient tensor itself: [P,3])."""
+        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_grad[update_filter, :2], dim=-1,
+                                                             keepdim=True)
+        self.denom[update_filter] += 1
+
+    def update_max_radii(self, radii, visibility_filter):
+        """train.py:178"""
+        self.max_radii2D[visibility_filter] = torch.max(self.max_radii2D[visibility_filter],
+                                                        radii[visibility_filter].float())
+
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]
 

@@ -104,6 +104,17 @@ class ViewShardedStep:
             self.slab.rebind()
             self.optimizer.step()
 
+    def sync_densify_stats(self, group=None):
+        """Make the densification statistics identical on every replica before a densify/prune decision
+        (SURVEY 8e): sums of xyz_gradient_accum / denom, maximum of max_radii2D.  Call it every
+        densification interval, not every step."""
+        m = self.model
+        if not (dist.is_available() and dist.is_initialized()) or getattr(m, "denom", None) is None:
+            return
+        dist.all_reduce(m.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(m.denom, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
     def compute_grads(self, pair_grad_fn=None, loss_fn=None):
         """Render this rank's views forward+backward; leaves the summed gradients in the slab.  Contains
         no collective, no host sync and (fused path) no allocation: capturable as one HIP graph."""
@@ -134,9 +145,9 @@ class ViewShardedStep:
         views = []
         for i, (cam, scam, t) in enumerate(self.pairs):
             a, b = self._slots[i]
-            views.append((cam, a))
-            if scam is not None:
-                views.append((scam, b))
+            views.append((cam, a, True))      # densification statistics come from the primary view only
+            if scam is not None:             # (train.py:102-104,128: the shifted render's are discarded)
+                views.append((scam, b, False))
         self.fused.begin_deferred()
         pkgs = iter(self.fused.render_batch(views, self.bg))
         outs, grads, total = [], [], None

@@ -162,9 +162,19 @@ typedef struct B3gsFusedView {
   const char* geometry;
   float* scratch;            /* that view's phase-1 sums; left zero */
   float* dL_dmeans2D;        /* optional [P,3] */
+  int32_t densify_stats;     /* != 0: this view feeds the densification statistics (train.py:178-179) */
 } B3gsFusedView;
+/* Densification statistics of scene/gaussian_model.py:147-152,409-411 and train.py:178, updated for every
+ * Gaussian visible (radii > 0) in a view with densify_stats set:
+ *   xyz_gradient_accum += ||dL_dmeans2D[:2]||,  denom += 1,  max_radii2D = max(max_radii2D, radii). */
+typedef struct B3gsDensifyStats {
+  float* xyz_gradient_accum; /* [P,1] */
+  float* denom;              /* [P,1] */
+  float* max_radii2D;        /* [P]   */
+} B3gsDensifyStats;
 int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
-                                 const B3gsRawGrads* grads, int32_t overwrite, b3gs_stream_t stream);
+                                 const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
+                                 b3gs_stream_t stream);
 
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -60,6 +60,14 @@ def _worker(rank, world, port, out_dir):
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, eps=1e-15)
     st = ViewShardedStep(model, [pairs[i] for i in mine], torch.zeros(3), optimizer=opt, render_fn=render)
     st.step(loss_fn=lambda i, cam, pkg, spkg, t: _loss_fn([gts[j] for j in mine])(i, cam, pkg, spkg, t))
+    # densification statistics: every rank contributes its own pairs, then one sync
+    model.init_densification_stats()
+    model.denom += float(len(mine))
+    model.xyz_gradient_accum += float(rank + 1)
+    model.max_radii2D += float(10 * (rank + 1))
+    st.sync_densify_stats()
+    assert float(model.denom[0]) == 3.0 and float(model.xyz_gradient_accum[0]) == 3.0
+    assert float(model.max_radii2D[0]) == 20.0
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), grad=st.slab.flat.numpy(),
              params=torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy(), mine=np.array(mine))
     dist.destroy_process_group()

@@ -117,3 +117,47 @@ def test_capacity_overflow_is_detected_and_recovered():
     with torch.no_grad():
         out = fr.render(pairs[0][0], bg, slot=0)
     assert not fr.overflowed() and float(out["rendered_alpha"].mean()) > 0.1
+
+
+def test_densification_statistics_match_reference_formula():
+    """a11: max_radii2D / xyz_gradient_accum / denom updated inside the fused multi-view accumulate equal
+    the reference's PyTorch update (train.py:178-179, scene/gaussian_model.py:409-411) applied to the
+    drop-in path's outputs, primary views only."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.render import PipelineParams, render
+    from binocular3dgs_amd.step import ViewShardedStep
+    W, H = 160, 120
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+
+    def grad_fn(i, pkg, spkg):
+        return [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]
+
+    model, pairs, bg = _setup(P=8000, W=W, H=H)
+    model.init_densification_stats()
+    fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs))
+    st = ViewShardedStep(model, pairs, bg, fused=fr)
+    for _ in range(2):
+        st.step(pair_grad_fn=grad_fn)
+    torch.cuda.synchronize()
+    got = (model.max_radii2D.clone(), model.xyz_gradient_accum.clone(), model.denom.clone())
+
+    ref, _, _ = _setup(P=8000, W=W, H=H)
+    ref.init_densification_stats()
+    for _ in range(2):
+        for cam, scam, t in pairs:
+            for p in ref.parameters():
+                p.grad = None
+            pkg = render(cam, ref, PipelineParams(), bg)
+            spkg = render(scam, ref, PipelineParams(), bg)
+            torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], spkg["render"]],
+                                    [gc, gd, ga, gc])
+            vis = pkg["visibility_filter"]
+            ref.update_max_radii(pkg["radii"], vis)
+            ref.add_densification_stats(pkg["viewspace_points"].grad, vis)
+    # a handful of Gaussians may flip visibility (in-kernel vs torch activations): compare where both agree
+    same = got[2].reshape(-1) == ref.denom.reshape(-1)
+    assert float(same.float().mean()) > 0.999
+    assert float(got[2].max()) == 2.0 * len(pairs)
+    assert rel_l2(got[1].reshape(-1)[same].cpu().numpy(), ref.xyz_gradient_accum.reshape(-1)[same].cpu().numpy()) < 2e-3
+    assert float((got[0][same] != ref.max_radii2D[same]).float().mean()) < 1e-3
