@@ -44,6 +44,13 @@ class B3gsFusedView(C.Structure):
                 ("scratch", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("densify_stats", C.c_int32)]
 
 
+class B3gsBlendView(C.Structure):
+    _fields_ = [("view", C.POINTER(B3gsScene)), ("geometry", C.c_void_p), ("binning", C.c_void_p),
+                ("image", C.c_void_p), ("out_color", C.c_void_p), ("out_depth", C.c_void_p),
+                ("out_alpha", C.c_void_p), ("dL_dcolor", C.c_void_p), ("dL_ddepth", C.c_void_p),
+                ("dL_dalpha", C.c_void_p), ("scratch", C.c_void_p)]
+
+
 class B3gsDensifyStats(C.Structure):
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
 
@@ -63,7 +70,7 @@ class B3gsKernelTimes(C.Structure):
 EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timing_collect", "b3gs_geometry_bytes", "b3gs_image_bytes",
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
-           "b3gs_backward_raw_accumulate")
+           "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch")
 
 _lib = None
 
@@ -103,8 +110,12 @@ def lib():
                                 C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 8 + [C.c_void_p]
     L.b3gs_backward.restype = C.c_int
     L.b3gs_forward_raw.argtypes = [C.POINTER(B3gsScene), C.POINTER(B3gsRawParams), C.c_void_p, C.c_void_p, C.c_int64,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p]
     L.b3gs_forward_raw.restype = C.c_int
+    for fn in (L.b3gs_blend_forward_batch, L.b3gs_blend_backward_batch):
+        fn.argtypes = [C.c_int32, C.POINTER(B3gsBlendView), C.c_void_p]
+        fn.restype = C.c_int
     L.b3gs_backward_scratch_floats.argtypes = [C.c_int32]
     L.b3gs_backward_scratch_floats.restype = C.c_size_t
     L.b3gs_backward_raw.argtypes = [C.POINTER(B3gsScene), C.POINTER(B3gsRawParams), C.c_void_p, C.c_void_p, C.c_void_p,

@@ -66,6 +66,32 @@ int check_raw(const B3gsScene* sc, const B3gsRawParams* rp) {
   return B3GS_OK;
 }
 
+void blend_forward_one(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im, float* out_color,
+                       float* out_depth, float* out_alpha, hipStream_t s) {
+  BlendBatch batch;
+  batch.n = 1;
+  batch.v[0] = b3gs_blend_view(sc, g, b, im);
+  batch.v[0].out_color = out_color;
+  batch.v[0].out_depth = out_depth;
+  batch.v[0].out_alpha = out_alpha;
+  b3gs_launch_blend_forward(batch, s);
+}
+
+BlendView blend_backward_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
+                              const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, float* m2d,
+                              float* col, float* op, float* cov, uint32_t cov_stride) {
+  BlendView v = b3gs_blend_view(sc, g, b, im);
+  v.dL_dcolor = dL_dcolor;
+  v.dL_ddepth = dL_ddepth;
+  v.dL_dalpha = dL_dalpha;
+  v.dL_dmeans2D = m2d;
+  v.dL_dcolors = col;
+  v.dL_dopacity = op;
+  v.dL_dcov3D = cov;
+  v.cov_stride = cov_stride;
+  return v;
+}
+
 // optional per-stage timing (bench only): events bracket each stage on the caller's stream.
 // Nothing synchronises inside the call: the events are parked in a thread-local list and turned
 // into milliseconds by b3gs_timing_collect() after the caller has synchronised the stream.
@@ -182,7 +208,7 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   b3gs_launch_binning(sc->P, sc->W, sc->H, N, g, b, im, s);
   if ((rc = debug_sync(sc, s, "binning"))) return rc;
   tm.mark(1);
-  b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
+  blend_forward_one(*sc, g, b, im, out_color, out_depth, out_alpha, s);
   if ((rc = debug_sync(sc, s, "render forward"))) return rc;
   tm.mark(2);
   HIP_TRY(hipGetLastError());
@@ -191,10 +217,10 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
 
 static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning, int64_t binning_capacity, char* image,
                                  float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                                 int32_t* device_num_rendered, hipStream_t s) {
+                                 int32_t* device_num_rendered, int phases, hipStream_t s) {
   const B3gsScene* sc = &sx.sc;
-  if (!geometry || !binning || !image || !out_color || !out_depth || !out_alpha || (sc->P > 0 && !radii) ||
-      binning_capacity <= 0 || binning_capacity > 0xFFFFFFFFll)
+  if (!geometry || !binning || !image || (sc->P > 0 && !radii) || binning_capacity <= 0 ||
+      binning_capacity > 0xFFFFFFFFll || ((phases & 2) && (!out_color || !out_depth || !out_alpha)))
     return fail(B3GS_ERR_ARG, "%s", "NULL buffer or bad capacity");
   GeomView g;
   ImgView im;
@@ -204,15 +230,19 @@ static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning
   b3gs_bin_view(binning, sc->P, binning_capacity, &b);
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(sx, g, im, radii, s);
-  tm.mark(0);
-  b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, device_num_rendered, s);
-  // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
-  // list, which the caller detects from *device_num_rendered > capacity and repeats
-  b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
-  tm.mark(1);
-  b3gs_launch_render_forward(*sc, g, b, im, out_color, out_depth, out_alpha, s);
-  tm.mark(2);
+  if (phases & 1) {
+    b3gs_launch_preprocess(sx, g, im, radii, s);
+    tm.mark(0);
+    b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, device_num_rendered, s);
+    // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
+    // list, which the caller detects from *device_num_rendered > capacity and repeats
+    b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
+    tm.mark(1);
+  }
+  if (phases & 2) {
+    blend_forward_one(*sc, g, b, im, out_color, out_depth, out_alpha, s);
+    tm.mark(2);
+  }
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }
@@ -223,12 +253,12 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
   int rc = check_scene(sc);
   if (rc) return rc;
   return forward_capacity_impl(wrap(sc), geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha,
-                               radii, device_num_rendered, (hipStream_t)stream);
+                               radii, device_num_rendered, 3, (hipStream_t)stream);
 }
 
 int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
                      int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
-                     int32_t* radii, int32_t* device_num_rendered, b3gs_stream_t stream) {
+                     int32_t* radii, int32_t* device_num_rendered, int phases, b3gs_stream_t stream) {
   int rc = check_raw(view, params);
   if (rc) return rc;
   SceneX sx;
@@ -237,7 +267,7 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
   sx.raw_mode = 1;
   sx.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
   return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
-                               device_num_rendered, (hipStream_t)stream);
+                               device_num_rendered, phases, (hipStream_t)stream);
 }
 
 size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)11 * (size_t)(P > 0 ? P : 0); }
@@ -274,7 +304,10 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
   StageTimer tm(s);
   tm.mark(-1);
   if (phases & 1) {
-    b3gs_launch_render_backward(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4, s);
+    BlendBatch batch;
+    batch.n = 1;
+    batch.v[0] = blend_backward_view(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4);
+    b3gs_launch_blend_backward(batch, s);
     tm.mark(3);
   }
   if (phases & 2) {
@@ -319,15 +352,84 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
   HIP_TRY(hipMemsetAsync(dL_dcolors, 0, P * 3 * sizeof(float), s));
   HIP_TRY(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
   HIP_TRY(hipMemsetAsync(dL_dcov3D, 0, P * 6 * sizeof(float), s));
-  if (num_rendered != 0)
-    b3gs_launch_render_backward(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors, dL_dopacity,
-                                dL_dcov3D, 6, s);
+  if (num_rendered != 0) {
+    BlendBatch batch;
+    batch.n = 1;
+    batch.v[0] = blend_backward_view(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors,
+                                     dL_dopacity, dL_dcov3D, 6);
+    b3gs_launch_blend_backward(batch, s);
+  }
   if ((rc = debug_sync(sc, s, "render backward"))) return rc;
   tm.mark(3);
   b3gs_launch_preprocess_backward(wrap(sc), g, radii, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D,
                                   dL_dsh, dL_dscales, dL_drotations, nullptr, nullptr, s);
   if ((rc = debug_sync(sc, s, "preprocess backward"))) return rc;
   tm.mark(4);
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+static int batch_views_ok(int32_t nviews, const B3gsBlendView* views) {
+  if (nviews <= 0 || nviews > B3GS_MAX_FUSED_VIEWS || !views)
+    return fail(B3GS_ERR_ARG, "%s", "bad view count (1..8) or NULL view table");
+  for (int k = 0; k < nviews; k++)
+    if (!views[k].view || !views[k].geometry || !views[k].binning || !views[k].image || views[k].view->W <= 0 ||
+        views[k].view->H <= 0 || !views[k].view->background)
+      return fail(B3GS_ERR_ARG, "%s", "NULL state buffer in a batched view");
+  return B3GS_OK;
+}
+
+int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream) {
+  int rc = batch_views_ok(nviews, views);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  BlendBatch batch;
+  batch.n = nviews;
+  for (int k = 0; k < nviews; k++) {
+    const B3gsBlendView& bv = views[k];
+    if (!bv.out_color || !bv.out_depth || !bv.out_alpha) return fail(B3GS_ERR_ARG, "%s", "NULL output image");
+    GeomView g;
+    ImgView im;
+    BinView b;
+    b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
+    b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
+    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, 1, &b);
+    batch.v[k] = b3gs_blend_view(*bv.view, g, b, im);
+    batch.v[k].out_color = bv.out_color;
+    batch.v[k].out_depth = bv.out_depth;
+    batch.v[k].out_alpha = bv.out_alpha;
+  }
+  StageTimer tm(s);
+  tm.mark(-1);
+  b3gs_launch_blend_forward(batch, s);
+  tm.mark(2);
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
+}
+
+int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream) {
+  int rc = batch_views_ok(nviews, views);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  BlendBatch batch;
+  batch.n = nviews;
+  for (int k = 0; k < nviews; k++) {
+    const B3gsBlendView& bv = views[k];
+    if (!bv.dL_dcolor || !bv.scratch) return fail(B3GS_ERR_ARG, "%s", "NULL dL_dcolor / scratch");
+    GeomView g;
+    ImgView im;
+    BinView b;
+    b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
+    b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
+    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, 1, &b);
+    const size_t P = (size_t)bv.view->P;  // scratch: conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
+    batch.v[k] = blend_backward_view(*bv.view, g, b, im, bv.dL_dcolor, bv.dL_ddepth, bv.dL_dalpha, bv.scratch + 4 * P,
+                                     bv.scratch + 7 * P, bv.scratch + 10 * P, bv.scratch, 4);
+  }
+  StageTimer tm(s);
+  tm.mark(-1);
+  b3gs_launch_blend_backward(batch, s);
+  tm.mark(3);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
 }

@@ -128,22 +128,6 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
                                      float* dL_drotations, const B3gsRawGrads* rg, float* m2d_out, hipStream_t s);
-// one pass over the Gaussians for `nviews` views whose blend backward (phase 1) has completed
-#define B3GS_MAX_FUSED_VIEWS 8
-struct B3gsViewRef {
-  int32_t W, H;
-  float tan_fovx, tan_fovy;
-  const float* viewmatrix;
-  const float* projmatrix;
-  const float* campos;
-  const int32_t* radii;
-  const uint32_t* clamped;   // inside the view's geometry buffer
-  float* scratch;            // the view's phase-1 sums (reset to zero here)
-  float* dL_dmeans2D;        // optional
-  int32_t densify_stats;
-};
-void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
-                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s);
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
                               hipStream_t s);
 
@@ -159,9 +143,48 @@ void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, uint32_t* img
 void b3gs_launch_binning(int32_t P, int32_t W, int32_t H, int64_t n_bound, const GeomView& g, const BinView& b,
                          const ImgView& im, hipStream_t s);
 
-void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
-                                float* out_color, float* out_depth, float* out_alpha, hipStream_t s);
-void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
-                                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D,
-                                 int cov_stride /* 6: [P,6] output doubles as scratch; 4: RAW scratch */, hipStream_t s);
+// ---- blend (per-tile alpha compositing) launches: one or several views per launch ---------------
+#define B3GS_MAX_FUSED_VIEWS 8
+struct BlendView {
+  int32_t W, H, grid_x, ntiles, block_base;   // block_base is filled by the launcher
+  const uint2* ranges;
+  const uint32_t* point_list;
+  const float4* rec;
+  const float* bg;
+  float* final_T;          // forward: written; backward: read
+  uint32_t* n_contrib;
+  float* out_color;        // forward outputs
+  float* out_depth;
+  float* out_alpha;
+  const float* dL_dcolor;  // backward inputs (dL_ddepth / dL_dalpha may be null)
+  const float* dL_ddepth;
+  const float* dL_dalpha;
+  float* dL_dmeans2D;      // backward accumulation targets (rows of 3, 3, 1, cov_stride floats)
+  float* dL_dcolors;
+  float* dL_dopacity;
+  float* dL_dcov3D;
+  uint32_t cov_stride;     // 6: the [P,6] output doubles as conic/depth scratch; 4: RAW scratch
+};
+struct BlendBatch {
+  int32_t n;
+  BlendView v[B3GS_MAX_FUSED_VIEWS];
+};
+BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im);
+void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s);
+void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s);
+
+// one pass over the Gaussians for `nviews` views whose blend backward (phase 1) has completed
+struct B3gsViewRef {
+  int32_t W, H;
+  float tan_fovx, tan_fovy;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  const int32_t* radii;
+  const uint32_t* clamped;   // inside the view's geometry buffer
+  float* scratch;            // the view's phase-1 sums (reset to zero here)
+  float* dL_dmeans2D;        // optional
+  int32_t densify_stats;
+};
+void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
+                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s);

@@ -20,6 +20,7 @@
 //  * workgroup -> tile map keeps raster-adjacent tiles (which share Gaussians) on one XCD's L2
 #include "b3gs_internal.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -39,6 +40,17 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {
 __device__ __forceinline__ int tile_of_block(int bid, int ntiles) {
   const int per = (ntiles + 7) >> 3;
   return (bid & 7) * per + (bid >> 3);
+}
+
+// Pick the view a workgroup belongs to.  The table travels in the kernel arguments; a chain of
+// wave-uniform selects (scalar moves, once per workgroup) avoids dynamic indexing of the argument
+// block, which the compiler would otherwise copy to scratch memory.
+__device__ __forceinline__ BlendView select_view(const BlendBatch& batch, int bid) {
+  BlendView v = batch.v[0];
+#pragma unroll
+  for (int k = 1; k < B3GS_MAX_FUSED_VIEWS; k++)
+    if (k < batch.n && bid >= batch.v[k].block_base) v = batch.v[k];
+  return v;
 }
 
 template <int CTRL, int ROW_MASK>
@@ -107,18 +119,28 @@ __device__ __forceinline__ float blend_power(const float4& A, float cyy, float d
   return __builtin_fmaf(-A.w * dx, dy, -0.5f * q);
 }
 
+// A blend launch covers one or several views: workgroups [block_base, next block_base) belong to view v.
+// Batching the views of an iteration into one launch lets the dispatcher pack ~11k tiles over the
+// machine (one view's 1900 tiles fill it exactly once, so every launch paid its own tail:
+// measured 126 us for one view, 446 us for six in one launch).
 template <int CHUNK>
-__global__ void __launch_bounds__(256)
-    render_fwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
-                      const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                      const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                      float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
-                      unsigned long long* __restrict__ trace) {
+__global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileShared<CHUNK> sh;
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_chunks = 0;
-  const int tile = tile_of_block(blockIdx.x, ntiles);
+  const BlendView bv = select_view(batch, (int)blockIdx.x);
+  const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
+  const uint2* __restrict__ ranges = bv.ranges;
+  const uint32_t* __restrict__ point_list = bv.point_list;
+  const float4* __restrict__ rec = bv.rec;
+  const float* __restrict__ bg = bv.bg;
+  float* __restrict__ final_T = bv.final_T;
+  uint32_t* __restrict__ n_contrib = bv.n_contrib;
+  float* __restrict__ out_color = bv.out_color;
+  float* __restrict__ out_depth = bv.out_depth;
+  float* __restrict__ out_alpha = bv.out_alpha;
+  const int tile = tile_of_block((int)blockIdx.x - bv.block_base, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -210,7 +232,7 @@ __global__ void __launch_bounds__(256)
 // accumulator tile, no second barrier phase: LDS holds only the staged chunk + 2.7 KB per wave.
 constexpr int RED_STRIDE = 68;
 #ifndef B3GS_BWD_WAVES
-#define B3GS_BWD_WAVES 6  /* waves per SIMD the register allocator must leave room for */
+#define B3GS_BWD_WAVES 5  /* waves per SIMD the register allocator must leave room for */
 #endif
 
 template <int CHUNK>
@@ -228,9 +250,6 @@ struct BwdPixel {
 // Per-pixel reverse step for one Gaussian; writes this lane's 10 partial gradients to p[].
 // Branch-free: a lane the Gaussian does not touch uses alpha = G = 0, which leaves T and the
 // "behind" composites unchanged and makes every partial an exact zero.
-// DA = the view has depth and/or alpha pixel gradients (primary views); shifted binocular views only
-// carry colour gradients (train.py:129), so their depth/alpha terms and the 10th component vanish.
-template <bool DA>
 __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const float4& B, float col_b, float depth,
                                          float G, float alpha, bool live, float (&p)[10]) {
   G = live ? G : 0.0f;
@@ -247,7 +266,7 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   px.Br = __builtin_fmaf(alpha, dr, px.Br);
   px.Bg = __builtin_fmaf(alpha, dg, px.Bg);
   px.Bb = __builtin_fmaf(alpha, db, px.Bb);
-  if (DA) {
+  {
     const float dd = depth - px.Bd, da = 1.0f - px.Ba;
     dL_da = __builtin_fmaf(dd, px.dD, dL_da);
     dL_da = __builtin_fmaf(da, px.dA, dL_da);
@@ -268,24 +287,34 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[6] = wgt * px.dCr;
   p[7] = wgt * px.dCg;
   p[8] = wgt * px.dCb;
-  p[9] = DA ? wgt * px.dD : 0.0f;
+  p[9] = wgt * px.dD;
 }
 
-template <int CHUNK, bool DA>
+template <int CHUNK>
 __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
-    render_bwd_kernel(int W, int H, int grid_x, int ntiles, const uint2* __restrict__ ranges,
-                      const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                      const float* __restrict__ bg, const float* __restrict__ final_T,
-                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-                      const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_img,
-                      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
-                      float* __restrict__ dL_dcov3D, unsigned cov_stride, unsigned long long* __restrict__ trace) {
+    render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileSharedBwd<CHUNK> sh;
+  __shared__ uint32_t s_max_last[4];
   const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_live = 0;
-  __shared__ uint32_t s_max_last[4];
-  const int tile = tile_of_block(blockIdx.x, ntiles);
+  const BlendView bv = select_view(batch, (int)blockIdx.x);
+  const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
+  const uint2* __restrict__ ranges = bv.ranges;
+  const uint32_t* __restrict__ point_list = bv.point_list;
+  const float4* __restrict__ rec = bv.rec;
+  const float* __restrict__ bg = bv.bg;
+  const float* __restrict__ final_T = bv.final_T;
+  const uint32_t* __restrict__ n_contrib = bv.n_contrib;
+  const float* __restrict__ dL_dcolor = bv.dL_dcolor;
+  const float* __restrict__ dL_ddepth = bv.dL_ddepth;
+  const float* __restrict__ dL_dalpha_img = bv.dL_dalpha;
+  float* __restrict__ dL_dmeans2D = bv.dL_dmeans2D;
+  float* __restrict__ dL_dcolors = bv.dL_dcolors;
+  float* __restrict__ dL_dopacity = bv.dL_dopacity;
+  float* __restrict__ dL_dcov3D = bv.dL_dcov3D;
+  const unsigned cov_stride = bv.cov_stride;
+  const int tile = tile_of_block((int)blockIdx.x - bv.block_base, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -343,7 +372,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; red_col = 0; }
   else if (rk < 9) { red_base = dL_dcolors; red_stride = 3; red_col = rk - 6; }
   else { red_base = dL_dcov3D; red_stride = cov_stride; red_col = 3; }
-  const bool red_writer = (rk < (DA ? 10u : 9u)) && (rpart == 0);
+  const bool red_writer = (rk < 10u) && (rpart == 0);
   float* const red = sh.red[w];
   const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
 
@@ -400,9 +429,9 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
           const float4 Cc = sh.f.C[gidx];
           const size_t g = (size_t)sh.id[gidx];
           float p[10];
-          bwd_eval<DA>(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
+          bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
 #pragma unroll
-          for (int k = 0; k < (DA ? 10 : 9); k++) red[k * RED_STRIDE + lane] = p[k];
+          for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
           if (pending) B3GS_RETIRE_PENDING();
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -431,7 +460,11 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
 constexpr int FWD_CHUNK = 256;
 unsigned long long* g_bwd_trace = nullptr;
 size_t g_bwd_trace_words = 0;
-unsigned long long* fwd_trace_buffer(int nblocks) {  // B3GS_FWD_TRACE=1: same per-wave trace for the forward
+unsigned long long* trace_buffer(int nblocks) {  // debug (B3GS_FWD_TRACE / B3GS_BWD_TRACE): per-wave cycle trace
+  if (g_bwd_trace && g_bwd_trace_words < (size_t)nblocks * 16) {
+    (void)hipFree(g_bwd_trace);
+    g_bwd_trace = nullptr;
+  }
   if (!g_bwd_trace) {
     (void)hipMalloc((void**)&g_bwd_trace, (size_t)nblocks * 16 * sizeof(unsigned long long));
     g_bwd_trace_words = (size_t)nblocks * 16;
@@ -442,42 +475,51 @@ constexpr int BWD_CHUNK = 64;
 
 }  // namespace
 
-void b3gs_launch_render_forward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
-                                float* out_color, float* out_depth, float* out_alpha, hipStream_t s) {
-  const int gx = (sc.W + B3GS_TILE - 1) / B3GS_TILE, gy = (sc.H + B3GS_TILE - 1) / B3GS_TILE;
-  const int ntiles = gx * gy;
-  if (ntiles <= 0) return;
-  const int nblocks = ((ntiles + 7) / 8) * 8;
-  hipLaunchKernelGGL(render_fwd_kernel<FWD_CHUNK>, dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, b.val[0],
-                     g.rec, sc.background, im.final_T, im.n_contrib, out_color, out_depth, out_alpha,
-                     getenv("B3GS_FWD_TRACE") ? fwd_trace_buffer(nblocks) : nullptr);
+namespace {
+int blocks_of(const BlendView& v) { return ((v.ntiles + 7) / 8) * 8; }
+}  // namespace
+
+void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
+  int total = 0;
+  for (int k = 0; k < batch.n; k++) {
+    batch.v[k].block_base = total;
+    total += blocks_of(batch.v[k]);
+  }
+  if (total <= 0) return;
+  hipLaunchKernelGGL(render_fwd_kernel<FWD_CHUNK>, dim3(total), dim3(256), 0, s, batch,
+                     getenv("B3GS_FWD_TRACE") ? trace_buffer(total) : nullptr);
 }
 
-void b3gs_launch_render_backward(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
-                                 const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
-                                 float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dcov3D,
-                                 int cov_stride, hipStream_t s) {
-  const int gx = (sc.W + B3GS_TILE - 1) / B3GS_TILE, gy = (sc.H + B3GS_TILE - 1) / B3GS_TILE;
-  const int ntiles = gx * gy;
-  if (ntiles <= 0) return;
-  const int nblocks = ((ntiles + 7) / 8) * 8;
-  // B3GS_BWD_TRACE=1: per-wave {start, end, iterations, live iterations} cycle trace (tools/bwd_trace.py)
-  static const bool want_trace = getenv("B3GS_BWD_TRACE") != nullptr;
-  if (want_trace && !g_bwd_trace) {
-    (void)hipMalloc((void**)&g_bwd_trace, (size_t)nblocks * 16 * sizeof(unsigned long long));
-    g_bwd_trace_words = (size_t)nblocks * 16;
+void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
+  int total = 0;
+  for (int k = 0; k < batch.n; k++) {
+    batch.v[k].block_base = total;
+    total += blocks_of(batch.v[k]);
   }
+  if (total <= 0) return;
+  // B3GS_BWD_TRACE=1: per-wave {cycles, wall start|end, iterations, live iterations} (tools/bwd_trace.py)
+  unsigned long long* trace = getenv("B3GS_BWD_TRACE") ? trace_buffer(total) : nullptr;
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
-  const bool da = dL_ddepth != nullptr || dL_dalpha != nullptr;
-#define B3GS_LAUNCH_BWD(C, DA_)                                                                                     \
-  hipLaunchKernelGGL((render_bwd_kernel<C, DA_>), dim3(nblocks), dim3(256), 0, s, sc.W, sc.H, gx, ntiles, im.ranges, \
-                     b.val[0], g.rec, sc.background, im.final_T, im.n_contrib, dL_dcolor, dL_ddepth, dL_dalpha,     \
-                     dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dcov3D, (unsigned)cov_stride, g_bwd_trace)
-  if (bwd_chunk == 256) { if (da) B3GS_LAUNCH_BWD(256, true); else B3GS_LAUNCH_BWD(256, false); }
-  else if (bwd_chunk == 128) { if (da) B3GS_LAUNCH_BWD(128, true); else B3GS_LAUNCH_BWD(128, false); }
-  else { if (da) B3GS_LAUNCH_BWD(64, true); else B3GS_LAUNCH_BWD(64, false); }
-#undef B3GS_LAUNCH_BWD
+  if (bwd_chunk == 256) hipLaunchKernelGGL(render_bwd_kernel<256>, dim3(total), dim3(256), 0, s, batch, trace);
+  else if (bwd_chunk == 128) hipLaunchKernelGGL(render_bwd_kernel<128>, dim3(total), dim3(256), 0, s, batch, trace);
+  else hipLaunchKernelGGL(render_bwd_kernel<64>, dim3(total), dim3(256), 0, s, batch, trace);
+}
+
+BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im) {
+  BlendView v;
+  memset(&v, 0, sizeof(v));
+  v.W = sc.W;
+  v.H = sc.H;
+  v.grid_x = (sc.W + B3GS_TILE - 1) / B3GS_TILE;
+  v.ntiles = v.grid_x * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
+  v.ranges = im.ranges;
+  v.point_list = b.val[0];
+  v.rec = g.rec;
+  v.bg = sc.background;
+  v.final_T = im.final_T;
+  v.n_contrib = im.n_contrib;
+  return v;
 }
 
 // debug only: copy the last backward's per-wave cycle trace to the host (returns words copied)

@@ -1,20 +1,21 @@
 """Fast path of the build's own training step: fused activations, persistent scratch, no host sync,
-views rendered concurrently on separate HIP streams.
+the views of an iteration binned concurrently and blended in ONE launch.
 
-`FusedRasterizer.render()` returns the same dict as the drop-in `render()` (render.py /
-gaussian_renderer/__init__.py:97-103) but goes through b3gs_forward_raw / b3gs_backward_raw:
+`FusedRasterizer.render_batch()` returns, per view, the same dict as the drop-in `render()`
+(render.py / gaussian_renderer/__init__.py:97-103) but goes through the raw-parameter entry points of
+include/b3gs_raster.h:
   * the parameter accessors of scene/gaussian_model.py:95-115 (exp / normalize / sigmoid / cat) and
-    their backward run inside the per-Gaussian HIP kernels -- no PyTorch elementwise kernels,
-  * gradients are accumulated (+=) directly into the `.grad` views of the flat gradient slab
-    (step.FlatGradSlab): no per-view AccumulateGrad adds, nothing to pack before the all-reduce,
+    their backward run inside the per-Gaussian HIP kernels -- no PyTorch elementwise kernels;
   * geometry / binning / image state lives in persistent per-slot buffers sized once (288 GB of HBM
     make over-allocation free), N stays on the device: zero allocations and zero host syncs per
-    view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph),
-  * every slot owns a HIP stream: the views of an iteration are independent until their gradients
-    meet in the slab, and the binning kernels (a few hundred workgroups each) leave most of the 256
-    CUs idle, so running the 6 views of an iteration concurrently hides them behind other views'
-    blend kernels.  Autograd runs each view's backward on the stream its forward used; the
-    non-atomic `+=` into the shared slab is ordered across streams by an event chain.
+    view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph);
+  * forward: projection + binning of every view on its own HIP stream (the binning kernels are a few
+    hundred workgroups each and leave most of the 256 CUs idle), then ONE blend launch for all
+    views (b3gs_blend_forward_batch);
+  * backward: ONE blend-backward launch for all views (b3gs_blend_backward_batch, per-view scratch),
+    then ONE pass over the Gaussians for all views (b3gs_backward_raw_accumulate): gradients are
+    stored (or accumulated) straight into the `.grad` views of the flat slab, together with the
+    densification statistics of the views that ask for them.
 Results equal the drop-in path up to activation rounding (tests/test_gpu_fused.py).
 """
 from __future__ import annotations
@@ -26,6 +27,8 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
+
+MAX_BATCH = 8   # views per batched launch (B3GS_MAX_FUSED_VIEWS)
 
 
 class _Slot:
@@ -58,20 +61,27 @@ class _ViewOutputs(dict):
         raise KeyError(key)
 
 
-class _RasterizeRaw(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, owner, slot_idx, view):
-        owner._forward(slot_idx, view)
-        s = owner.slots[slot_idx]
-        ctx.owner, ctx.slot_idx, ctx.view = owner, slot_idx, view
-        ctx.mark_non_differentiable(s.radii)
-        return s.color, s.radii, s.depth, s.alpha
+class _RasterizeBatch(torch.autograd.Function):
+    """All views of a render_batch() call as one autograd node: 4 outputs per view
+    (colour, radii, depth, alpha); the backward receives every view's pixel gradients at once."""
 
     @staticmethod
-    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
-        ctx.owner._backward(ctx.slot_idx, ctx.view, g_color, g_depth, g_alpha)
-        # gradients were accumulated in place into the parameters' .grad (flat slab views)
-        return (None,) * 9
+    def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, owner, specs):
+        owner._forward_batch(specs)
+        ctx.owner, ctx.specs = owner, specs
+        outs = []
+        for sp in specs:
+            s = owner.slots[sp["slot"]]
+            ctx.mark_non_differentiable(s.radii)
+            outs += [s.color, s.radii, s.depth, s.alpha]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        per_view = [(grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]) for k in range(len(ctx.specs))]
+        ctx.owner._backward_batch(ctx.specs, per_view)
+        # gradients are written in place into the parameters' .grad (flat slab views)
+        return (None,) * 8
 
 
 class FusedRasterizer:
@@ -86,13 +96,10 @@ class FusedRasterizer:
         self.P = p.shape[0]
         self.K = model._features_dc.shape[1] + model._features_rest.shape[1]
         self.capacity = int(binning_capacity) if binning_capacity else max(4_000_000, 12 * self.P)
-        self.concurrent = bool(concurrent)
+        self.concurrent = bool(concurrent)   # bin the views of a batch on separate streams
         self._want_m2d = want_means2D
-        self.slots: List[_Slot] = []
-        for _ in range(num_slots):
-            self.slots.append(self._new_slot(torch.cuda.Stream(self.dev) if self.concurrent else None))
-        self._acc_event: Optional[torch.cuda.Event] = None   # tail of the accumulate chain
-        self._deferred = None   # list of (slot_idx, B3gsScene) while a deferred-accumulate section is open
+        self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev)) for _ in range(num_slots)]
+        self._deferred = None   # [(spec, B3gsScene)] while a deferred-accumulate section is open
         self._params = _lib.B3gsRawParams()
         self._grads = _lib.B3gsRawGrads()
 
@@ -101,13 +108,12 @@ class FusedRasterizer:
         return _Slot(self.P, self.W, self.H, self.capacity, self.dev, self._want_m2d,
                      L.b3gs_backward_scratch_floats(self.P), stream)
 
-    # ---- C-ABI calls ------------------------------------------------------------------------
-    def _scene(self, view) -> _lib.B3gsScene:
-        cam, bg, scaling_modifier, debug = view[:4]
-        m = self.model
+    # ---- C-ABI plumbing -----------------------------------------------------------------------
+    def _scene(self, sp) -> _lib.B3gsScene:
+        cam, m = sp["cam"], self.model
         return _lib.B3gsScene(self.P, int(m.active_sh_degree), int(self.K), self.W, self.H,
-                              math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(scaling_modifier), 0,
-                              int(bool(debug)), bg.data_ptr(), None, None, None, None, None, None, None,
+                              math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), float(sp["scaling_modifier"]), 0,
+                              int(bool(sp["debug"])), sp["bg"].data_ptr(), None, None, None, None, None, None, None,
                               cam.world_view_transform.data_ptr(), cam.full_proj_transform.data_ptr(),
                               cam.camera_center.data_ptr())
 
@@ -118,66 +124,104 @@ class FusedRasterizer:
         rp.scaling, rp.rotation, rp.opacity = m._scaling.data_ptr(), m._rotation.data_ptr(), m._opacity.data_ptr()
         return rp
 
-    def _forward(self, slot_idx, view):
-        L, s = _lib.lib(), self.slots[slot_idx]
-        sc = self._scene(view)
-        rc = L.b3gs_forward_raw(C.byref(sc), C.byref(self._bind_params()), s.geom.data_ptr(), s.binning.data_ptr(),
-                                s.capacity, s.img.data_ptr(), s.color.data_ptr(), s.depth.data_ptr(),
-                                s.alpha.data_ptr(), s.radii.data_ptr(), s.n_dev.data_ptr(),
-                                torch.cuda.current_stream(self.dev).cuda_stream)
-        _lib.check(rc, "b3gs_forward_raw")
-
-    def _backward(self, slot_idx, view, g_color, g_depth, g_alpha):
-        L, s, m = _lib.lib(), self.slots[slot_idx], self.model
-        sc = self._scene(view)
-        gr = self._grads
+    def _bind_grads(self):
+        m, gr = self.model, self._grads
         for name, p in (("xyz", m._xyz), ("features_dc", m._features_dc), ("features_rest", m._features_rest),
                         ("scaling", m._scaling), ("rotation", m._rotation), ("opacity", m._opacity)):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             setattr(gr, name, p.grad.data_ptr() if p.numel() else None)
-        if g_color is None:
-            g_color = torch.zeros((3, self.H, self.W), dtype=torch.float32, device=self.dev)
-        gc = g_color.contiguous()
-        gd = None if g_depth is None else g_depth.contiguous()
-        ga = None if g_alpha is None else g_alpha.contiguous()
-        stream = torch.cuda.current_stream(self.dev)   # autograd runs this node on the forward's stream
+        return gr
 
-        def call(phases):
-            rc = L.b3gs_backward_raw(C.byref(sc), C.byref(self._bind_params()), s.radii.data_ptr(), s.geom.data_ptr(),
-                                     s.binning.data_ptr(), s.img.data_ptr(), gc.data_ptr(),
-                                     None if gd is None else gd.data_ptr(), None if ga is None else ga.data_ptr(),
-                                     s.scratch.data_ptr(), C.byref(gr),
-                                     None if s.means2D_grad is None else s.means2D_grad.data_ptr(), phases,
-                                     stream.cuda_stream)
-            _lib.check(rc, "b3gs_backward_raw")
+    def _blend_table(self, specs, scenes, grads=None):
+        arr = (_lib.B3gsBlendView * len(specs))()
+        keep = []
+        for k, (sp, sc) in enumerate(zip(specs, scenes)):
+            s = self.slots[sp["slot"]]
+            arr[k].view = C.pointer(sc)
+            arr[k].geometry, arr[k].binning, arr[k].image = s.geom.data_ptr(), s.binning.data_ptr(), s.img.data_ptr()
+            arr[k].out_color, arr[k].out_depth, arr[k].out_alpha = s.color.data_ptr(), s.depth.data_ptr(), s.alpha.data_ptr()
+            if grads is not None:
+                gc, gd, ga = grads[k]
+                if gc is None:
+                    gc = torch.zeros((3, self.H, self.W), dtype=torch.float32, device=self.dev)
+                gc = gc.contiguous()
+                gd = None if gd is None else gd.contiguous()
+                ga = None if ga is None else ga.contiguous()
+                keep += [gc, gd, ga]
+                arr[k].dL_dcolor = gc.data_ptr()
+                arr[k].dL_ddepth = None if gd is None else gd.data_ptr()
+                arr[k].dL_dalpha = None if ga is None else ga.data_ptr()
+                arr[k].scratch = s.scratch.data_ptr()
+        return arr, keep
 
-        if self._deferred is not None:            # phase 2 of all views is fused into finish_deferred()
-            call(1)
-            self._deferred.append((slot_idx, sc, bool(view[4]) if len(view) > 4 else False))
+    def _forward_batch(self, specs):
+        L = _lib.lib()
+        main = torch.cuda.current_stream(self.dev)
+        scenes = [self._scene(sp) for sp in specs]
+        rp = self._bind_params()
+        if self.concurrent:
+            # Every view runs its whole forward on its own stream.  Measured (1M Gaussians, 6 views): the
+            # binning kernels of one view overlap well with the BLEND kernel of another (forward phase
+            # 1.79 ms), but not with each other (binning on 6 streams + one batched blend: 2.26 ms).
+            for sp, sc in zip(specs, scenes):
+                s = self.slots[sp["slot"]]
+                s.stream.wait_stream(main)
+                rc = L.b3gs_forward_raw(C.byref(sc), C.byref(rp), s.geom.data_ptr(), s.binning.data_ptr(), s.capacity,
+                                        s.img.data_ptr(), s.color.data_ptr(), s.depth.data_ptr(), s.alpha.data_ptr(),
+                                        s.radii.data_ptr(), s.n_dev.data_ptr(), 3, s.stream.cuda_stream)
+                _lib.check(rc, "b3gs_forward_raw")
+            for sp in specs:
+                main.wait_stream(self.slots[sp["slot"]].stream)
             return
-        if not self.concurrent:
-            call(3)
-            return
-        call(1)                                   # blend backward: private scratch, runs concurrently
-        if self._acc_event is not None:
-            stream.wait_event(self._acc_event)    # the += into the shared slab is not atomic: one view at a time
-        call(2)
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        self._acc_event = ev
+        # single stream: projection + binning per view, then one blend launch per <= 8 views
+        for sp, sc in zip(specs, scenes):
+            s = self.slots[sp["slot"]]
+            rc = L.b3gs_forward_raw(C.byref(sc), C.byref(rp), s.geom.data_ptr(), s.binning.data_ptr(), s.capacity,
+                                    s.img.data_ptr(), None, None, None, s.radii.data_ptr(), s.n_dev.data_ptr(), 1,
+                                    main.cuda_stream)
+            _lib.check(rc, "b3gs_forward_raw(phase 1)")
+        for c0 in range(0, len(specs), MAX_BATCH):
+            arr, _ = self._blend_table(specs[c0:c0 + MAX_BATCH], scenes[c0:c0 + MAX_BATCH])
+            _lib.check(L.b3gs_blend_forward_batch(len(arr), arr, main.cuda_stream), "b3gs_blend_forward_batch")
+
+    def _backward_batch(self, specs, grads):
+        L = _lib.lib()
+        stream = torch.cuda.current_stream(self.dev)
+        scenes = [self._scene(sp) for sp in specs]
+        for c0 in range(0, len(specs), MAX_BATCH):
+            arr, keep = self._blend_table(specs[c0:c0 + MAX_BATCH], scenes[c0:c0 + MAX_BATCH], grads[c0:c0 + MAX_BATCH])
+            _lib.check(L.b3gs_blend_backward_batch(len(arr), arr, stream.cuda_stream), "b3gs_blend_backward_batch")
+            del keep
+        pend = list(zip(specs, scenes))
+        if self._deferred is not None:
+            self._deferred += pend            # per-Gaussian pass happens once, in finish_deferred()
+        else:
+            self._accumulate(pend, overwrite=False)
+
+    def _accumulate(self, pend, overwrite: bool):
+        L, m = _lib.lib(), self.model
+        gr = self._bind_grads()
+        stats = None
+        if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
+            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr())
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        for c0 in range(0, len(pend), MAX_BATCH):
+            chunk = pend[c0:c0 + MAX_BATCH]
+            arr = (_lib.B3gsFusedView * len(chunk))()
+            for k, (sp, sc) in enumerate(chunk):
+                sl = self.slots[sp["slot"]]
+                arr[k].view = C.pointer(sc)
+                arr[k].radii, arr[k].geometry = sl.radii.data_ptr(), sl.geom.data_ptr()
+                arr[k].scratch = sl.scratch.data_ptr()
+                arr[k].dL_dmeans2D = None if sl.means2D_grad is None else sl.means2D_grad.data_ptr()
+                arr[k].densify_stats = int(bool(sp["densify_stats"]) and stats is not None)
+            rc = L.b3gs_backward_raw_accumulate(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
+                                                int(bool(overwrite) and c0 == 0),
+                                                None if stats is None else C.byref(stats), stream)
+            _lib.check(rc, "b3gs_backward_raw_accumulate")
 
     # ---- public -----------------------------------------------------------------------------
-    def _render_on_current_stream(self, viewpoint_camera, bg_color, slot, scaling_modifier, debug,
-                                  densify_stats=False) -> dict:
-        m = self.model
-        view = (viewpoint_camera, bg_color, scaling_modifier, debug, densify_stats)
-        color, radii, depth, alpha = _RasterizeRaw.apply(m._xyz, m._features_dc, m._features_rest, m._scaling,
-                                                         m._rotation, m._opacity, self, slot, view)
-        s = self.slots[slot]
-        return _ViewOutputs({"render": color, "viewspace_points_grad": s.means2D_grad, "radii": radii,
-                             "rendered_depth": depth, "rendered_alpha": alpha})
-
     def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
                debug: bool = False) -> dict:
         """One view.  Same keys as render(); `viewspace_points_grad` ([P,3], filled by backward) replaces
@@ -186,77 +230,38 @@ class FusedRasterizer:
 
     def render_batch(self, views: Sequence, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
                      debug: bool = False) -> List[dict]:
-        """Render [(camera, slot[, densify_stats]), ...] concurrently (one stream per slot); views with
-        densify_stats=True feed the model's densification statistics (init_densification_stats) in
-        finish_deferred(), as the primary view does at train.py:178-179.  On return the current stream
-        has been made to wait for all of them, so the outputs can be consumed normally.  Calling
-        backward ONCE on a loss that depends on several of the views lets autograd run their backward
-        passes concurrently as well."""
-        views = [(v[0], v[1], (v[2] if len(v) > 2 else False)) for v in views]
-        if not self.concurrent:
-            return [self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug, ds)
-                    for cam, slot, ds in views]
-        main = torch.cuda.current_stream(self.dev)
+        """Render [(camera, slot[, densify_stats]), ...]: binning concurrently (one stream per slot), then
+        one blend launch; the outputs live on the current stream.  Views with densify_stats=True feed
+        the model's densification statistics (init_densification_stats), as the primary view does at
+        train.py:178-179.  All views of the call form ONE autograd node."""
+        m = self.model
+        specs = tuple({"cam": v[0], "slot": int(v[1]), "densify_stats": bool(v[2]) if len(v) > 2 else False,
+                       "bg": bg_color, "scaling_modifier": scaling_modifier, "debug": debug} for v in views)
+        assert len({sp["slot"] for sp in specs}) == len(specs), "each view of a batch needs its own slot"
+        flat = _RasterizeBatch.apply(m._xyz, m._features_dc, m._features_rest, m._scaling, m._rotation, m._opacity,
+                                     self, specs)
         out = []
-        self._acc_event = None
-        for cam, slot, ds in views:
-            st = self.slots[slot].stream
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                out.append(self._render_on_current_stream(cam, bg_color, slot, scaling_modifier, debug, ds))
-        for _, slot, _ds in views:
-            main.wait_stream(self.slots[slot].stream)
+        for k, sp in enumerate(specs):
+            color, radii, depth, alpha = flat[4 * k:4 * k + 4]
+            out.append(_ViewOutputs({"render": color, "viewspace_points_grad": self.slots[sp["slot"]].means2D_grad,
+                                     "radii": radii, "rendered_depth": depth, "rendered_alpha": alpha}))
         return out
 
     def begin_deferred(self):
-        """Open a section in which every view's backward only runs the blend backward (phase 1, own
-        scratch, own stream); finish_deferred() then does the per-Gaussian chain rule of ALL those
-        views in one kernel (b3gs_backward_raw_accumulate)."""
+        """Open a section in which backward passes only run the blend backward (per-view scratch);
+        finish_deferred() then does the per-Gaussian chain rule of ALL their views in one kernel."""
         self._deferred = []
 
     def finish_deferred(self, overwrite: bool = True):
-        """Join the view streams and accumulate every deferred view in one pass over the Gaussians.
-        overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them."""
+        """overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them."""
         pend, self._deferred = self._deferred, None
-        self.join()
         if not pend:
             if overwrite:
                 for p in self.model.parameters():
                     if p.grad is not None:
                         p.grad.zero_()
             return
-        L, m = _lib.lib(), self.model
-        gr = self._grads
-        for name, p in (("xyz", m._xyz), ("features_dc", m._features_dc), ("features_rest", m._features_rest),
-                        ("scaling", m._scaling), ("rotation", m._rotation), ("opacity", m._opacity)):
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            setattr(gr, name, p.grad.data_ptr() if p.numel() else None)
-        stats = None
-        if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
-            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr())
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        for c0 in range(0, len(pend), 8):
-            chunk = pend[c0:c0 + 8]
-            arr = (_lib.B3gsFusedView * len(chunk))()
-            for k, (slot_idx, sc, want_stats) in enumerate(chunk):
-                sl = self.slots[slot_idx]
-                arr[k].densify_stats = int(want_stats and stats is not None)
-                arr[k].view = C.pointer(sc)
-                arr[k].radii, arr[k].geometry = sl.radii.data_ptr(), sl.geom.data_ptr()
-                arr[k].scratch = sl.scratch.data_ptr()
-                arr[k].dL_dmeans2D = None if sl.means2D_grad is None else sl.means2D_grad.data_ptr()
-            rc = L.b3gs_backward_raw_accumulate(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
-                                                int(bool(overwrite) and c0 == 0),
-                                                None if stats is None else C.byref(stats), stream)
-            _lib.check(rc, "b3gs_backward_raw_accumulate")
-
-    def join(self):
-        """Make the current stream wait for every slot stream (call before consuming the slab)."""
-        if self.concurrent:
-            main = torch.cuda.current_stream(self.dev)
-            for s in self.slots:
-                main.wait_stream(s.stream)
+        self._accumulate(pend, overwrite)
 
     def num_rendered(self):
         """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered

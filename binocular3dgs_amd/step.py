@@ -139,9 +139,9 @@ class ViewShardedStep:
         return n_rendered
 
     def _step_fused(self, pair_grad_fn, loss_fn):
-        """All views of the step are rendered concurrently (one stream per view), the loss / upstream
-        gradients of every pair are formed on the current stream, and ONE backward call lets autograd
-        run the per-view backward passes concurrently on the streams their forwards used."""
+        """All views of the step in one render_batch() (binning concurrent, one blend launch), the loss /
+        upstream gradients of every pair formed on the current stream, ONE backward call (one blend-
+        backward launch for all views), then one per-Gaussian pass for all views (finish_deferred)."""
         views = []
         for i, (cam, scam, t) in enumerate(self.pairs):
             a, b = self._slots[i]

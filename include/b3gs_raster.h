@@ -134,9 +134,33 @@ typedef struct B3gsRawGrads {  /* accumulated into (+=); same shapes as B3gsRawP
 /* Sync-free forward (see b3gs_forward_capacity) on raw parameters.  `view` supplies P, D, M (= total
  * SH coefficients per channel), W, H, tan_fov*, scale_modifier, prefiltered, debug, background,
  * viewmatrix, projmatrix, campos; its per-Gaussian tensor pointers are ignored. */
+/* `phases`: bit 0 = per-Gaussian projection + binning (ends with the tile lists in `binning`), bit 1 =
+ * blend forward (the three output images); 3 = both.  A caller rendering several views runs phase 1 of
+ * each view on its own stream and then ONE b3gs_blend_forward_batch() for all of them. */
 int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
                      int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
-                     int32_t* radii, int32_t* device_num_rendered, b3gs_stream_t stream);
+                     int32_t* radii, int32_t* device_num_rendered, int phases, b3gs_stream_t stream);
+
+/* Blend (per-tile alpha compositing) of up to 8 views in ONE launch each way.  One view's ~1900 tiles fill
+ * the 256 CUs roughly once, so a per-view launch pays its own tail; batched, the dispatcher packs the tiles
+ * of all views (MI355X, 1M Gaussians, 800x600: forward 126 us per view alone, 74 us per view batched).
+ * forward: needs every view's b3gs_forward_raw(..., phases = 1) complete on a stream `stream` waits for;
+ * backward: = phase 1 of b3gs_backward_raw for every view (own zeroed `scratch` each). */
+typedef struct B3gsBlendView {
+  const B3gsScene* view;
+  const char* geometry;
+  const char* binning;
+  const char* image;
+  float* out_color;          /* forward */
+  float* out_depth;
+  float* out_alpha;
+  const float* dL_dcolor;    /* backward */
+  const float* dL_ddepth;    /* may be NULL */
+  const float* dL_dalpha;    /* may be NULL */
+  float* scratch;            /* backward: b3gs_backward_scratch_floats(P) zeroed floats */
+} B3gsBlendView;
+int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
+int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
 
 /* Backward of b3gs_forward_raw.  `scratch` holds b3gs_backward_scratch_floats(P) floats that must be
  * ZERO on entry and are left zero on exit (persistent across views: no per-view memset).
