@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--optimizer", choices=("b3gs", "torch"), default="b3gs",
+                    help="b3gs: one-launch fused Adam (b3gs_adam_step); torch: torch.optim.Adam(fused=True), 12 launches")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
                     help="fused: b3gs_forward_raw/backward_raw (activations in-kernel, persistent scratch, no host sync); "
@@ -100,8 +102,12 @@ def main():
     if not args.no_optimizer:
         # learning rates of arguments/__init__.py:75-82, eps of scene/gaussian_model.py:163
         lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]
-        opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), lrs)], lr=0.0,
-                               eps=1e-15, fused=True)
+        if args.optimizer == "b3gs":
+            from binocular3dgs_amd.step import FusedAdam
+            opt = FusedAdam(model.parameters(), lrs, eps=1e-15)
+        else:
+            opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), lrs)], lr=0.0,
+                                   eps=1e-15, fused=True)
     fused = None
     if args.path == "fused":
         from binocular3dgs_amd.fused import FusedRasterizer
@@ -153,7 +159,7 @@ def main():
     elif use_graph:
         # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
         # (6 views fwd+bwd, slab zero, Adam) is one hipGraph launch
-        if opt is not None:
+        if opt is not None and args.optimizer == "torch":
             for g_ in opt.param_groups:
                 g_["capturable"] = True
             for st_ in opt.state.values():
@@ -263,7 +269,8 @@ def main():
                        "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
                        "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
-                       "optimizer_in_step": opt is not None, "path": args.path, "hip_graph": bool(use_graph),
+                       "optimizer_in_step": opt is not None,
+                       "optimizer": None if opt is None else args.optimizer, "path": args.path, "hip_graph": bool(use_graph),
                        "view_streams": (len(fused.slots) if fused is not None and fused.concurrent else 1),
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},

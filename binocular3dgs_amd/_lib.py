@@ -51,6 +51,11 @@ class B3gsBlendView(C.Structure):
                 ("dL_dalpha", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class B3gsAdamSegment(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("count", C.c_int64), ("lr", C.c_float)]
+
+
 class B3gsDensifyStats(C.Structure):
     _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
 
@@ -70,7 +75,8 @@ class B3gsKernelTimes(C.Structure):
 EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timing_collect", "b3gs_geometry_bytes", "b3gs_image_bytes",
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
-           "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch")
+           "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
+           "b3gs_adam_step")
 
 _lib = None
 
@@ -126,6 +132,9 @@ def lib():
                                                C.POINTER(B3gsRawGrads), C.c_int32, C.POINTER(B3gsDensifyStats),
                                                C.c_void_p]
     L.b3gs_backward_raw_accumulate.restype = C.c_int
+    L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_int32, C.c_void_p]
+    L.b3gs_adam_step.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int
     L.b3gs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

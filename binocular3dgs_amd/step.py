@@ -61,6 +61,52 @@ class FlatGradSlab:
         return self.flat.numel() * 4
 
 
+class FusedAdam:
+    """torch.optim.Adam semantics (betas, eps, per-tensor learning rates; no weight decay / amsgrad) for
+    all parameter tensors of the model in one HIP launch (b3gs_adam_step), step counter on the device
+    (graph-replayable).  `opacity_decay` (e.g. 0.995, train.py:171-173,278-279) is applied to the tensor
+    with index `opacity_index` after its update when set.  State lives in two flat fp32 buffers."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], lrs: Sequence[float], betas=(0.9, 0.999), eps=1e-15,
+                 opacity_decay: float = 0.0, opacity_index: int = -1):
+        import ctypes as C
+
+        from . import _lib
+        self._C, self._lib = C, _lib
+        self.params = list(params)
+        self.lrs = [float(x) for x in lrs]
+        assert len(self.params) == len(self.lrs) <= 8
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.betas, self.eps = betas, float(eps)
+        self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
+
+    def step(self):
+        C, _lib = self._C, self._lib
+        segs = (_lib.B3gsAdamSegment * len(self.params))()
+        off = 0
+        for k, (p, lr) in enumerate(zip(self.params, self.lrs)):
+            assert p.grad is not None and p.is_contiguous() and p.grad.is_contiguous()
+            segs[k].param, segs[k].grad = p.data_ptr(), p.grad.data_ptr()
+            segs[k].exp_avg = self.exp_avg.data_ptr() + 4 * off
+            segs[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * off
+            segs[k].count, segs[k].lr = p.numel(), lr
+            off += p.numel()
+        dev = self.params[0].device
+        rc = _lib.lib().b3gs_adam_step(len(self.params), segs, self.step_count.data_ptr(), self.betas[0], self.betas[1],
+                                       self.eps, self.opacity_decay, self.opacity_index,
+                                       torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "b3gs_adam_step")
+
+    def zero_grad(self, set_to_none: bool = False):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+
 def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
     """Round-robin assignment of view pairs to ranks (pair i -> rank i % world)."""
     return [i for i in range(num_pairs) if i % world == rank]

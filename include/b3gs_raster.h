@@ -200,6 +200,24 @@ int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, con
                                  const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
                                  b3gs_stream_t stream);
 
+/* ---- fused optimiser step -----------------------------------------------------------
+ * Adam exactly as torch.optim.Adam (no amsgrad, no weight decay) for up to 8 parameter tensors with their
+ * own learning rates in ONE launch: the reference's six parameter groups (scene/gaussian_model.py:154-167,
+ * eps = 1e-15) and optimizer.step() at train.py:196-198.  `device_step` (int32 on the device, incremented
+ * by the call) keeps the bias correction replayable from a HIP graph.  opacity_decay > 0 additionally
+ * applies  o <- logit(sigmoid(o) * opacity_decay)  to segment `opacity_segment` after its update
+ * (gaussian_model.py:307-309, train.py:171-173). */
+typedef struct B3gsAdamSegment {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t count;  /* floats */
+  float lr;
+} B3gsAdamSegment;
+int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
+                   float eps, float opacity_decay, int32_t opacity_segment, b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);

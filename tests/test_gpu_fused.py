@@ -161,3 +161,34 @@ def test_densification_statistics_match_reference_formula():
     assert float(got[2].max()) == 2.0 * len(pairs)
     assert rel_l2(got[1].reshape(-1)[same].cpu().numpy(), ref.xyz_gradient_accum.reshape(-1)[same].cpu().numpy()) < 2e-3
     assert float((got[0][same] != ref.max_radii2D[same]).float().mean()) < 1e-3
+
+
+def test_fused_adam_matches_torch_adam_and_opacity_decay():
+    from binocular3dgs_amd.step import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 3, 3), (5000, 3), (5000, 4), (5000, 1)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs)], eps=1e-15)
+    mine = FusedAdam(b, lrs, eps=1e-15)
+    for it in range(5):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p) * (10.0 ** (it - 3))
+            p.grad = g.clone()
+            q.grad = g.clone()
+        ref.step()
+        mine.step()
+    torch.cuda.synchronize()
+    assert int(mine.step_count.item()) == 5
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) < 2e-6 * max(1.0, float(p.abs().max()))
+    # opacity decay on the last tensor: o <- logit(sigmoid(o_updated) * 0.995)
+    dec = FusedAdam(b, lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5)
+    before = b[5].detach().clone()
+    for q in b:
+        q.grad = torch.zeros_like(q)
+    dec.step()
+    torch.cuda.synchronize()
+    s = torch.sigmoid(before) * 0.995
+    assert float((b[5] - torch.log(s / (1 - s))).abs().max()) < 1e-5
