@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
                     help="fused: b3gs_forward_raw/backward_raw (activations in-kernel, persistent scratch, no host sync); "
                          "dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
+    ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched",
+                    help="batched: every stage one launch for all 6 views, pairs share a depth sort; "
+                         "streams: one stream per view; serial: one stream, per-view launches")
     ap.add_argument("--serial-views", action="store_true",
                     help="render the views one after the other on one stream (un-overlapped kernel times, for profiles)")
     ap.add_argument("--dp-path", action="store_true",
@@ -111,7 +114,8 @@ def main():
     fused = None
     if args.path == "fused":
         from binocular3dgs_amd.fused import FusedRasterizer
-        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), concurrent=not args.serial_views)
+        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs),
+                                schedule="serial" if args.serial_views else args.schedule)
     stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt, fused=fused)
     stepper.slab.force_collective = bool(args.dp_path)
 
@@ -190,19 +194,23 @@ def main():
         views += 2 * len(pairs)
     barrier()
     t1 = time.perf_counter()
-    if use_graph or (fused is not None and fused.concurrent):
-        # per-kernel durations need the kernels un-overlapped: a few eager iterations with the views
-        # rendered one after the other on one stream (same workload, same kernels), after the timed region
-        L.b3gs_timing_collect()            # resolve (and discard) stages parked during the overlapped region
+    timed_views = args.steps * 2 * len(pairs)
+    if use_graph or (fused is not None and fused.schedule == "streams"):
+        # per-kernel durations need eager launches on one stream: a few more iterations after the timed
+        # region, same workload and kernels ("batched" keeps its batched launches; "streams" cannot be
+        # timed per kernel while overlapped and is issued view by view here)
+        L.b3gs_timing_collect()            # resolve (and discard) stages parked during the timed region
         L.b3gs_set_timing(None)
         times = _lib.B3gsKernelTimes()
         L.b3gs_set_timing(C.byref(times))
-        was = fused.concurrent
-        fused.concurrent = False
+        was = fused.schedule
+        if was == "streams":
+            fused.schedule, fused.concurrent = "serial", False
         for _ in range(min(args.steps, 5)):
             stepper.step(pair_grad_fn=grad_fn)
         barrier()
-        fused.concurrent = was
+        fused.schedule, fused.concurrent = was, was == "streams"
+        timed_views = min(args.steps, 5) * 2 * len(pairs)
     L.b3gs_timing_collect()
     L.b3gs_set_timing(None)
     elapsed = t1 - t0
@@ -218,7 +226,7 @@ def main():
         from binocular3dgs_amd.render import render
         pkg = render(pairs[0][0], model, PipelineParams(), bg)
         V = int((pkg["radii"] > 0).sum().item())
-    n_views = max(int(times.calls), 1)
+    n_views = max(timed_views, 1)
     # N: read back from one more forward through the C ABI surface
     from binocular3dgs_amd import _C
     with torch.no_grad():
@@ -247,6 +255,10 @@ def main():
         # + 4-byte index per tile instance; fwd writes 28 B/pixel, bwd reads 28 B/pixel and updates
         # 10 fp32 accumulators per visible Gaussian (read+write = 80 B)
         dom_bytes = (48 * N + 28 * HW + 8 * Tn) if dom == "render_fwd" else (48 * N + 28 * HW + 8 * Tn + 80 * V)
+        # views per launch of that kernel: the blend backward always takes all views of the iteration, the
+        # blend forward does unless every view runs on its own stream
+        vpl = views_per_iter if (fused is not None and (dom == "render_bwd" or fused.schedule != "streams")) else 1
+        vpl = min(vpl, 8)
         dom_s = single[dom] / 1e3
         achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
         R, Wt = byte_model(P, V, N, HW, Tn)
@@ -271,13 +283,13 @@ def main():
                        "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
                        "optimizer_in_step": opt is not None,
                        "optimizer": None if opt is None else args.optimizer, "path": args.path, "hip_graph": bool(use_graph),
-                       "view_streams": (len(fused.slots) if fused is not None and fused.concurrent else 1),
+                       "schedule": None if fused is None else fused.schedule,
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
             "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_launch": dom_bytes,
-                         "avg_launch_ms": round(single[dom], 4),
+                         "traffic": None if traffic is None else traffic * vpl, "bytes_per_launch": dom_bytes * vpl,
+                         "avg_launch_ms": round(single[dom] * vpl, 4), "views_per_launch": vpl,
                          "note": "blend kernels are VALU/LDS-bound (SURVEY 8d caveat); see pixgauss_evals_per_s"},
             "roofline_view": {"bound": "hbm", "bytes_per_view": R + Wt, "read_bytes_per_view": R,
                               "kernel_ms_per_view": round(view_ms, 4),

@@ -51,6 +51,13 @@ class B3gsBlendView(C.Structure):
                 ("dL_dalpha", C.c_void_p), ("scratch", C.c_void_p)]
 
 
+class B3gsForwardView(C.Structure):
+    _fields_ = [("view", C.POINTER(B3gsScene)), ("geometry", C.c_void_p), ("binning", C.c_void_p),
+                ("binning_capacity", C.c_int64), ("image", C.c_void_p), ("out_color", C.c_void_p),
+                ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
+                ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32)]
+
+
 class B3gsAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("count", C.c_int64), ("lr", C.c_float)]
@@ -76,7 +83,7 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
-           "b3gs_adam_step")
+           "b3gs_adam_step", "b3gs_forward_raw_batch")
 
 _lib = None
 
@@ -132,6 +139,9 @@ def lib():
                                                C.POINTER(B3gsRawGrads), C.c_int32, C.POINTER(B3gsDensifyStats),
                                                C.c_void_p]
     L.b3gs_backward_raw_accumulate.restype = C.c_int
+    L.b3gs_forward_raw_batch.argtypes = [C.c_int32, C.POINTER(B3gsForwardView), C.POINTER(B3gsRawParams), C.c_int,
+                                         C.c_void_p]
+    L.b3gs_forward_raw_batch.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int

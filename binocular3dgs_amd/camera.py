@@ -111,6 +111,9 @@ class Camera:
         wvt = self.world_view_transform.clone()
         wvt[3, 0] -= float(trans_dist)
         cam._set(wvt, self.projection_matrix)
+        # only world_view_transform[3, 0] differs: every Gaussian has the same view-space z in both cameras, so
+        # the pair can share one depth sort (FusedRasterizer, b3gs_forward_raw_batch depth_order_from)
+        cam.same_depth_as = getattr(self, "same_depth_as", None) or self
         return cam
 
 

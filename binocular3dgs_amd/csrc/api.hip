@@ -187,10 +187,21 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
 
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_preprocess(wrap(sc), g, im, radii, s);
+  {
+    const SceneX sx = wrap(sc);
+    PreBatch pb;
+    pb.n = 1;
+    pb.raw_mode = sx.raw_mode;
+    pb.tight = sx.tight;
+    pb.raw = sx.raw;
+    pb.sc[0] = sx.sc;
+    pb.out[0] = b3gs_pre_out(sx.sc, g, im, radii);
+    b3gs_launch_preprocess(pb, s);
+  }
   if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
   tm.mark(0);
-  b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, nullptr, s);
+  BinJob job{sc->W, sc->H, g, BinView{}, im, 0, nullptr, -1, nullptr};
+  b3gs_launch_depth_order_batch(sc->P, 1, &job, s);
   if ((rc = debug_sync(sc, s, "depth sort + scan"))) return rc;
 
   // the one blocking read-back of the forward: N sizes the binning buffer
@@ -205,7 +216,9 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   BinView b;
   b3gs_bin_view(bbuf, sc->P, N, &b);
 
-  b3gs_launch_binning(sc->P, sc->W, sc->H, N, g, b, im, s);
+  job.b = b;
+  job.n_bound = N;
+  b3gs_launch_tile_lists_batch(sc->P, 1, &job, s);
   if ((rc = debug_sync(sc, s, "binning"))) return rc;
   tm.mark(1);
   blend_forward_one(*sc, g, b, im, out_color, out_depth, out_alpha, s);
@@ -231,12 +244,19 @@ static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning
   StageTimer tm(s);
   tm.mark(-1);
   if (phases & 1) {
-    b3gs_launch_preprocess(sx, g, im, radii, s);
+    PreBatch pb;
+    pb.n = 1;
+    pb.raw_mode = sx.raw_mode;
+    pb.tight = sx.tight;
+    pb.raw = sx.raw;
+    pb.sc[0] = sx.sc;
+    pb.out[0] = b3gs_pre_out(sx.sc, g, im, radii);
+    b3gs_launch_preprocess(pb, s);
     tm.mark(0);
-    b3gs_launch_depth_sort_and_scan(sc->P, g, im.header, device_num_rendered, s);
     // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
     // list, which the caller detects from *device_num_rendered > capacity and repeats
-    b3gs_launch_binning(sc->P, sc->W, sc->H, binning_capacity, g, b, im, s);
+    BinJob job{sc->W, sc->H, g, b, im, binning_capacity, device_num_rendered, -1, nullptr};
+    b3gs_launch_binning_batch(sc->P, 1, &job, s);
     tm.mark(1);
   }
   if (phases & 2) {
@@ -268,6 +288,61 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
   sx.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
   return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
                                device_num_rendered, phases, (hipStream_t)stream);
+}
+
+int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
+                           b3gs_stream_t stream) {
+  if (nviews <= 0 || nviews > B3GS_MAX_FUSED_VIEWS || !views) return fail(B3GS_ERR_ARG, "%s", "nviews must be 1..8");
+  hipStream_t s = (hipStream_t)stream;
+  PreBatch pb;
+  BinJob jobs[B3GS_MAX_FUSED_VIEWS];
+  BlendBatch bb;
+  pb.n = bb.n = nviews;
+  pb.raw_mode = 1;
+  pb.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
+  for (int k = 0; k < nviews; k++) {
+    const B3gsForwardView& fv = views[k];
+    int rc = check_raw(fv.view, params);
+    if (rc) return rc;
+    const B3gsScene& sc = *fv.view;
+    if (sc.P != views[0].view->P || sc.M != views[0].view->M || sc.D != views[0].view->D ||
+        sc.scale_modifier != views[0].view->scale_modifier)
+      return fail(B3GS_ERR_ARG, "%s", "views of one batch must share P, M, D, scale_modifier");
+    if (!fv.geometry || !fv.binning || !fv.image || (sc.P > 0 && !fv.radii) || fv.binning_capacity <= 0 ||
+        fv.binning_capacity > 0xFFFFFFFFll || ((phases & 2) && (!fv.out_color || !fv.out_depth || !fv.out_alpha)))
+      return fail(B3GS_ERR_ARG, "%s", "NULL buffer or bad capacity");
+    if (fv.depth_order_from != -1 &&
+        (fv.depth_order_from < 0 || fv.depth_order_from >= nviews || views[fv.depth_order_from].depth_order_from != -1))
+      return fail(B3GS_ERR_ARG, "%s", "depth_order_from must name a view of the batch that sorts its own keys");
+    GeomView g;
+    ImgView im;
+    BinView b;
+    b3gs_geom_view(fv.geometry, sc.P, &g);
+    b3gs_img_view(fv.image, sc.W, sc.H, &im);
+    b3gs_bin_view(fv.binning, sc.P, fv.binning_capacity, &b);
+    pb.sc[k] = sc;
+    pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
+    jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr};
+    bb.v[k] = b3gs_blend_view(sc, g, b, im);
+    bb.v[k].out_color = fv.out_color;
+    bb.v[k].out_depth = fv.out_depth;
+    bb.v[k].out_alpha = fv.out_alpha;
+  }
+  pb.raw = *params;
+  StageTimer tm(s);
+  tm.mark(-1);
+  if (phases & 1) {
+    b3gs_launch_preprocess(pb, s);
+    tm.mark(0);
+    b3gs_launch_binning_batch(views[0].view->P, nviews, jobs, s);
+    tm.mark(1);
+  }
+  if (phases & 2) {
+    b3gs_launch_blend_forward(bb, s);
+    tm.mark(2);
+  }
+  HIP_TRY(hipGetLastError());
+  return B3GS_OK;
 }
 
 size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)11 * (size_t)(P > 0 ? P : 0); }

@@ -119,11 +119,33 @@ struct SceneX {
   int tight;  // bin only the tiles the alpha >= 1/255 footprint can reach (fused path; see preprocess.hip)
 };
 
+#define B3GS_MAX_FUSED_VIEWS 8
+
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
 
-// also zeroes the tile ranges of `im` (the first `tiles` lanes of the launch do it)
-void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, const ImgView& im, int32_t* radii, hipStream_t s);
+// Projection of every Gaussian into up to B3GS_MAX_FUSED_VIEWS views in ONE pass over the parameters
+// (thread = Gaussian, loop over views: position / covariance / opacity are read and activated once).
+// In raw mode all views share `raw`; otherwise nviews must be 1 and the tensors come from sc[0].
+// Also zeroes every view's tile ranges.
+struct PreOut {
+  float4* rec;
+  uint32_t* depth_key;
+  uint32_t* tiles_touched;
+  uint2* rect;
+  uint32_t* clamped;
+  int32_t* radii;
+  uint2* ranges;
+  int32_t ntiles;
+};
+struct PreBatch {
+  int32_t n, raw_mode, tight;
+  B3gsRawParams raw;
+  B3gsScene sc[B3GS_MAX_FUSED_VIEWS];
+  PreOut out[B3GS_MAX_FUSED_VIEWS];
+};
+PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, int32_t* radii);
+void b3gs_launch_preprocess(const PreBatch& pb, hipStream_t s);
 void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii,
                                      float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
                                      float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
@@ -131,20 +153,30 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
                               hipStream_t s);
 
-// depth sort of all P Gaussians (culled ones sink to the end), scan of tiles_touched in depth
-// order; leaves N in g.header[0] and V in g.header[1].  Result: sorted indices in g.sval[0].
-// N is also written to img_header[0] and *n_out (device) when those are non-null.
-void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, uint32_t* img_header, int32_t* n_out,
-                                     hipStream_t s);
-// emit (tile, idx) instances in depth order, stable sort by tile id, tile ranges.
-// `n_bound` = number of instances the launch must cover (host-known N, or the capacity when N
-// lives only on the device; kernels clamp to the device-side N in g.header[0]).
-// Final lists end up in b.key[0] / b.val[0].
-void b3gs_launch_binning(int32_t P, int32_t W, int32_t H, int64_t n_bound, const GeomView& g, const BinView& b,
-                         const ImgView& im, hipStream_t s);
+// Binning of one or several views of the same P Gaussians (every kernel takes all views: blockIdx.y):
+// depth sort of all P Gaussians (those behind the near plane sink to the end), scan of tiles_touched in
+// depth order (N -> g.header[0], V -> g.header[1], N also -> im.header[0] and *n_out when non-null), emission of
+// the (tile, idx) instances in depth order, stable sort by tile id, tile ranges.  Final lists end up in
+// b.key[0] / b.val[0].  `n_bound` = number of instances the launches must cover (host-known N, or the
+// capacity when N lives only on the device; kernels clamp to the device-side N).
+// order_from: -1 = sort this view's own depth keys; k >= 0 = reuse the depth order of view k of the batch
+// (whose order_from must be -1), valid when both views assign the same view-space z to every Gaussian.
+struct BinJob {
+  int32_t W, H;
+  GeomView g;
+  BinView b;
+  ImgView im;
+  int64_t n_bound;
+  int32_t* n_out;
+  int32_t order_from;
+  const uint32_t* order;  // internal (order_from == -2): explicit depth order
+};
+void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
+// the two halves, for callers that size the binning buffer from N in between (b3gs_forward)
+void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);  // sort + scan
+void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);   // emit + split + ranges
 
 // ---- blend (per-tile alpha compositing) launches: one or several views per launch ---------------
-#define B3GS_MAX_FUSED_VIEWS 8
 struct BlendView {
   int32_t W, H, grid_x, ntiles, block_base;   // block_base is filled by the launcher
   const uint2* ranges;

@@ -1,15 +1,22 @@
-// Tile binning: depth order, instance emission, stable tile split, per-tile ranges.
+// Tile binning: depth order, instance emission, stable tile split, per-tile ranges -- for one view or
+// for a BATCH of views per launch (blockIdx.y = view).
 //
 // The published rasterizer (and oracle/tile_ref.c) sorts N (tile<<32 | depth-bits) 64-bit keys in
 // one stable radix sort, 6 byte-passes over N at 800x600.  The same permutation is produced here
 // with far less HBM traffic by sorting in two levels:
 //   1. stable LSD radix sort of the P Gaussians by their 32 depth bits (4 passes over P;
-//      culled Gaussians carry key 0xFFFFFFFF and sink to the end; ties keep index order),
+//      Gaussians behind the near plane carry key 0xFFFFFFFF and sink to the end; ties keep index order),
 //   2. emit the (tile, index) instances in that depth order (wave-cooperative expansion:
 //      coalesced writes regardless of how many tiles one Gaussian covers),
 //   3. stable LSD radix sort of the N instances by tile id only (ceil(log2(tiles)/8) passes,
 //      2 at 800x600 and 1600x1600) -- stability keeps the depth/index order inside each tile.
-// Resulting point_list is bit-identical to the 64-bit sort (tests/test_binning_parity.py).
+// Resulting point_list is bit-identical to the 64-bit sort (tests/test_gpu_parity.py).
+//
+// Batching: one view's pass is ~250 workgroups of 4 waves on a 256-CU part (one wave per SIMD: pure
+// latency).  The training iteration renders 6 views of the same Gaussians, so every launch here takes
+// up to B3GS_MAX_FUSED_VIEWS jobs.  Views whose view-space depth is identical -- the binocular pairs:
+// the shifted camera moves along the camera x axis only (utils/pose_utils.py:148-163), so row z of
+// the view matrix is unchanged -- share ONE depth sort (`order_from`).
 //
 // All kernels read the element count from device memory (N is produced on the device), so the
 // same launches serve the sync-free forward; grids are sized from a host-side bound.
@@ -56,22 +63,79 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* tm
   __syncthreads();
   return base + inc - v;
 }
+// ---- batch descriptors: kernel arguments by value, blockIdx.y selects the job ------------------
+struct SortJob {
+  const uint32_t* kin;
+  const uint32_t* vin;   // null: value = element index
+  uint32_t* kout;
+  uint32_t* vout;
+  const uint32_t* n_ptr; // null: n = n_cap
+  uint32_t n_cap;
+  uint32_t nblk;
+  uint32_t* hist;        // [256 * nblk] digit-major + 256 totals
+};
+struct SortBatch {
+  int32_t n;
+  SortJob j[B3GS_MAX_FUSED_VIEWS];
+};
+
+struct ScanJob {
+  const uint32_t* order;    // depth order (own or the donor view's)
+  const uint32_t* touched;
+  uint32_t* soffs;
+  uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
+  uint32_t* chunk_vis;      // [SCAN_MAX_CHUNKS]
+  uint32_t* header;
+  uint32_t* img_header;
+  int32_t* n_out;
+};
+struct ScanBatch {
+  int32_t n, P, tiles_per_chunk, nchunks;
+  ScanJob j[B3GS_MAX_FUSED_VIEWS];
+};
+
+struct EmitJob {
+  const uint32_t* order;
+  const uint32_t* soffs;
+  const uint32_t* touched;
+  const uint2* rect;
+  uint32_t* tile_out;
+  uint32_t* idx_out;
+  uint32_t n_cap;
+  int32_t grid_x;
+};
+struct EmitBatch {
+  int32_t n, P;
+  EmitJob j[B3GS_MAX_FUSED_VIEWS];
+};
+
+struct RangeJob {
+  const uint32_t* tile_sorted;
+  const uint32_t* n_ptr;
+  uint2* ranges;
+  uint32_t n_cap;
+};
+struct RangeBatch {
+  int32_t n;
+  RangeJob j[B3GS_MAX_FUSED_VIEWS];
+};
 
 // ---------------------------------------------------------------------------------------------
-// scan of tiles_touched in depth order: soffs[s] = sum_{s' <= s} tiles_touched[sval[s']]
-// three launches: per-chunk sums, scan of chunk sums (+ N, V to the header), per-chunk rescan
+// scan of tiles_touched in depth order: soffs[s] = sum_{s' <= s} tiles_touched[order[s']]
+// three launches: per-chunk sums, scan of chunk sums (+ N, V to the headers), per-chunk rescan
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096
 constexpr int SCAN_MAX_CHUNKS = 2048;
 
-__global__ void __launch_bounds__(SCAN_THREADS)
-    scan_chunk_sums(int P, int tiles_per_chunk, const uint32_t* __restrict__ order, const uint32_t* __restrict__ touched,
-                    uint32_t* __restrict__ chunk_sums, uint32_t* __restrict__ chunk_vis) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
-  const int64_t begin = (int64_t)blockIdx.x * tiles_per_chunk * SCAN_TILE;
-  const int64_t end = min((int64_t)P, begin + (int64_t)tiles_per_chunk * SCAN_TILE);
+  const ScanJob& job = sb.j[blockIdx.y];
+  const uint32_t* __restrict__ order = job.order;
+  const uint32_t* __restrict__ touched = job.touched;
+  const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   uint32_t sum = 0, vis = 0;
   for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
     uint32_t t = touched[order[i]];
@@ -82,23 +146,23 @@ __global__ void __launch_bounds__(SCAN_THREADS)
   block_excl_scan_256(sum, tmp, &tot);
   block_excl_scan_256(vis, tmp, &tot2);
   if (threadIdx.x == 0) {
-    chunk_sums[blockIdx.x] = tot;
-    chunk_vis[blockIdx.x] = tot2;
+    job.chunk_sums[blockIdx.x] = tot;
+    job.chunk_vis[blockIdx.x] = tot2;
   }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS)
-    scan_chunk_offsets(int nchunks, uint32_t* __restrict__ chunk_sums, const uint32_t* __restrict__ chunk_vis,
-                       uint32_t* __restrict__ header, uint32_t* __restrict__ img_header, int32_t* __restrict__ n_out) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
+  const ScanJob& job = sb.j[blockIdx.x];
+  const int nchunks = sb.nchunks;
   // nchunks <= 2048: 8 per thread, sequential
   uint32_t loc[8], s = 0, v = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     int idx = threadIdx.x * 8 + k;
-    loc[k] = idx < nchunks ? chunk_sums[idx] : 0u;
+    loc[k] = idx < nchunks ? job.chunk_sums[idx] : 0u;
     s += loc[k];
-    v += idx < nchunks ? chunk_vis[idx] : 0u;
+    v += idx < nchunks ? job.chunk_vis[idx] : 0u;
   }
   uint32_t tot, totv;
   uint32_t base = block_excl_scan_256(s, tmp, &tot);
@@ -106,24 +170,27 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     int idx = threadIdx.x * 8 + k;
-    if (idx < nchunks) chunk_sums[idx] = base;
+    if (idx < nchunks) job.chunk_sums[idx] = base;
     base += loc[k];
   }
   if (threadIdx.x == 0) {
-    header[0] = tot;   // N
-    header[1] = totv;  // V
-    if (img_header) { img_header[0] = tot; img_header[1] = totv; }
-    if (n_out) *n_out = (int32_t)tot;
+    job.header[0] = tot;   // N
+    job.header[1] = totv;  // V
+    if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; }
+    if (job.n_out) *job.n_out = (int32_t)tot;
   }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS)
-    scan_chunk_apply(int P, int tiles_per_chunk, const uint32_t* __restrict__ order, const uint32_t* __restrict__ touched,
-                     const uint32_t* __restrict__ chunk_offs, uint32_t* __restrict__ soffs) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_apply(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
-  uint32_t carry = chunk_offs[blockIdx.x];
-  const int64_t begin = (int64_t)blockIdx.x * tiles_per_chunk * SCAN_TILE;
-  for (int t = 0; t < tiles_per_chunk; t++) {
+  const ScanJob& job = sb.j[blockIdx.y];
+  const uint32_t* __restrict__ order = job.order;
+  const uint32_t* __restrict__ touched = job.touched;
+  uint32_t* __restrict__ soffs = job.soffs;
+  const int P = sb.P;
+  uint32_t carry = job.chunk_sums[blockIdx.x];
+  const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  for (int t = 0; t < sb.tiles_per_chunk; t++) {
     const int64_t tb = begin + (int64_t)t * SCAN_TILE;
     if (tb >= P) break;
     // blocked arrangement: thread owns SCAN_ITEMS consecutive elements
@@ -152,12 +219,16 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 //   rowscan: one workgroup per digit: exclusive prefix over workgroups, digit total -> totals[d]
 //   scatter: wave-striped stable ranking (ballot match), LDS reorder, coalesced run writes
 // n is read from *n_ptr and clamped to n_cap.
+// (A single-launch chained-scan pass with decoupled look-back was measured on MI355X and is SLOWER
+//  here -- sort stage 352 us vs 274 us per view: a dependent kernel boundary costs ~1.5 us, an
+//  agent-scope hand-off 1-2 us PER look-back hop -- so the pass stays three launches.)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(B3GS_SORT_THREADS)
-    radix_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr, uint32_t n_cap, int shift,
-               uint32_t nblk, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_hist(SortBatch sb, int shift) {
   __shared__ uint32_t h[256];
-  const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
+  const SortJob& job = sb.j[blockIdx.y];
+  if (blockIdx.x >= job.nblk) return;
+  const uint32_t* __restrict__ keys = job.kin;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * B3GS_SORT_TILE;
@@ -169,12 +240,14 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS)
     }
   }
   __syncthreads();
-  hist[threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+  job.hist[threadIdx.x * job.nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(256) radix_rowscan(uint32_t nblk, uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+__global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
   __shared__ uint32_t tmp[8];
-  uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+  const SortJob& job = sb.j[blockIdx.y];
+  const uint32_t nblk = job.nblk;
+  uint32_t* row = job.hist + (size_t)blockIdx.x * nblk;
   uint32_t carry = 0;
   for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
     uint32_t i = b0 + threadIdx.x;
@@ -184,14 +257,10 @@ __global__ void __launch_bounds__(256) radix_rowscan(uint32_t nblk, uint32_t* __
     if (i < nblk) row[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+  if (threadIdx.x == 0) job.hist[(size_t)256 * nblk + blockIdx.x] = carry;  // totals
 }
 
-__global__ void __launch_bounds__(B3GS_SORT_THREADS)
-    radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr,
-                  uint32_t n_cap, int shift, uint32_t nblk, const uint32_t* __restrict__ hist,
-                  const uint32_t* __restrict__ totals) {
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int shift) {
   __shared__ uint32_t wave_cnt[4][256];
   __shared__ uint32_t blk_start[256];  // first slot of digit d inside this workgroup's reorder buffer
   __shared__ uint32_t gbase[256];      // global destination of that first slot
@@ -199,7 +268,16 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS)
   __shared__ uint32_t s_key[B3GS_SORT_TILE];
   __shared__ uint32_t s_val[B3GS_SORT_TILE];
 
-  const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
+  const SortJob& job = sb.j[blockIdx.y];
+  if (blockIdx.x >= job.nblk) return;
+  const uint32_t* __restrict__ keys_in = job.kin;
+  const uint32_t* __restrict__ vals_in = job.vin;
+  uint32_t* __restrict__ keys_out = job.kout;
+  uint32_t* __restrict__ vals_out = job.vout;
+  const uint32_t nblk = job.nblk;
+  const uint32_t* __restrict__ hist = job.hist;
+  const uint32_t* __restrict__ totals = job.hist + (size_t)256 * nblk;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
   const uint32_t tile_base = blockIdx.x * B3GS_SORT_TILE;
   if (tile_base >= n) return;  // uniform per workgroup
   const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
@@ -283,183 +361,35 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS)
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Single-launch radix pass ("onesweep"): histogram, cross-workgroup prefix and scatter in ONE
-// kernel per 8-bit digit.  The global digit histograms of all passes are produced up front (for
-// the depth sort by radix_global_hist, for the tile sort inside emit_instances), so a pass only
-// needs, per digit, the number of keys in EARLIER workgroups: chained scan with decoupled
-// look-back.  Inter-workgroup protocol (placement independent, MI355X guide G16 "granule" form):
-// one 32-bit word per (workgroup, digit) = flag[31:30] | count[29:0], written with ONE agent-scope
-// relaxed atomic store and polled with agent-scope relaxed atomic loads -- value and flag travel
-// in the same word, so no separate payload needs release/acquire ordering.  Workgroup ids come
-// from an atomic ticket, so every predecessor a workgroup waits for has already started (no
-// dependence on dispatch order); every spin is bounded.
-// Scratch layout (words): ghist[4][256] | tickets[16] | pad | status[pass][nblk][256]
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t OS_GHIST = 0, OS_TICKET = 1024, OS_STATUS = 1280;
-constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INC = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
-
-__global__ void __launch_bounds__(B3GS_SORT_THREADS)
-    radix_global_hist(const uint32_t* __restrict__ keys, uint32_t n, int passes, uint32_t* __restrict__ scratch) {
-  __shared__ uint32_t h[4][256];
-#pragma unroll
-  for (int p = 0; p < 4; p++) h[p][threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * B3GS_SORT_TILE;
-#pragma unroll
-  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
-    const uint32_t i = base + k * B3GS_SORT_THREADS + threadIdx.x;
-    if (i < n) {
-      const uint32_t key = keys[i];
-      for (int p = 0; p < passes; p++) atomicAdd(&h[p][(key >> (8 * p)) & 0xFF], 1u);
-    }
-  }
-  __syncthreads();
-  for (int p = 0; p < passes; p++) {
-    const uint32_t c = h[p][threadIdx.x];
-    if (c) atomicAdd(&scratch[OS_GHIST + p * 256 + threadIdx.x], c);
-  }
-}
-
-__global__ void __launch_bounds__(B3GS_SORT_THREADS)
-    radix_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr,
-                   uint32_t n_cap, int pass, uint32_t nblk, uint32_t* __restrict__ scratch) {
-  __shared__ uint32_t wave_cnt[4][256];
-  __shared__ uint32_t blk_start[256];
-  __shared__ uint32_t gbase[256];
-  __shared__ uint32_t tmp[8];
-  __shared__ uint32_t s_blk;
-  __shared__ uint32_t s_key[B3GS_SORT_TILE];
-  __shared__ uint32_t s_val[B3GS_SORT_TILE];
-
-  const int shift = 8 * pass;
-  const uint32_t n = n_ptr ? min(*n_ptr, n_cap) : n_cap;
-  if (threadIdx.x == 0) s_blk = atomicAdd(&scratch[OS_TICKET + pass], 1u);
-#pragma unroll
-  for (int k = 0; k < 4; k++) wave_cnt[k][threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t blk = s_blk;
-  uint32_t* status = scratch + OS_STATUS + ((size_t)pass * nblk + blk) * 256;
-  const uint32_t tile_base = blk * B3GS_SORT_TILE;
-  if (tile_base >= n) {  // past the end: publish zeros so that nobody ever waits on this workgroup
-    __hip_atomic_store(&status[threadIdx.x], OS_FLAG_INC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
-  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  const u64 lt = lanemask_lt();
-
-  uint32_t key[B3GS_SORT_ITEMS], val[B3GS_SORT_ITEMS], rank[B3GS_SORT_ITEMS];
-#pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
-    const bool valid = li < tile_n;
-    const uint32_t gi = tile_base + li;
-    key[r] = valid ? keys_in[gi] : 0xFFFFFFFFu;
-    val[r] = valid ? (vals_in ? vals_in[gi] : gi) : 0u;
-  }
-#pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
-    const bool valid = li < tile_n;
-    const uint32_t d = (key[r] >> shift) & 0xFF;
-    u64 m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const bool bit = (d >> b) & 1u;
-      const u64 bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
-    }
-    const uint32_t before = (uint32_t)__popcll(m & lt);
-    const uint32_t cnt = wave_cnt[w][d];
-    rank[r] = cnt + before;
-    __builtin_amdgcn_wave_barrier();
-    if (valid && before == 0) wave_cnt[w][d] = cnt + (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-
-  {
-    const uint32_t d = threadIdx.x;
-    const uint32_t c0 = wave_cnt[0][d], c1 = wave_cnt[1][d], c2 = wave_cnt[2][d], c3 = wave_cnt[3][d];
-    const uint32_t tot = c0 + c1 + c2 + c3;
-    // publish this workgroup's count of digit d, then look back for the exclusive prefix
-    __hip_atomic_store(&status[d], OS_FLAG_AGG | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t excl = 0;
-    for (int pb = (int)blk - 1; pb >= 0; pb--) {
-      const uint32_t* ps = scratch + OS_STATUS + ((size_t)pass * nblk + (uint32_t)pb) * 256 + d;
-      uint32_t v = 0;
-      for (int spin = 0; spin < (1 << 24); spin++) {
-        v = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v >> 30) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      excl += v & OS_VAL_MASK;
-      if ((v >> 30) != 1u) break;  // inclusive prefix found (or spin bound hit: fail soft, never hang)
-    }
-    __hip_atomic_store(&status[d], OS_FLAG_INC | ((excl + tot) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    uint32_t dummy, dummy2;
-    const uint32_t start = block_excl_scan_256(tot, tmp, &dummy);
-    const uint32_t dig_base = block_excl_scan_256(scratch[OS_GHIST + pass * 256 + d], tmp, &dummy2);
-    wave_cnt[0][d] = start;
-    wave_cnt[1][d] = start + c0;
-    wave_cnt[2][d] = start + c0 + c1;
-    wave_cnt[3][d] = start + c0 + c1 + c2;
-    blk_start[d] = start;
-    gbase[d] = dig_base + excl;
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
-    if (li < tile_n) {
-      const uint32_t d = (key[r] >> shift) & 0xFF;
-      const uint32_t p = wave_cnt[w][d] + rank[r];
-      s_key[p] = key[r];
-      s_val[p] = val[r];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
-    const uint32_t p = k * B3GS_SORT_THREADS + threadIdx.x;
-    if (p < tile_n) {
-      const uint32_t kk = s_key[p];
-      const uint32_t d = (kk >> shift) & 0xFF;
-      const uint32_t dst = gbase[d] + (p - blk_start[d]);
-      keys_out[dst] = kk;
-      vals_out[dst] = s_val[p];
-    }
-  }
+// one pass over all jobs; swaps every job's in/out buffers afterwards (vin becomes non-null)
+void radix_pass(SortBatch& sb, int shift, hipStream_t s) {
+  uint32_t max_blk = 0;
+  for (int k = 0; k < sb.n; k++) max_blk = sb.j[k].nblk > max_blk ? sb.j[k].nblk : max_blk;
+  if (sb.n <= 0 || max_blk == 0) return;
+  hipLaunchKernelGGL(radix_hist, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
+  hipLaunchKernelGGL(radix_rowscan, dim3(256, sb.n), dim3(256), 0, s, sb);
+  hipLaunchKernelGGL(radix_scatter, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
 }
 
 // ---------------------------------------------------------------------------------------------
 // instance emission in depth order (wave-cooperative expansion)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-    emit_instances(int P, int grid_x, const uint32_t* __restrict__ order, const uint32_t* __restrict__ soffs,
-                   const uint32_t* __restrict__ touched, const uint2* __restrict__ rect, uint32_t n_cap,
-                   uint32_t* __restrict__ tile_out, uint32_t* __restrict__ idx_out, int hist_passes,
-                   uint32_t* __restrict__ os_scratch) {
+__global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ uint32_t s_end[4][64];
-  __shared__ uint32_t s_hist[4][256];  // digit histograms of the tile ids this workgroup emits (onesweep input)
-  if (hist_passes > 0) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) s_hist[p][threadIdx.x] = 0;
-    __syncthreads();
-  }
+  const EmitJob& job = eb.j[blockIdx.y];
+  const int P = eb.P;
+  const uint32_t n_cap = job.n_cap;
+  uint32_t* __restrict__ tile_out = job.tile_out;
+  uint32_t* __restrict__ idx_out = job.idx_out;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   const int s = blockIdx.x * 256 + threadIdx.x;
   uint32_t gid = 0, cnt = 0, end = 0;
   uint2 rc = make_uint2(0, 0);
   if (s < P) {
-    gid = order[s];
-    cnt = touched[gid];
-    end = soffs[s];
-    rc = rect[gid];
+    gid = job.order[s];
+    cnt = job.touched[gid];
+    end = job.soffs[s];
+    rc = job.rect[gid];
   }
   // lanes past P inherit the last valid end so the search array stays monotone
   const uint32_t wave_end = __shfl(end, 63 - (int)__builtin_clzll(__ballot(s < P) | 1ull), 64);
@@ -467,7 +397,7 @@ __global__ void __launch_bounds__(256)
   s_end[w][lane] = end;
   const uint32_t wave_begin = __shfl(end - cnt, 0, 64);
   __builtin_amdgcn_wave_barrier();
-  const bool wave_active = __ballot(cnt != 0) != 0;  // waves of culled Gaussians (sorted to the end) emit nothing
+  const bool wave_active = __ballot(cnt != 0) != 0;  // waves of culled Gaussians emit nothing
 
   const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu;
   const uint32_t rw = x1 - x0;
@@ -487,122 +417,145 @@ __global__ void __launch_bounds__(256)
     if (j < wave_end && j < n_cap) {
       const uint32_t k = j - (src_end - src_cnt);
       const uint32_t ry = k / src_rw, rx = k - ry * src_rw;
-      const uint32_t tile = (src_y0 + ry) * (uint32_t)grid_x + (src_x0 + rx);
-      tile_out[j] = tile;
+      tile_out[j] = (src_y0 + ry) * (uint32_t)job.grid_x + (src_x0 + rx);
       idx_out[j] = src_gid;
-      for (int p = 0; p < hist_passes; p++) atomicAdd(&s_hist[p][(tile >> (8 * p)) & 0xFF], 1u);
-    }
-  }
-  if (hist_passes > 0) {
-    __syncthreads();
-    for (int p = 0; p < hist_passes; p++) {
-      const uint32_t c = s_hist[p][threadIdx.x];
-      if (c) atomicAdd(&os_scratch[OS_GHIST + p * 256 + threadIdx.x], c);
     }
   }
 }
 
-__global__ void __launch_bounds__(256)
-    tile_ranges(const uint32_t* __restrict__ tile_sorted, const uint32_t* __restrict__ n_ptr, uint32_t n_cap,
-                uint2* __restrict__ ranges) {
-  const uint32_t n = min(*n_ptr, n_cap);
+__global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
+  const RangeJob& job = rb.j[blockIdx.y];
+  const uint32_t* __restrict__ tile_sorted = job.tile_sorted;
+  const uint32_t n = min(*job.n_ptr, job.n_cap);
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const uint32_t t = tile_sorted[j];
-  if (j == 0 || tile_sorted[j - 1] != t) ranges[t].x = j;
-  if (j == n - 1 || tile_sorted[j + 1] != t) ranges[t].y = j + 1;
+  if (j == 0 || tile_sorted[j - 1] != t) job.ranges[t].x = j;
+  if (j == n - 1 || tile_sorted[j + 1] != t) job.ranges[t].y = j + 1;
 }
 
-void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const uint32_t* n_ptr,
-                uint32_t n_cap, int shift, uint32_t* hist, hipStream_t s) {
-  const uint32_t nblk = b3gs_sort_blocks((int64_t)n_cap);
-  uint32_t* totals = hist + (size_t)256 * nblk;  // 256 spare words at the tail of the scratch
-  hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(B3GS_SORT_THREADS), 0, s, kin, n_ptr, n_cap, shift, nblk, hist);
-  hipLaunchKernelGGL(radix_rowscan, dim3(256), dim3(256), 0, s, nblk, hist, totals);
-  hipLaunchKernelGGL(radix_scatter, dim3(nblk), dim3(B3GS_SORT_THREADS), 0, s, kin, vin, kout, vout, n_ptr, n_cap, shift,
-                     nblk, hist, totals);
-}
-
-// Measured on MI355X (P = 1M, N = 4.8M, 6 passes per view): the chained-scan pass is correct but
-// SLOWER than histogram / row scan / scatter as three launches (sort stage 352 us vs 274 us per view):
-// a dependent kernel boundary costs ~1.5 us here, a cross-workgroup hand-off through agent-scope
-// atomics ~1-2 us PER look-back hop.  The three-launch pass is therefore the default;
-// B3GS_SORT=onesweep selects the single-launch pass for A/B runs.
-bool use_onesweep() {
-  static const bool v = getenv("B3GS_SORT") && getenv("B3GS_SORT")[0] == 'o';
-  return v;
-}
-size_t onesweep_scratch_words(uint32_t nblk, int passes) { return OS_STATUS + (size_t)passes * nblk * 256; }
-void onesweep_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, const uint32_t* n_ptr,
-                   uint32_t n_cap, int pass, uint32_t* scratch, hipStream_t s) {
-  const uint32_t nblk = b3gs_sort_blocks((int64_t)n_cap);
-  hipLaunchKernelGGL(radix_onesweep, dim3(nblk), dim3(B3GS_SORT_THREADS), 0, s, kin, vin, kout, vout, n_ptr, n_cap, pass,
-                     nblk, scratch);
+int tile_sort_passes(int W, int H) {
+  const size_t tiles = (size_t)((W + B3GS_TILE - 1) / B3GS_TILE) * (size_t)((H + B3GS_TILE - 1) / B3GS_TILE);
+  int tbits = 0;
+  while (((size_t)1 << tbits) < tiles) tbits++;
+  return tbits == 0 ? 0 : (tbits + 7) / 8;
 }
 
 }  // namespace
 
-void b3gs_launch_depth_sort_and_scan(int32_t P, const GeomView& g, uint32_t* img_header, int32_t* n_out,
-                                     hipStream_t s) {
-  if (P <= 0) {
-    (void)hipMemsetAsync(g.header, 0, 8, s);
-    if (img_header) (void)hipMemsetAsync(img_header, 0, 8, s);
-    if (n_out) (void)hipMemsetAsync(n_out, 0, 4, s);
-    return;
-  }
-  // 4 passes: depth_key -> skey[1] -> skey[0] -> skey[1] -> skey[0]
-  if (use_onesweep()) {
-    const uint32_t nblk = b3gs_sort_blocks((int64_t)P);
-    (void)hipMemsetAsync(g.hist, 0, onesweep_scratch_words(nblk, 4) * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(radix_global_hist, dim3(nblk), dim3(B3GS_SORT_THREADS), 0, s, g.depth_key, (uint32_t)P, 4, g.hist);
-    onesweep_pass(g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, 0, g.hist, s);
-    onesweep_pass(g.skey[1], g.sval[1], g.skey[0], g.sval[0], nullptr, (uint32_t)P, 1, g.hist, s);
-    onesweep_pass(g.skey[0], g.sval[0], g.skey[1], g.sval[1], nullptr, (uint32_t)P, 2, g.hist, s);
-    onesweep_pass(g.skey[1], g.sval[1], g.skey[0], g.sval[0], nullptr, (uint32_t)P, 3, g.hist, s);
-  } else {
-    const uint32_t* n_ptr = nullptr;  // P is known on the host
-    radix_pass(g.depth_key, nullptr, g.skey[1], g.sval[1], n_ptr, (uint32_t)P, 0, g.hist, s);
-    radix_pass(g.skey[1], g.sval[1], g.skey[0], g.sval[0], n_ptr, (uint32_t)P, 8, g.hist, s);
-    radix_pass(g.skey[0], g.sval[0], g.skey[1], g.sval[1], n_ptr, (uint32_t)P, 16, g.hist, s);
-    radix_pass(g.skey[1], g.sval[1], g.skey[0], g.sval[0], n_ptr, (uint32_t)P, 24, g.hist, s);
-  }
-
-  const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
-  const int tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
-  const int nchunks = (total_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-  uint32_t* chunk_sums = g.scan_tmp;
-  uint32_t* chunk_vis = g.scan_tmp + SCAN_MAX_CHUNKS;
-  hipLaunchKernelGGL(scan_chunk_sums, dim3(nchunks), dim3(SCAN_THREADS), 0, s, P, tiles_per_chunk, g.sval[0],
-                     g.tiles_touched, chunk_sums, chunk_vis);
-  hipLaunchKernelGGL(scan_chunk_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, nchunks, chunk_sums, chunk_vis, g.header,
-                     img_header, n_out);
-  hipLaunchKernelGGL(scan_chunk_apply, dim3(nchunks), dim3(SCAN_THREADS), 0, s, P, tiles_per_chunk, g.sval[0],
-                     g.tiles_touched, chunk_sums, g.soffs);
+static const uint32_t* depth_order_of(const BinJob* jobs, int v) {
+  const BinJob& jb = jobs[v];
+  return jb.order_from == -1 ? jb.g.sval[0] : (jb.order_from >= 0 ? jobs[jb.order_from].g.sval[0] : jb.order);
 }
 
-void b3gs_launch_binning(int32_t P, int32_t W, int32_t H, int64_t n_bound, const GeomView& g, const BinView& b,
-                         const ImgView& im, hipStream_t s) {
-  const int gx = (W + B3GS_TILE - 1) / B3GS_TILE, gy = (H + B3GS_TILE - 1) / B3GS_TILE;
-  const size_t tiles = (size_t)gx * gy;
-  // im.ranges was zeroed by the preprocess launch (empty tiles keep [0,0))
-  if (P <= 0 || n_bound <= 0) return;
-  const uint32_t n_cap = (uint32_t)n_bound;
-  const uint32_t* n_ptr = g.header;  // N
-  int tbits = 0;
-  while (((size_t)1 << tbits) < tiles) tbits++;
-  const int passes = tbits == 0 ? 0 : (tbits + 7) / 8;
-  // emit into the buffer from which `passes` ping-pongs end in [0]
-  const int first = passes & 1;
-  const bool os = use_onesweep() && passes <= 4;
-  if (os && passes > 0)
-    (void)hipMemsetAsync(b.hist, 0, onesweep_scratch_words(b3gs_sort_blocks((int64_t)n_cap), passes) * sizeof(uint32_t), s);
-  hipLaunchKernelGGL(emit_instances, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, g.sval[0], g.soffs,
-                     g.tiles_touched, g.rect, n_cap, b.key[first], b.val[first], os ? passes : 0, b.hist);
-  int cur = first;
-  for (int p = 0; p < passes; p++) {
-    if (os) onesweep_pass(b.key[cur], b.val[cur], b.key[cur ^ 1], b.val[cur ^ 1], n_ptr, n_cap, p, b.hist, s);
-    else radix_pass(b.key[cur], b.val[cur], b.key[cur ^ 1], b.val[cur ^ 1], n_ptr, n_cap, 8 * p, b.hist, s);
-    cur ^= 1;
+void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
+  b3gs_launch_depth_order_batch(P, nviews, jobs, s);
+  b3gs_launch_tile_lists_batch(P, nviews, jobs, s);
+}
+
+void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
+  if (nviews <= 0) return;
+  if (P <= 0) {
+    for (int v = 0; v < nviews; v++) {
+      (void)hipMemsetAsync(jobs[v].g.header, 0, 8, s);
+      if (jobs[v].im.header) (void)hipMemsetAsync(jobs[v].im.header, 0, 8, s);
+      if (jobs[v].n_out) (void)hipMemsetAsync(jobs[v].n_out, 0, 4, s);
+    }
+    return;
   }
-  hipLaunchKernelGGL(tile_ranges, dim3((n_cap + 255) / 256), dim3(256), 0, s, b.key[0], n_ptr, n_cap, im.ranges);
+  // ---- 1. depth order: 4 passes depth_key -> skey[1] -> skey[0] -> skey[1] -> skey[0] for every view that
+  //         does not borrow another view's order; result in sval[0]
+  SortBatch db;
+  db.n = 0;
+  const uint32_t pblk = b3gs_sort_blocks((int64_t)P);
+  for (int v = 0; v < nviews; v++) {
+    if (jobs[v].order_from != -1) continue;
+    const GeomView& g = jobs[v].g;
+    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, g.hist};
+  }
+  for (int pass = 0; pass < 4; pass++) {
+    radix_pass(db, 8 * pass, s);
+    int k = 0;
+    for (int v = 0; v < nviews; v++) {
+      if (jobs[v].order_from != -1) continue;
+      const GeomView& g = jobs[v].g;
+      const int dst = pass & 1;  // destination of the NEXT pass: [0], [1], [0]
+      SortJob& j = db.j[k++];
+      j.kin = g.skey[dst ^ 1];
+      j.vin = g.sval[dst ^ 1];
+      j.kout = g.skey[dst];
+      j.vout = g.sval[dst];
+    }
+  }
+
+  // ---- 2. scan of tiles_touched in depth order -> soffs, N, V
+  const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
+  ScanBatch sc;
+  sc.n = nviews;
+  sc.P = P;
+  sc.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
+  sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
+  for (int v = 0; v < nviews; v++) {
+    const BinJob& jb = jobs[v];
+    sc.j[v] = ScanJob{depth_order_of(jobs, v), jb.g.tiles_touched, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
+                      jb.g.header, jb.im.header, jb.n_out};
+  }
+  hipLaunchKernelGGL(scan_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  hipLaunchKernelGGL(scan_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
+  hipLaunchKernelGGL(scan_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+}
+
+void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
+  if (nviews <= 0 || P <= 0) return;
+  // views of different tile-sort depth cannot share the pass loop: run them one by one
+  const int passes = tile_sort_passes(jobs[0].W, jobs[0].H);
+  for (int v = 1; v < nviews; v++) {
+    if (tile_sort_passes(jobs[v].W, jobs[v].H) != passes) {
+      for (int k = 0; k < nviews; k++) {
+        BinJob one = jobs[k];
+        // a donor index refers to the batch; resolve it to the donor's buffers before splitting
+        if (one.order_from >= 0) { one.order = jobs[one.order_from].g.sval[0]; one.order_from = -2; }
+        b3gs_launch_tile_lists_batch(P, 1, &one, s);
+      }
+      return;
+    }
+  }
+
+
+  // ---- 3. emit (tile, index) instances in depth order into the buffer from which `passes` ping-pongs end in [0];
+  //         every kernel clamps to min(N, capacity)
+  const int first = passes & 1;
+  EmitBatch eb;
+  eb.n = nviews;
+  eb.P = P;
+  SortBatch tb;
+  tb.n = nviews;
+  RangeBatch rb;
+  rb.n = nviews;
+  uint32_t max_cap = 0;
+  for (int v = 0; v < nviews; v++) {
+    const BinJob& jb = jobs[v];
+    const uint32_t n_cap = (uint32_t)(jb.n_bound > 0 ? jb.n_bound : 0);
+    max_cap = n_cap > max_cap ? n_cap : max_cap;
+    eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.tiles_touched, jb.g.rect, jb.b.key[first], jb.b.val[first], n_cap,
+                      (jb.W + B3GS_TILE - 1) / B3GS_TILE};
+    tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
+                      b3gs_sort_blocks((int64_t)n_cap), jb.b.hist};
+    rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap};
+  }
+  if (max_cap == 0) return;  // im.ranges was zeroed by the preprocess launch (empty tiles keep [0,0))
+  hipLaunchKernelGGL(emit_instances, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
+
+  // ---- 4. stable split by tile id
+  for (int p = 0; p < passes; p++) {
+    radix_pass(tb, 8 * p, s);
+    for (int v = 0; v < nviews; v++) {
+      SortJob& j = tb.j[v];
+      const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
+      j.kin = j.kout; j.vin = j.vout;
+      j.kout = const_cast<uint32_t*>(k); j.vout = const_cast<uint32_t*>(vv);
+    }
+  }
+  // ---- 5. per-tile [begin, end)
+  hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
 }

@@ -188,13 +188,29 @@ __device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, floa
 }
 
 template <bool RAW>
-__global__ void __launch_bounds__(256)
-    preprocess_fwd_kernel(SceneX sx_, GeomView g, int32_t* __restrict__ radii, uint2* __restrict__ ranges, int ntiles) {
-  const B3gsScene& sc = sx_.sc;
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < ntiles) ranges[i] = make_uint2(0u, 0u);  // empty tiles keep [0,0): saves a memset launch
-  if (i >= sc.P) return;
-  const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sc.means3D;
+  for (int v = 0; v < pb.n; v++)
+    if (i < pb.out[v].ntiles) pb.out[v].ranges[i] = make_uint2(0u, 0u);  // empty tiles keep [0,0): saves a memset launch
+  if (i >= pb.sc[0].P) return;
+  // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
+  // scale modifier), activated opacity
+  SceneX sx_;
+  sx_.sc = pb.sc[0];
+  sx_.raw = pb.raw;
+  sx_.raw_mode = pb.raw_mode;
+  sx_.tight = pb.tight;
+  const float* __restrict__ means3D = RAW ? sx_.raw.xyz : sx_.sc.means3D;
+  const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
+  float c6[6];
+  cov3d_of<RAW>(sx_, i, c6);
+  const float op = load_opacity<RAW>(sx_, i);
+  const ShView sh = sh_view<RAW>(sx_, i);
+
+#pragma unroll 1
+  for (int v = 0; v < pb.n; v++) {
+  const B3gsScene& sc = pb.sc[v];
+  const PreOut& g = pb.out[v];
   const Mat16 vm = load_mat(sc.viewmatrix);
   const Mat16 pm = load_mat(sc.projmatrix);
 
@@ -202,21 +218,21 @@ __global__ void __launch_bounds__(256)
   uint32_t touched = 0, dkey = 0xFFFFFFFFu, clamp_bits = 0;
   uint2 rect = make_uint2(0, 0);
 
-  const float px3 = means3D[3 * (size_t)i], py3 = means3D[3 * (size_t)i + 1], pz3 = means3D[3 * (size_t)i + 2];
   float pv[3];
   pv[0] = ((vm.m[0] * px3 + vm.m[4] * py3) + vm.m[8] * pz3) + vm.m[12];
   pv[1] = ((vm.m[1] * px3 + vm.m[5] * py3) + vm.m[9] * pz3) + vm.m[13];
   pv[2] = ((vm.m[2] * px3 + vm.m[6] * py3) + vm.m[10] * pz3) + vm.m[14];
 
   if (sc.prefiltered || !(pv[2] <= B3GS_NEAR)) {  // same predicate form as the oracle (NaN passes)
+    // the key depends on view-space z alone (not on the screen-space culls below, whose Gaussians emit no
+    // instances anyway), so two views with the same z row of the view matrix produce the same depth order
+    dkey = __float_as_uint(pv[2]);
     float hx = ((pm.m[0] * px3 + pm.m[4] * py3) + pm.m[8] * pz3) + pm.m[12];
     float hy = ((pm.m[1] * px3 + pm.m[5] * py3) + pm.m[9] * pz3) + pm.m[13];
     float hw = ((pm.m[3] * px3 + pm.m[7] * py3) + pm.m[11] * pz3) + pm.m[15];
     float pw = 1.0f / (hw + 0.0000001f);
     float ppx = hx * pw, ppy = hy * pw;
 
-    float c6[6];
-    cov3d_of<RAW>(sx_, i, c6);
     const float fx = (float)sc.W / (2.0f * sc.tan_fovx), fy = (float)sc.H / (2.0f * sc.tan_fovy);
     Ewa e = ewa_project(pv, fx, fy, sc.tan_fovx, sc.tan_fovy, c6, vm);
     float a = e.a + 0.3f, b = e.b, c = e.c + 0.3f;
@@ -246,7 +262,6 @@ __global__ void __launch_bounds__(256)
           float dx = px3 - sc.campos[0], dy = py3 - sc.campos[1], dz = pz3 - sc.campos[2];
           float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
           dx = dx * inv; dy = dy * inv; dz = dz * inv;
-          const ShView sh = sh_view<RAW>(sx_, i);
 #pragma unroll
           for (int ch = 0; ch < 3; ch++) {
             float v = sh_eval(sc.D, sh, ch, dx, dy, dz) + 0.5f;
@@ -254,7 +269,6 @@ __global__ void __launch_bounds__(256)
             rgb[ch] = fmaxf(v, 0.0f);
           }
         }
-        const float op = load_opacity<RAW>(sx_, i);
         // conservative half-extents of the region where op*G >= 1/255 (G <= 1): used by the blend
         // kernels to skip whole 8x8 pixel quadrants; never changes which pixels contribute
         float ext_x = -1.0e30f, ext_y = -1.0e30f;
@@ -285,16 +299,16 @@ __global__ void __launch_bounds__(256)
         rec[3] = make_float4(a, b, c, 0.f);
         radius_out = (int32_t)fminf(rad_f, 2147483520.0f);
         touched = (uint32_t)area;
-        dkey = __float_as_uint(pv[2]);
         rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
       }
     }
   }
-  radii[i] = radius_out;
+  g.radii[i] = radius_out;
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
   g.rect[i] = rect;
   g.clamped[i] = clamp_bits;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -748,13 +762,26 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means3D, co
 
 }  // namespace
 
-void b3gs_launch_preprocess(const SceneX& sx, const GeomView& g, const ImgView& im, int32_t* radii, hipStream_t s) {
-  const int ntiles = ((sx.sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sx.sc.H + B3GS_TILE - 1) / B3GS_TILE);
-  const int work = sx.sc.P > ntiles ? sx.sc.P : ntiles;
-  if (work <= 0) return;
+PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, int32_t* radii) {
+  PreOut o;
+  o.rec = g.rec;
+  o.depth_key = g.depth_key;
+  o.tiles_touched = g.tiles_touched;
+  o.rect = g.rect;
+  o.clamped = g.clamped;
+  o.radii = radii;
+  o.ranges = im.ranges;
+  o.ntiles = ((sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
+  return o;
+}
+
+void b3gs_launch_preprocess(const PreBatch& pb, hipStream_t s) {
+  int work = pb.sc[0].P;
+  for (int v = 0; v < pb.n; v++) work = pb.out[v].ntiles > work ? pb.out[v].ntiles : work;
+  if (pb.n <= 0 || work <= 0) return;
   const dim3 grid((work + 255) / 256);
-  if (sx.raw_mode) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, grid, dim3(256), 0, s, sx, g, radii, im.ranges, ntiles);
-  else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, grid, dim3(256), 0, s, sx, g, radii, im.ranges, ntiles);
+  if (pb.raw_mode) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, grid, dim3(256), 0, s, pb);
+  else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, grid, dim3(256), 0, s, pb);
 }
 
 void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const int32_t* radii, float* dL_dmeans2D,

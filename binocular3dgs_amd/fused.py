@@ -86,7 +86,7 @@ class _RasterizeBatch(torch.autograd.Function):
 
 class FusedRasterizer:
     def __init__(self, model, width: int, height: int, num_slots: int = 2, binning_capacity: Optional[int] = None,
-                 want_means2D: bool = True, concurrent: bool = True):
+                 want_means2D: bool = True, concurrent: bool = True, schedule: Optional[str] = None):
         self.model = model
         self.W, self.H = int(width), int(height)
         p = model.get_xyz
@@ -96,7 +96,13 @@ class FusedRasterizer:
         self.P = p.shape[0]
         self.K = model._features_dc.shape[1] + model._features_rest.shape[1]
         self.capacity = int(binning_capacity) if binning_capacity else max(4_000_000, 12 * self.P)
-        self.concurrent = bool(concurrent)   # bin the views of a batch on separate streams
+        # how the views of one render_batch() are issued:
+        #   "batched": every stage ONE launch for all views (b3gs_forward_raw_batch), binocular pairs share
+        #              one depth sort;  "streams": each view's forward on its own stream;  "serial": one stream,
+        #              per-view projection + binning, one blend launch
+        self.schedule = schedule or ("batched" if concurrent else "serial")
+        assert self.schedule in ("batched", "streams", "serial")
+        self.concurrent = self.schedule == "streams"
         self._want_m2d = want_means2D
         self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev)) for _ in range(num_slots)]
         self._deferred = None   # [(spec, B3gsScene)] while a deferred-accumulate section is open
@@ -160,6 +166,27 @@ class FusedRasterizer:
         main = torch.cuda.current_stream(self.dev)
         scenes = [self._scene(sp) for sp in specs]
         rp = self._bind_params()
+        if self.schedule == "batched":
+            for c0 in range(0, len(specs), MAX_BATCH):
+                chunk = specs[c0:c0 + MAX_BATCH]
+                arr = (_lib.B3gsForwardView * len(chunk))()
+                for k, sp in enumerate(chunk):
+                    s = self.slots[sp["slot"]]
+                    arr[k].view = C.pointer(scenes[c0 + k])
+                    arr[k].geometry, arr[k].binning, arr[k].image = s.geom.data_ptr(), s.binning.data_ptr(), s.img.data_ptr()
+                    arr[k].binning_capacity = s.capacity
+                    arr[k].out_color, arr[k].out_depth, arr[k].out_alpha = (s.color.data_ptr(), s.depth.data_ptr(),
+                                                                            s.alpha.data_ptr())
+                    arr[k].radii, arr[k].device_num_rendered = s.radii.data_ptr(), s.n_dev.data_ptr()
+                    # a camera made by Camera.shifted() has the z row of its parent's view matrix: same depth order
+                    donor = getattr(sp["cam"], "same_depth_as", None)
+                    arr[k].depth_order_from = -1
+                    for j in range(k):
+                        if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
+                            arr[k].depth_order_from = j
+                rc = L.b3gs_forward_raw_batch(len(chunk), arr, C.byref(rp), 3, main.cuda_stream)
+                _lib.check(rc, "b3gs_forward_raw_batch")
+            return
         if self.concurrent:
             # Every view runs its whole forward on its own stream.  Measured (1M Gaussians, 6 views): the
             # binning kernels of one view overlap well with the BLEND kernel of another (forward phase

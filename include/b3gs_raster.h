@@ -141,6 +141,29 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
                      int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
                      int32_t* radii, int32_t* device_num_rendered, int phases, b3gs_stream_t stream);
 
+/* The whole forward of up to 8 views of the SAME Gaussians, every stage one launch for all views:
+ * the projection reads and activates each Gaussian once for all views, the radix passes / scans / emission
+ * / blend take the views as blockIdx.y (a single view's pass is ~250 workgroups on 256 CUs: latency-bound).
+ * depth_order_from: -1 = this view sorts its own depth keys; k = reuse view k's depth order -- valid iff
+ * both view matrices have the same z row, which is what the binocular shifted cameras are (the translation is
+ * along the camera x axis, utils/pose_utils.py:148-163): one depth sort per input/shifted pair.
+ * Views share P, M, D, scale_modifier; W, H may differ.  phases as in b3gs_forward_raw. */
+typedef struct B3gsForwardView {
+  const B3gsScene* view;
+  char* geometry;
+  char* binning;
+  int64_t binning_capacity;
+  char* image;
+  float* out_color;
+  float* out_depth;
+  float* out_alpha;
+  int32_t* radii;
+  int32_t* device_num_rendered;
+  int32_t depth_order_from;
+} B3gsForwardView;
+int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
+                           b3gs_stream_t stream);
+
 /* Blend (per-tile alpha compositing) of up to 8 views in ONE launch each way.  One view's ~1900 tiles fill
  * the 256 CUs roughly once, so a per-view launch pays its own tail; batched, the dispatcher packs the tiles
  * of all views (MI355X, 1M Gaussians, 800x600: forward 126 us per view alone, 74 us per view batched).

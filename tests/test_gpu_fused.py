@@ -81,9 +81,10 @@ def test_step_with_fused_path_matches_dropin_step():
     assert rel_l2(flats[1].cpu().numpy(), flats[0].cpu().numpy()) < 2e-3
 
 
-def test_concurrent_streams_equal_serial():
-    """6 views on 6 streams (forward and backward concurrent, accumulation chained by events) give the
-    same slab as the same views rendered one after the other."""
+def test_schedules_give_the_same_gradients():
+    """The three ways of issuing the 6 views of an iteration -- one launch per stage for all views with the
+    binocular pairs sharing a depth sort ("batched"), one stream per view ("streams"), one after the other
+    ("serial") -- give the same tile lists, hence the same slab."""
     from binocular3dgs_amd import synth
     from binocular3dgs_amd.fused import FusedRasterizer
     from binocular3dgs_amd.step import ViewShardedStep
@@ -94,9 +95,9 @@ def test_concurrent_streams_equal_serial():
         return [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]
 
     flats = []
-    for conc in (False, True):
+    for schedule in ("serial", "streams", "batched"):
         model, pairs, bg = _setup(P=20000, W=W, H=H)
-        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), concurrent=conc)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), schedule=schedule)
         st = ViewShardedStep(model, pairs, bg, fused=fr)
         for _ in range(3):
             st.step(pair_grad_fn=grad_fn)
@@ -104,6 +105,32 @@ def test_concurrent_streams_equal_serial():
         flats.append(st.slab.flat.clone())
     assert float(flats[0].abs().max()) > 0
     assert rel_l2(flats[1].cpu().numpy(), flats[0].cpu().numpy()) < 1e-4
+    assert rel_l2(flats[2].cpu().numpy(), flats[0].cpu().numpy()) < 1e-4
+
+
+def test_batched_forward_is_bit_identical_to_per_view_forward():
+    """b3gs_forward_raw_batch (multi-view projection, batched radix passes, shared depth order for the
+    shifted camera) must produce exactly the per-view results: same N, radii, point lists (hence images)."""
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H = 208, 144
+    model, pairs, bg = _setup(P=30000, W=W, H=H)
+    views = []
+    for i, (cam, scam, _t) in enumerate(pairs):
+        views += [(cam, 2 * i), (scam, 2 * i + 1)]
+    res = {}
+    for schedule in ("serial", "batched"):
+        fr = FusedRasterizer(model, W, H, num_slots=len(views), schedule=schedule)
+        with torch.no_grad():
+            outs = fr.render_batch(views, bg)
+        torch.cuda.synchronize()
+        n = fr.num_rendered()
+        res[schedule] = [(n[k], o["radii"].clone(), o["render"].clone(), o["rendered_depth"].clone(),
+                          fr.slots[k].binning[:4 * n[k]].clone()) for k, o in enumerate(outs)]
+    for a, b in zip(res["serial"], res["batched"]):
+        assert a[0] == b[0] and a[0] > 0
+        assert torch.equal(a[1], b[1])
+        assert torch.equal(a[4], b[4])          # point_list (val[0] sits at offset 0 of the binning buffer)
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
 def test_capacity_overflow_is_detected_and_recovered():

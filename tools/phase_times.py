@@ -36,9 +36,9 @@ def timed(fn, n=20):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for conc in (True, False):
+for conc in ("batched", "streams", "serial"):
     model = synth.synth_model(P, seed=0, device=dev, width=W, height=H)
-    fr = FusedRasterizer(model, W, H, num_slots=6, concurrent=conc)
+    fr = FusedRasterizer(model, W, H, num_slots=6, schedule=conc)
     st = ViewShardedStep(model, pairs, bg, fused=fr)
 
     def fwd_only():
@@ -51,4 +51,4 @@ for conc in (True, False):
     tf = timed(fwd_only)
     ts = timed(lambda: st.compute_grads(pair_grad_fn=grad_fn))
     print("%s: forward phase %.3f ms, forward+backward %.3f ms -> backward phase %.3f ms" %
-          ("concurrent" if conc else "serial", tf, ts, ts - tf))
+          (conc, tf, ts, ts - tf))
