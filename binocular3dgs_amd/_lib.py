@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libb3gs_raster.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -70,7 +70,7 @@ class B3gsDensifyStats(C.Structure):
 class B3gsDebugViews(C.Structure):
     _fields_ = [("tiles_touched", C.c_void_p), ("depths", C.c_void_p), ("records", C.c_void_p),
                 ("point_list", C.c_void_p), ("tile_ids", C.c_void_p), ("ranges", C.c_void_p),
-                ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
+                ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("packed_idx_bits", C.c_int32)]
 
 
 class B3gsKernelTimes(C.Structure):

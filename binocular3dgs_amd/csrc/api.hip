@@ -568,7 +568,8 @@ int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, cons
   if (binning) {
     b3gs_bin_view(const_cast<char*>(binning), P, num_rendered, &b);
     out->point_list = b.val[0];
-    out->tile_ids = b.key[0];
+    out->packed_idx_bits = b3gs_packed_idx_bits(P, W, H);
+    out->tile_ids = out->packed_idx_bits >= 0 ? nullptr : b.key[0];
   }
   out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
   out->final_T = im.final_T;

@@ -27,6 +27,7 @@ struct GeomView {       // sized by P
   uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
   uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
   uint32_t* soffs;      // [P]   inclusive scan of tiles_touched in depth order
+  uint2* srect;         // [P]   rect in depth order
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
   uint32_t* scan_tmp;   // [4096] block sums for scans
 };
@@ -50,6 +51,22 @@ struct ImgView {        // sized by W*H
 
 static inline size_t b3gs_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline uint32_t b3gs_sort_blocks(int64_t n) { return (uint32_t)((n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE); }
+
+// bits of a tile id at W x H
+static inline int b3gs_tile_bits(int W, int H) {
+  const size_t tiles = (size_t)((W + B3GS_TILE - 1) / B3GS_TILE) * (size_t)((H + B3GS_TILE - 1) / B3GS_TILE);
+  int tbits = 0;
+  while (((size_t)1 << tbits) < tiles) tbits++;
+  return tbits;
+}
+// Tile instances are ONE 32-bit word (tile << idx_bits) | gaussian_index whenever both fit (e.g. up to 2M
+// Gaussians at 800x600); returns idx_bits, or -1 when they do not and (tile, index) are two words.
+// A pure function of (P, W, H): forward, backward and debug views all derive the same answer.
+static inline int b3gs_packed_idx_bits(int32_t P, int W, int H) {
+  int pbits = 1;
+  while (((int64_t)1 << pbits) < (int64_t)P) pbits++;
+  return pbits + b3gs_tile_bits(W, H) <= 32 ? pbits : -1;
+}
 
 // radix-sort scratch: 1280 header words (global digit histograms, tickets) + one status word per
 // (pass <= 4, workgroup, digit) for the chained scan; also covers the 3-launch variant's 256*(nblk+1)
@@ -76,6 +93,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   for (int i = 0; i < 2; i++) t.skey[i] = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
   t.soffs = b3gs_carve<uint32_t>(cur, p);
+  t.srect = b3gs_carve<uint2>(cur, p);
   t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
   if (v) *v = t;
@@ -181,6 +199,7 @@ struct BlendView {
   int32_t W, H, grid_x, ntiles, block_base;   // block_base is filled by the launcher
   const uint2* ranges;
   const uint32_t* point_list;
+  uint32_t idx_mask;       // Gaussian index = point_list[j] & idx_mask (packed tile|index words, see b3gs_packed_idx_bits)
   const float4* rec;
   const float* bg;
   float* final_T;          // forward: written; backward: read

@@ -68,11 +68,13 @@ struct SortJob {
   const uint32_t* kin;
   const uint32_t* vin;   // null: value = element index
   uint32_t* kout;
-  uint32_t* vout;
+  uint32_t* vout;        // null: keys only (packed tile|index keys)
   const uint32_t* n_ptr; // null: n = n_cap
   uint32_t n_cap;
   uint32_t nblk;
+  int32_t shift_base;    // added to the pass shift (position of the tile id inside a packed key)
   uint32_t* hist;        // [256 * nblk] digit-major + 256 totals
+  uint2* ranges;         // non-null on the LAST pass of the tile sort: per-tile [begin, end) by atomic min / max
 };
 struct SortBatch {
   int32_t n;
@@ -81,7 +83,8 @@ struct SortBatch {
 
 struct ScanJob {
   const uint32_t* order;    // depth order (own or the donor view's)
-  const uint32_t* touched;
+  const uint2* rect;        // tile rectangles by Gaussian
+  uint2* srect;             // the same in depth order (written by the first scan launch: ONE gather per view)
   uint32_t* soffs;
   uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
   uint32_t* chunk_vis;      // [SCAN_MAX_CHUNKS]
@@ -97,12 +100,12 @@ struct ScanBatch {
 struct EmitJob {
   const uint32_t* order;
   const uint32_t* soffs;
-  const uint32_t* touched;
-  const uint2* rect;
-  uint32_t* tile_out;
+  const uint2* srect;
+  uint32_t* tile_out;   // tile id, or (tile << idx_bits) | index when idx_out is null
   uint32_t* idx_out;
   uint32_t n_cap;
   int32_t grid_x;
+  int32_t idx_bits;
 };
 struct EmitBatch {
   int32_t n, P;
@@ -114,7 +117,12 @@ struct RangeJob {
   const uint32_t* n_ptr;
   uint2* ranges;
   uint32_t n_cap;
+  int32_t shift;        // tile id = key >> shift
 };
+
+__device__ __forceinline__ uint32_t rect_area(uint2 rc) {
+  return ((rc.y & 0xFFFFu) - (rc.x & 0xFFFFu)) * ((rc.y >> 16) - (rc.x >> 16));
+}
 struct RangeBatch {
   int32_t n;
   RangeJob j[B3GS_MAX_FUSED_VIEWS];
@@ -133,12 +141,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
   const ScanJob& job = sb.j[blockIdx.y];
   const uint32_t* __restrict__ order = job.order;
-  const uint32_t* __restrict__ touched = job.touched;
+  const uint2* __restrict__ rect = job.rect;
+  uint2* __restrict__ srect = job.srect;
   const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   uint32_t sum = 0, vis = 0;
   for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-    uint32_t t = touched[order[i]];
+    const uint2 rc = rect[order[i]];  // tiles_touched == area of the rectangle (preprocess keeps them consistent)
+    srect[i] = rc;
+    uint32_t t = rect_area(rc);
     sum += t;
     vis += (t != 0);
   }
@@ -182,34 +193,44 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_apply(ScanBatch sb) {
-  __shared__ uint32_t tmp[8];
+  __shared__ uint32_t wave_tot[4];
   const ScanJob& job = sb.j[blockIdx.y];
-  const uint32_t* __restrict__ order = job.order;
-  const uint32_t* __restrict__ touched = job.touched;
+  const uint2* __restrict__ srect = job.srect;
   uint32_t* __restrict__ soffs = job.soffs;
   const int P = sb.P;
+  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   uint32_t carry = job.chunk_sums[blockIdx.x];
   const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   for (int t = 0; t < sb.tiles_per_chunk; t++) {
     const int64_t tb = begin + (int64_t)t * SCAN_TILE;
     if (tb >= P) break;
-    // blocked arrangement: thread owns SCAN_ITEMS consecutive elements
-    uint32_t loc[SCAN_ITEMS], s = 0;
+    // wave w owns the contiguous slab [w*1024, (w+1)*1024) of the tile, 16 rounds of 64 consecutive
+    // elements (coalesced loads and stores); running inclusive scan in registers
+    const int64_t wb = tb + (int64_t)w * (SCAN_ITEMS * 64);
+    uint32_t inc[SCAN_ITEMS], run = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-      int64_t i = tb + (int64_t)threadIdx.x * SCAN_ITEMS + k;
-      loc[k] = i < P ? touched[order[i]] : 0u;
-      s += loc[k];
+    for (int r = 0; r < SCAN_ITEMS; r++) {
+      const int64_t i = wb + r * 64 + lane;
+      const uint32_t v = i < P ? rect_area(srect[i]) : 0u;
+      inc[r] = run + wave_incl_scan(v);
+      run = __shfl(inc[r], 63, 64);
     }
-    uint32_t tot;
-    uint32_t run = carry + block_excl_scan_256(s, tmp, &tot);
+    if (lane == 0) wave_tot[w] = run;
+    __syncthreads();
+    uint32_t base = carry, tot = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-      int64_t i = tb + (int64_t)threadIdx.x * SCAN_ITEMS + k;
-      run += loc[k];
-      if (i < P) soffs[i] = run;
+    for (unsigned k = 0; k < 4; k++) {
+      const uint32_t x = wave_tot[k];
+      if (k < w) base += x;
+      tot += x;
+    }
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; r++) {
+      const int64_t i = wb + r * 64 + lane;
+      if (i < P) soffs[i] = base + inc[r];
     }
     carry += tot;
+    __syncthreads();
   }
 }
 
@@ -223,10 +244,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_apply(ScanBatch sb) {
 //  here -- sort stage 352 us vs 274 us per view: a dependent kernel boundary costs ~1.5 us, an
 //  agent-scope hand-off 1-2 us PER look-back hop -- so the pass stays three launches.)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_hist(SortBatch sb, int shift) {
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_hist(SortBatch sb, int pass_shift) {
   __shared__ uint32_t h[256];
   const SortJob& job = sb.j[blockIdx.y];
   if (blockIdx.x >= job.nblk) return;
+  const int shift = pass_shift + job.shift_base;
   const uint32_t* __restrict__ keys = job.kin;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
   h[threadIdx.x] = 0;
@@ -260,7 +282,7 @@ __global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
   if (threadIdx.x == 0) job.hist[(size_t)256 * nblk + blockIdx.x] = carry;  // totals
 }
 
-__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int shift) {
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int pass_shift) {
   __shared__ uint32_t wave_cnt[4][256];
   __shared__ uint32_t blk_start[256];  // first slot of digit d inside this workgroup's reorder buffer
   __shared__ uint32_t gbase[256];      // global destination of that first slot
@@ -270,6 +292,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
 
   const SortJob& job = sb.j[blockIdx.y];
   if (blockIdx.x >= job.nblk) return;
+  const int shift = pass_shift + job.shift_base;
   const uint32_t* __restrict__ keys_in = job.kin;
   const uint32_t* __restrict__ vals_in = job.vin;
   uint32_t* __restrict__ keys_out = job.kout;
@@ -296,7 +319,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
     const bool valid = li < tile_n;
     const uint32_t gi = tile_base + li;
     key[r] = valid ? keys_in[gi] : 0xFFFFFFFFu;
-    val[r] = valid ? (vals_in ? vals_in[gi] : gi) : 0u;
+    val[r] = (valid && vals_out) ? (vals_in ? vals_in[gi] : gi) : 0u;
   }
 #pragma unroll
   for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
@@ -344,7 +367,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
       const uint32_t d = (key[r] >> shift) & 0xFF;
       const uint32_t p = wave_cnt[w][d] + rank[r];
       s_key[p] = key[r];
-      s_val[p] = val[r];
+      if (vals_out) s_val[p] = val[r];
     }
   }
   __syncthreads();
@@ -356,7 +379,16 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
       const uint32_t d = (kk >> shift) & 0xFF;
       const uint32_t dst = gbase[d] + (p - blk_start[d]);
       keys_out[dst] = kk;
-      vals_out[dst] = s_val[p];
+      if (vals_out) vals_out[dst] = s_val[p];
+      if (job.ranges) {
+        // Last pass: the keys of one tile are contiguous in this workgroup's reorder buffer (grouped by the
+        // top digit, ordered by the lower ones from the earlier passes) and land on consecutive addresses,
+        // so run boundaries give the tile's range inside this workgroup; min / max merge the workgroups
+        // (a few atomics per workgroup).  Ranges start at (0xFFFFFFFF, 0) = empty (preprocess).
+        const uint32_t tile = kk >> job.shift_base;
+        if (p == 0 || (s_key[p - 1] >> job.shift_base) != tile) atomicMin(&job.ranges[tile].x, dst);
+        if (p == tile_n - 1 || (s_key[p + 1] >> job.shift_base) != tile) atomicMax(&job.ranges[tile].y, dst + 1u);
+      }
     }
   }
 }
@@ -387,9 +419,9 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   uint2 rc = make_uint2(0, 0);
   if (s < P) {
     gid = job.order[s];
-    cnt = job.touched[gid];
+    rc = job.srect[s];
+    cnt = rect_area(rc);
     end = job.soffs[s];
-    rc = job.rect[gid];
   }
   // lanes past P inherit the last valid end so the search array stays monotone
   const uint32_t wave_end = __shfl(end, 63 - (int)__builtin_clzll(__ballot(s < P) | 1ull), 64);
@@ -417,8 +449,13 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     if (j < wave_end && j < n_cap) {
       const uint32_t k = j - (src_end - src_cnt);
       const uint32_t ry = k / src_rw, rx = k - ry * src_rw;
-      tile_out[j] = (src_y0 + ry) * (uint32_t)job.grid_x + (src_x0 + rx);
-      idx_out[j] = src_gid;
+      const uint32_t tile = (src_y0 + ry) * (uint32_t)job.grid_x + (src_x0 + rx);
+      if (idx_out) {
+        tile_out[j] = tile;
+        idx_out[j] = src_gid;
+      } else {
+        tile_out[j] = (tile << job.idx_bits) | src_gid;
+      }
     }
   }
 }
@@ -429,15 +466,14 @@ __global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
   const uint32_t n = min(*job.n_ptr, job.n_cap);
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  const uint32_t t = tile_sorted[j];
-  if (j == 0 || tile_sorted[j - 1] != t) job.ranges[t].x = j;
-  if (j == n - 1 || tile_sorted[j + 1] != t) job.ranges[t].y = j + 1;
+  const int sh = job.shift;
+  const uint32_t t = tile_sorted[j] >> sh;
+  if (j == 0 || (tile_sorted[j - 1] >> sh) != t) job.ranges[t].x = j;
+  if (j == n - 1 || (tile_sorted[j + 1] >> sh) != t) job.ranges[t].y = j + 1;
 }
 
 int tile_sort_passes(int W, int H) {
-  const size_t tiles = (size_t)((W + B3GS_TILE - 1) / B3GS_TILE) * (size_t)((H + B3GS_TILE - 1) / B3GS_TILE);
-  int tbits = 0;
-  while (((size_t)1 << tbits) < tiles) tbits++;
+  const int tbits = b3gs_tile_bits(W, H);
   return tbits == 0 ? 0 : (tbits + 7) / 8;
 }
 
@@ -471,7 +507,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   for (int v = 0; v < nviews; v++) {
     if (jobs[v].order_from != -1) continue;
     const GeomView& g = jobs[v].g;
-    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, g.hist};
+    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, 0, g.hist, nullptr};
   }
   for (int pass = 0; pass < 4; pass++) {
     radix_pass(db, 8 * pass, s);
@@ -497,7 +533,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
-    sc.j[v] = ScanJob{depth_order_of(jobs, v), jb.g.tiles_touched, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
+    sc.j[v] = ScanJob{depth_order_of(jobs, v), jb.g.rect, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
                       jb.g.header, jb.im.header, jb.n_out};
   }
   hipLaunchKernelGGL(scan_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
@@ -537,25 +573,38 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
     const BinJob& jb = jobs[v];
     const uint32_t n_cap = (uint32_t)(jb.n_bound > 0 ? jb.n_bound : 0);
     max_cap = n_cap > max_cap ? n_cap : max_cap;
-    eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.tiles_touched, jb.g.rect, jb.b.key[first], jb.b.val[first], n_cap,
-                      (jb.W + B3GS_TILE - 1) / B3GS_TILE};
-    tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
-                      b3gs_sort_blocks((int64_t)n_cap), jb.b.hist};
-    rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap};
+    const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
+    const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
+    if (idx_bits >= 0) {
+      // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
+      // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
+      // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits};
+      tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
+                        b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr};
+      rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits};
+    } else {
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0};
+      tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
+                        b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr};
+      rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0};
+    }
   }
-  if (max_cap == 0) return;  // im.ranges was zeroed by the preprocess launch (empty tiles keep [0,0))
+  if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
   hipLaunchKernelGGL(emit_instances, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
   for (int p = 0; p < passes; p++) {
+    if (p == passes - 1)
+      for (int v = 0; v < nviews; v++) tb.j[v].ranges = jobs[v].im.ranges;
     radix_pass(tb, 8 * p, s);
     for (int v = 0; v < nviews; v++) {
       SortJob& j = tb.j[v];
       const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
       j.kin = j.kout; j.vin = j.vout;
-      j.kout = const_cast<uint32_t*>(k); j.vout = const_cast<uint32_t*>(vv);
+      j.kout = const_cast<uint32_t*>(k); j.vout = const_cast<uint32_t*>(vv);  // stays null for packed keys
     }
   }
-  // ---- 5. per-tile [begin, end)
-  hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
+  // ---- 5. per-tile [begin, end): produced by the last pass above; a single-tile image has no pass
+  if (passes == 0) hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
 }

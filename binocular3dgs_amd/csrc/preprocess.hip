@@ -191,7 +191,7 @@ template <bool RAW>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (int v = 0; v < pb.n; v++)
-    if (i < pb.out[v].ntiles) pb.out[v].ranges[i] = make_uint2(0u, 0u);  // empty tiles keep [0,0): saves a memset launch
+    if (i < pb.out[v].ntiles) pb.out[v].ranges[i] = make_uint2(0xFFFFFFFFu, 0u);  // empty = (max, 0): the tile sort's last pass min/maxes into it
   if (i >= pb.sc[0].P) return;
   // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
   // scale modifier), activated opacity
@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
           const int ty1 = clampi_from_float(floorf((my + ext_y) / T) + 1.0f, gy);
           x0 = max(x0, tx0); x1 = max(x0, min(x1, tx1));
           y0 = max(y0, ty0); y1 = max(y0, min(y1, ty1));
-          area = (ext_x < 0.0f) ? 0 : (x1 - x0) * (y1 - y0);
+          if (ext_x < 0.0f) x1 = x0;  // opacity below 1/255: no tiles (rect area == tiles_touched, binning relies on it)
+          area = (x1 - x0) * (y1 - y0);
         }
         float4* rec = g.rec + 4 * (size_t)i;
         rec[0] = make_float4(mx, my, cxx, cxy);

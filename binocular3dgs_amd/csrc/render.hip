@@ -80,7 +80,7 @@ struct TileShared {
 // Stage one chunk: lane `tid` fetches list entry (first + tid); returns the Gaussian id (or -1).
 template <int CHUNK>
 __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t* __restrict__ point_list,
-                                           const float4* __restrict__ rec, uint32_t first, uint32_t last,
+                                           uint32_t idx_mask, const float4* __restrict__ rec, uint32_t first, uint32_t last,
                                            float tile_px, float tile_py) {
   const unsigned tid = threadIdx.x;
   const uint32_t idx = first + tid;
@@ -88,7 +88,7 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t
   bool hit[4] = {false, false, false, false};
   if (CHUNK < 256 && tid >= (unsigned)CHUNK) return id;  // whole waves: wave-uniform exit
   if (idx < last) {
-    id = (int)point_list[idx];
+    id = (int)(point_list[idx] & idx_mask);
     const float4* r = rec + 4 * (size_t)id;
     const float4 r0 = r[0], r1 = r[1], r2 = r[2];
     sh.A[tid] = r0;
@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   const int py = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
   const bool inside = px < W && py < H;
   const float fpx = (float)px, fpy = (float)py;
-  const uint2 range = ranges[tile];
+  uint2 range = ranges[tile];
+  if (range.y <= range.x) range = make_uint2(0u, 0u);  // empty tiles hold (0xFFFFFFFF, 0)
   const int nchunks = (int)((range.y - range.x + CHUNK - 1) / CHUNK);
 
   bool done = !inside;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
 
   for (int c = 0; c < nchunks; c++) {
     if (__syncthreads_and(done)) break;
-    stage_chunk(sh, point_list, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
+    stage_chunk(sh, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
     n_chunks++;
     if (__ballot(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
@@ -321,7 +322,8 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   const int ipx = tile_x * B3GS_TILE + (int)((w & 1) * 8 + (lane & 7));
   const int ipy = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
   const bool inside = ipx < W && ipy < H;
-  const uint2 range = ranges[tile];
+  uint2 range = ranges[tile];
+  if (range.y <= range.x) range = make_uint2(0u, 0u);  // empty tiles hold (0xFFFFFFFF, 0)
 
   BwdPixel px;
   px.fpx = (float)ipx;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   } while (0)
 
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
-    const int id = stage_chunk(sh.f, point_list, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
+    const int id = stage_chunk(sh.f, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
                                (float)(tile_y * B3GS_TILE));
     if (tid < (unsigned)CHUNK) sh.id[tid] = id;
     __syncthreads();
@@ -515,6 +517,8 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.ntiles = v.grid_x * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   v.ranges = im.ranges;
   v.point_list = b.val[0];
+  const int idx_bits = b3gs_packed_idx_bits(sc.P, sc.W, sc.H);
+  v.idx_mask = (idx_bits < 0 || idx_bits >= 32) ? 0xFFFFFFFFu : ((1u << idx_bits) - 1u);
   v.rec = g.rec;
   v.bg = sc.background;
   v.final_T = im.final_T;

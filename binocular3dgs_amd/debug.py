@@ -30,7 +30,17 @@ def state_views(P: int, W: int, H: int, num_rendered: int, geom: torch.Tensor, b
                ranges=_slice(img, v.ranges, tiles * 2, torch.int32).view(tiles, 2),
                final_T=_slice(img, v.final_T, W * H, torch.float32).view(H, W),
                n_contrib=_slice(img, v.n_contrib, W * H, torch.int32).view(H, W))
+    # empty tiles are stored as (0xFFFFFFFF, 0) (min / max identity of the tile sort's last pass): show [0, 0)
+    empty = out["ranges"][:, 1].to(torch.int64) <= (out["ranges"][:, 0].to(torch.int64) & 0xFFFFFFFF)
+    out["ranges"] = torch.where(empty[:, None], torch.zeros_like(out["ranges"]), out["ranges"])
     if has_bin:
-        out["point_list"] = _slice(binning, v.point_list, num_rendered, torch.int32)
-        out["tile_ids"] = _slice(binning, v.tile_ids, num_rendered, torch.int32)
+        words = _slice(binning, v.point_list, num_rendered, torch.int32)
+        if v.packed_idx_bits >= 0:
+            # one word per instance: (tile << bits) | index (b3gs_raster.h, B3gsDebugViews)
+            w64 = words.to(torch.int64) & 0xFFFFFFFF
+            out["point_list"] = (w64 & ((1 << v.packed_idx_bits) - 1)).to(torch.int32)
+            out["tile_ids"] = (w64 >> v.packed_idx_bits).to(torch.int32)
+        else:
+            out["point_list"] = words
+            out["tile_ids"] = _slice(binning, v.tile_ids, num_rendered, torch.int32)
     return out

@@ -69,6 +69,7 @@ class _RasterizeBatch(torch.autograd.Function):
     def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, owner, specs):
         owner._forward_batch(specs)
         ctx.owner, ctx.specs = owner, specs
+        ctx.set_materialize_grads(False)   # outputs without an upstream gradient arrive as None, not as zero images
         outs = []
         for sp in specs:
             s = owner.slots[sp["slot"]]

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 1
+#define B3GS_ABI_VERSION 2
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -251,11 +251,13 @@ typedef struct B3gsDebugViews {
   const uint32_t* tiles_touched; /* [P] */
   const float* depths;           /* [P] */
   const float* records;          /* [P,16] x,y,cxx,cxy,cyy,opacity,r,g,b,depth,ext_x,ext_y,... */
-  const uint32_t* point_list;    /* [N] Gaussian index per instance, tile-major, depth-sorted */
-  const uint32_t* tile_ids;      /* [N] tile id per sorted instance */
-  const uint32_t* ranges;        /* [tiles,2] */
+  const uint32_t* point_list;    /* [N] one word per instance, tile-major, depth-sorted: the Gaussian index, or
+                                  *     (tile << packed_idx_bits) | index when packed_idx_bits >= 0 */
+  const uint32_t* tile_ids;      /* [N] tile id per sorted instance; NULL when the words are packed */
+  const uint32_t* ranges;        /* [tiles,2] begin, end; an EMPTY tile holds (0xFFFFFFFF, 0) */
   const float* final_T;          /* [H*W] */
   const uint32_t* n_contrib;     /* [H*W] */
+  int32_t packed_idx_bits;       /* >= 0 whenever bits(P) + bits(tiles) <= 32 (e.g. <= 2M Gaussians at 800x600) */
 } B3gsDebugViews;
 int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,
                      const char* binning, const char* image, B3gsDebugViews* out);
