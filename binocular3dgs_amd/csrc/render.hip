@@ -73,7 +73,7 @@ template <int CHUNK>
 struct TileShared {
   float4 A[CHUNK];  // x, y, cxx, cxy
   float4 B[CHUNK];  // cyy, opacity, r, g
-  float4 C[CHUNK];  // b, depth, -, -
+  float4 C[CHUNK];  // b, depth, Gaussian index (bits), -
   u64 mask[4][CHUNK / 64];   // [quadrant][producer wave]
 };
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t
     const float4 r0 = r[0], r1 = r[1], r2 = r[2];
     sh.A[tid] = r0;
     sh.B[tid] = r1;
-    sh.C[tid] = make_float4(r2.x, r2.y, 0.f, 0.f);
+    sh.C[tid] = make_float4(r2.x, r2.y, __int_as_float(id), 0.f);
     // footprint [x-ex, x+ex] x [y-ey, y+ey] against the four 8x8 quadrants (pixel centres
     // tile_p + {0..7} and tile_p + {8..15})
     const float lx = r0.x - r2.z - tile_px, hx = r0.x + r2.z - tile_px;
@@ -123,11 +123,11 @@ __device__ __forceinline__ float blend_power(const float4& A, float cyy, float d
 // Batching the views of an iteration into one launch lets the dispatcher pack ~11k tiles over the
 // machine (one view's 1900 tiles fill it exactly once, so every launch paid its own tail:
 // measured 126 us for one view, 446 us for six in one launch).
-template <int CHUNK>
+template <int CHUNK, bool TRACE>
 __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileShared<CHUNK> sh;
-  const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
-  const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_chunks = 0;
   const BlendView bv = select_view(batch, (int)blockIdx.x);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
@@ -160,13 +160,13 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
     if (__syncthreads_and(done)) break;
     stage_chunk(sh, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
-    n_chunks++;
-    if (__ballot(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
+    if (TRACE) n_chunks++;
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
 #pragma unroll 1
     for (int pw = 0; pw < CHUNK / 64; pw++) {
       u64 m = uniform_u64(sh.mask[w][pw]);
       while (m) {
-        n_iter++;
+        if (TRACE) n_iter++;
         const int j = __builtin_ctzll(m);
         m &= m - 1;
         const int gidx = pw * 64 + j;
@@ -179,21 +179,21 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
         // branch-free: a pixel this Gaussian does not touch (or a finished pixel) blends alpha = 0,
         // which leaves T, the sums and last_contributor unchanged
         const bool live = !done && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-        float a = live ? alpha : 0.0f;
-        const bool stop = live && (T * (1.0f - a) < B3GS_T_EPS);  // would saturate: not blended, pixel done
+        const float test_T = T * (1.0f - (live ? alpha : 0.0f));
+        const bool stop = live && (test_T < B3GS_T_EPS);  // would saturate: not blended, pixel done
         done = done || stop;
-        a = stop ? 0.0f : a;
-        const float wgt = a * T;
+        const bool blend = live && !stop;
+        const float wgt = blend ? alpha * T : 0.0f;
         Cr = __builtin_fmaf(B.z, wgt, Cr);
         Cg = __builtin_fmaf(B.w, wgt, Cg);
         Cb = __builtin_fmaf(Cc.x, wgt, Cb);
         Dp = __builtin_fmaf(Cc.y, wgt, Dp);
         Ac += wgt;
-        T = T * (1.0f - a);
-        last_contributor = (a > 0.0f) ? (uint32_t)(c * CHUNK + gidx + 1) : last_contributor;
-        if (__ballot(!done) == 0) break;
+        T = blend ? test_T : T;
+        last_contributor = blend ? (uint32_t)(c * CHUNK + gidx + 1) : last_contributor;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
       }
-      if (__ballot(!done) == 0) break;
+      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
     }
   }
   if (inside) {
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
     out_depth[pix] = Dp;
     out_alpha[pix] = Ac;
   }
-  if (trace && lane == 0) {
+  if (TRACE && lane == 0) {
     unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
@@ -239,7 +239,6 @@ constexpr int RED_STRIDE = 68;
 template <int CHUNK>
 struct TileSharedBwd {
   TileShared<CHUNK> f;
-  int id[CHUNK];
   float red[4][10 * RED_STRIDE];
 };
 
@@ -291,13 +290,13 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[9] = wgt * px.dD;
 }
 
-template <int CHUNK>
+template <int CHUNK, bool TRACE>
 __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileSharedBwd<CHUNK> sh;
   __shared__ uint32_t s_max_last[4];
-  const unsigned long long t_start = trace ? __builtin_readcyclecounter() : 0ull;
-  const unsigned long long r_start = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_live = 0;
   const BlendView bv = select_view(batch, (int)blockIdx.x);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
@@ -367,15 +366,18 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   // reduction role of this lane: component k = lane>>2 (valid for k < 10), part = lane&3; the
   // component's destination array, row stride (floats) and column
   const unsigned rk = lane >> 2, rpart = lane & 3;
-  float* red_base;
-  unsigned red_stride, red_col;
-  if (rk < 2) { red_base = dL_dmeans2D; red_stride = 3; red_col = rk; }
-  else if (rk < 5) { red_base = dL_dcov3D; red_stride = cov_stride; red_col = rk - 2; }
-  else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; red_col = 0; }
-  else if (rk < 9) { red_base = dL_dcolors; red_stride = 3; red_col = rk - 6; }
-  else { red_base = dL_dcov3D; red_stride = cov_stride; red_col = 3; }
+  float* red_base;   // destination array + column of this lane's component
+  unsigned red_stride;
+  if (rk < 2) { red_base = dL_dmeans2D + rk; red_stride = 3; }
+  else if (rk < 5) { red_base = dL_dcov3D + (rk - 2); red_stride = cov_stride; }
+  else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; }
+  else if (rk < 9) { red_base = dL_dcolors + (rk - 6); red_stride = 3; }
+  else { red_base = dL_dcov3D + 3; red_stride = cov_stride; }
   const bool red_writer = (rk < 10u) && (rpart == 0);
   float* const red = sh.red[w];
+  static_assert(RED_STRIDE * 4 == 272, "row offsets of the ds_write_addtid_b32 block");
+  // LDS byte offset of this wave's scratch (an LDS pointer's value is its offset in the workgroup's allocation)
+  const uint32_t red_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)red);
   const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
 
   // Software pipeline across Gaussians (a wave is an in-order machine and every tile's waves are
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   //     before the next Gaussian's row writes execute.
   //   * the record of the next list entry is fetched before the current one is evaluated.
   float4 q0, q1, q2, q3;      // pending reduction reads
-  size_t pend_g = 0;          // Gaussian they belong to
+  uint32_t pend_g = 0;        // Gaussian they belong to (P < 2^24: 24-bit multiply for the row offset)
   bool pending = false;
 #define B3GS_RETIRE_PENDING()                                                          \
   do {                                                                                 \
@@ -395,13 +397,56 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));            \
     v = dpp_add<0xB1, 0xF>(v); /* quad_perm [1,0,3,2] */                               \
     v = dpp_add<0x4E, 0xF>(v); /* quad_perm [2,3,0,1] -> 4 parts of component rk */    \
-    if (red_writer) unsafeAtomicAdd(red_base + pend_g * red_stride + red_col, v);      \
+    if (red_writer) unsafeAtomicAdd(red_base + __umul24(pend_g, red_stride), v);       \
   } while (0)
 
+  // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
+#define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
+  do {                                                                                           \
+    const float power = blend_power(A, B.x, A.x - px.fpx, A.y - px.fpy);                         \
+    const float G = __expf(power);                                                               \
+    const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);                                          \
+    const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
+    if (TRACE) n_iter++;                                                                         \
+    if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
+      if (TRACE) n_live++;                                                                       \
+      float p[10];                                                                               \
+      bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);                                         \
+      B3GS_ROW_WRITES(p);                                                                        \
+      if (pending) B3GS_RETIRE_PENDING();                                                        \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
+      __builtin_amdgcn_wave_barrier();                                                           \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
+      q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];                            \
+      pend_g = (uint32_t)__float_as_int(Cc.z);                                                   \
+      pending = true;                                                                            \
+    }                                                                                            \
+  } while (0)
+  // row k of the per-wave scratch <- component k of every lane.  ds_write_addtid_b32 (address = M0 + offset
+  // + 4*lane, no address VGPR); s_nop: a SALU write of M0 needs one wait state before an LDS add-TID
+  // instruction, which the assembler does not insert inside an asm block.
+#define B3GS_ROW_WRITES(p)                                                                       \
+  asm volatile(                                                                                  \
+      "s_mov_b32 m0, %10\n\t"                                                                    \
+      "s_nop 0\n\t"                                                                              \
+      "ds_write_addtid_b32 %0 offset:0\n\t"                                                      \
+      "ds_write_addtid_b32 %1 offset:272\n\t"                                                    \
+      "ds_write_addtid_b32 %2 offset:544\n\t"                                                    \
+      "ds_write_addtid_b32 %3 offset:816\n\t"                                                    \
+      "ds_write_addtid_b32 %4 offset:1088\n\t"                                                   \
+      "ds_write_addtid_b32 %5 offset:1360\n\t"                                                   \
+      "ds_write_addtid_b32 %6 offset:1632\n\t"                                                   \
+      "ds_write_addtid_b32 %7 offset:1904\n\t"                                                   \
+      "ds_write_addtid_b32 %8 offset:2176\n\t"                                                   \
+      "ds_write_addtid_b32 %9 offset:2448"                                                       \
+      :                                                                                          \
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),  \
+        "v"(p[8]), "v"(p[9]), "s"(red_m0)                                                        \
+      : "memory")
+
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
-    const int id = stage_chunk(sh.f, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
-                               (float)(tile_y * B3GS_TILE));
-    if (tid < (unsigned)CHUNK) sh.id[tid] = id;
+    stage_chunk(sh.f, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
+                (float)(tile_y * B3GS_TILE));
     __syncthreads();
 #pragma unroll 1
     for (int pw = CHUNK / 64 - 1; pw >= 0; pw--) {
@@ -411,46 +456,39 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       const uint32_t lim = wave_last - base;  // positions >= wave_last were never reached by this quadrant
       if (lim < 64) m &= (1ull << lim) - 1ull;
       if (m == 0) continue;
+      // Walk the set bits from the back.  The record of the NEXT candidate (three broadcast ds_read_b128:
+      // A, B, C incl. the Gaussian index) is fetched before the current one is evaluated; the loop is
+      // unrolled by two so the two register sets swap roles instead of being copied.
       int j = 63 - __builtin_clzll(m);
       m &= ~(1ull << j);
-      float4 A = sh.f.A[pw * 64 + j], B = sh.f.B[pw * 64 + j];
+      const float4* const sA = sh.f.A + pw * 64;
+      const float4* const sB = sh.f.B + pw * 64;
+      const float4* const sC = sh.f.C + pw * 64;
+      float4 A0 = sA[j], B0 = sB[j], C0 = sC[j], A1, B1, C1;
       while (true) {
-        // prefetch the next candidate of this round
-        const bool more = m != 0;
-        const int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
+        bool more = m != 0;
+        int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
         m &= ~(1ull << jn);
-        const float4 An = sh.f.A[pw * 64 + jn], Bn = sh.f.B[pw * 64 + jn];
-        const int gidx = pw * 64 + j;
-        const float power = blend_power(A, B.x, A.x - px.fpx, A.y - px.fpy);
-        const float G = __expf(power);
-        const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);
-        const bool live = (base + (uint32_t)j < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-        n_iter++;
-        if (__ballot(live) != 0) {
-          n_live++;
-          const float4 Cc = sh.f.C[gidx];
-          const size_t g = (size_t)sh.id[gidx];
-          float p[10];
-          bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);
-#pragma unroll
-          for (int k = 0; k < 10; k++) red[k * RED_STRIDE + lane] = p[k];
-          if (pending) B3GS_RETIRE_PENDING();
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];
-          pend_g = g;
-          pending = true;
-        }
+        A1 = sA[jn]; B1 = sB[jn]; C1 = sC[jn];
+        B3GS_BWD_CANDIDATE(A0, B0, C0, j);
         if (!more) break;
-        j = jn; A = An; B = Bn;
+        j = jn;
+        more = m != 0;
+        jn = more ? 63 - __builtin_clzll(m) : j;
+        m &= ~(1ull << jn);
+        A0 = sA[jn]; B0 = sB[jn]; C0 = sC[jn];
+        B3GS_BWD_CANDIDATE(A1, B1, C1, j);
+        if (!more) break;
+        j = jn;
       }
     }
     __syncthreads();
   }
+#undef B3GS_BWD_CANDIDATE
+#undef B3GS_ROW_WRITES
   if (pending) B3GS_RETIRE_PENDING();
 #undef B3GS_RETIRE_PENDING
-  if (trace && lane == 0) {
+  if (TRACE && lane == 0) {
     unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;            // shader cycles this wave lived
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);  // 100 MHz wall clock: start | end
@@ -488,8 +526,10 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
     total += blocks_of(batch.v[k]);
   }
   if (total <= 0) return;
-  hipLaunchKernelGGL(render_fwd_kernel<FWD_CHUNK>, dim3(total), dim3(256), 0, s, batch,
-                     getenv("B3GS_FWD_TRACE") ? trace_buffer(total) : nullptr);
+  if (getenv("B3GS_FWD_TRACE"))  // debug: per-wave cycle trace (tools/bwd_trace.py fwd)
+    hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, true>), dim3(total), dim3(256), 0, s, batch, trace_buffer(total));
+  else
+    hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, false>), dim3(total), dim3(256), 0, s, batch, nullptr);
 }
 
 void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
@@ -503,9 +543,10 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   unsigned long long* trace = getenv("B3GS_BWD_TRACE") ? trace_buffer(total) : nullptr;
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
-  if (bwd_chunk == 256) hipLaunchKernelGGL(render_bwd_kernel<256>, dim3(total), dim3(256), 0, s, batch, trace);
-  else if (bwd_chunk == 128) hipLaunchKernelGGL(render_bwd_kernel<128>, dim3(total), dim3(256), 0, s, batch, trace);
-  else hipLaunchKernelGGL(render_bwd_kernel<64>, dim3(total), dim3(256), 0, s, batch, trace);
+  if (trace) hipLaunchKernelGGL((render_bwd_kernel<64, true>), dim3(total), dim3(256), 0, s, batch, trace);
+  else if (bwd_chunk == 256) hipLaunchKernelGGL((render_bwd_kernel<256, false>), dim3(total), dim3(256), 0, s, batch, trace);
+  else if (bwd_chunk == 128) hipLaunchKernelGGL((render_bwd_kernel<128, false>), dim3(total), dim3(256), 0, s, batch, trace);
+  else hipLaunchKernelGGL((render_bwd_kernel<64, false>), dim3(total), dim3(256), 0, s, batch, trace);
 }
 
 BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im) {

@@ -19,6 +19,18 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
       if (KIND == 5) { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[(i + 1) & 15]), false, false); a[i] = __uint_as_float(r[0]); a[(i + 1) & 15] = __uint_as_float(r[1]); }
       if (KIND == 6) a[i] = fminf(a[i], 0.99f);
       if (KIND == 7) a[i] = (a[i] > 0.5f) ? a[i] : 0.25f;   // v_cmp + v_cndmask
+      if (KIND == 9 && (i & 1) == 0) {  // one v_pk_fma_f32 per PAIR of elements: 8 instructions per 16 elements
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f x = {a[i], a[i + 1]};
+        x = __builtin_elementwise_fma(x, (v2f){1.0001f, 1.0002f}, (v2f){0.5f, 0.25f});
+        a[i] = x.x; a[i + 1] = x.y;
+      }
+      if (KIND == 10 && (i & 1) == 0) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f x = {a[i], a[i + 1]};
+        x = x * (v2f){1.0001f, 1.0002f};
+        a[i] = x.x; a[i + 1] = x.y;
+      }
       if (KIND == 8) { int t = __builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x140, 0xF, 0xF, false); a[i] = a[i] + __int_as_float(t); }
     }
   }
@@ -49,6 +61,7 @@ int main() {
       run<8>("v_add_f32_dpp rowmirror", occ, out);
       run<3>("v_exp_f32", occ, out); run<4>("v_rcp_f32", occ, out); run<5>("v_permlane32_swap", occ, out);
       run<6>("v_min_f32", occ, out); run<7>("v_cmp+v_cndmask", occ, out);
+      run<9>("v_pk_fma_f32 (x0.5 instr)", occ, out); run<10>("v_pk_mul_f32 (x0.5 instr)", occ, out);
     }
   }
   return 0;
