@@ -79,7 +79,8 @@ void blend_forward_one(const B3gsScene& sc, const GeomView& g, const BinView& b,
 
 BlendView blend_backward_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im,
                               const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, float* m2d,
-                              float* col, float* op, float* cov, uint32_t cov_stride) {
+                              float* col, float* op, float* cov, uint32_t m2d_stride, uint32_t col_stride,
+                              uint32_t op_stride, uint32_t cov_stride) {
   BlendView v = b3gs_blend_view(sc, g, b, im);
   v.dL_dcolor = dL_dcolor;
   v.dL_ddepth = dL_ddepth;
@@ -88,6 +89,9 @@ BlendView blend_backward_view(const B3gsScene& sc, const GeomView& g, const BinV
   v.dL_dcolors = col;
   v.dL_dopacity = op;
   v.dL_dcov3D = cov;
+  v.m2d_stride = m2d_stride;
+  v.col_stride = col_stride;
+  v.op_stride = op_stride;
   v.cov_stride = cov_stride;
   return v;
 }
@@ -345,7 +349,10 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   return B3GS_OK;
 }
 
-size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)11 * (size_t)(P > 0 ? P : 0); }
+// Raw-mode scratch: one row of B3GS_SCRATCH_ROW floats (48 bytes) per Gaussian -- conic xx, xy, yy, depth |
+// mean2D x, y | colour r, g, b | opacity | 2 pad -- so the 10-lane atomic of the blend backward lands on one
+// row (one or two cache lines) instead of four arrays, and the per-Gaussian pass reads three float4.
+size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)B3GS_SCRATCH_ROW * (size_t)(P > 0 ? P : 0); }
 
 int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,
                       const char* binning, const char* image, const float* dL_dcolor, const float* dL_ddepth,
@@ -370,25 +377,24 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
   b3gs_geom_view(const_cast<char*>(geometry), view->P, &g);
   b3gs_img_view(const_cast<char*>(image), view->W, view->H, &im);
   b3gs_bin_view(const_cast<char*>(binning), view->P, 1, &b);  // only val[0] (offset 0) is read
-  // scratch layout (zero on entry, left zero on exit): conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
+  // scratch (zero on entry, left zero on exit): rows of B3GS_SCRATCH_ROW floats, see b3gs_backward_scratch_floats
   const size_t P = (size_t)view->P;
-  float* s_cov = scratch;
-  float* s_m2d = scratch + 4 * P;
-  float* s_col = scratch + 7 * P;
-  float* s_op = scratch + 10 * P;
+  (void)P;
   StageTimer tm(s);
   tm.mark(-1);
   if (phases & 1) {
     BlendBatch batch;
     batch.n = 1;
-    batch.v[0] = blend_backward_view(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, s_m2d, s_col, s_op, s_cov, 4);
+    batch.v[0] = blend_backward_view(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, scratch + 4, scratch + 6,
+                                     scratch + 9, scratch, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW,
+                                     B3GS_SCRATCH_ROW);
     b3gs_launch_blend_backward(batch, s);
     tm.mark(3);
   }
   if (phases & 2) {
     if (!(phases & 1)) tm.mark(-1);
-    b3gs_launch_preprocess_backward(sx, g, radii, s_m2d, s_col, s_op, nullptr, s_cov, nullptr, nullptr, nullptr, grads,
-                                    dL_dmeans2D, s);
+    b3gs_launch_preprocess_backward(sx, g, radii, nullptr, nullptr, nullptr, nullptr, scratch, nullptr, nullptr, nullptr,
+                                    grads, dL_dmeans2D, s);
     tm.mark(4);
   }
   HIP_TRY(hipGetLastError());
@@ -431,7 +437,7 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
     BlendBatch batch;
     batch.n = 1;
     batch.v[0] = blend_backward_view(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors,
-                                     dL_dopacity, dL_dcov3D, 6);
+                                     dL_dopacity, dL_dcov3D, 3, 3, 1, 6);
     b3gs_launch_blend_backward(batch, s);
   }
   if ((rc = debug_sync(sc, s, "render backward"))) return rc;
@@ -497,9 +503,9 @@ int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_s
     b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
     b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
     b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, 1, &b);
-    const size_t P = (size_t)bv.view->P;  // scratch: conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
-    batch.v[k] = blend_backward_view(*bv.view, g, b, im, bv.dL_dcolor, bv.dL_ddepth, bv.dL_dalpha, bv.scratch + 4 * P,
-                                     bv.scratch + 7 * P, bv.scratch + 10 * P, bv.scratch, 4);
+    batch.v[k] = blend_backward_view(*bv.view, g, b, im, bv.dL_dcolor, bv.dL_ddepth, bv.dL_dalpha, bv.scratch + 4,
+                                     bv.scratch + 6, bv.scratch + 9, bv.scratch, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW,
+                                     B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW);
   }
   StageTimer tm(s);
   tm.mark(-1);

@@ -138,6 +138,7 @@ struct SceneX {
 };
 
 #define B3GS_MAX_FUSED_VIEWS 8
+#define B3GS_SCRATCH_ROW 12   /* floats per Gaussian in the raw-mode backward scratch (api.hip) */
 
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
@@ -214,7 +215,8 @@ struct BlendView {
   float* dL_dcolors;
   float* dL_dopacity;
   float* dL_dcov3D;
-  uint32_t cov_stride;     // 6: the [P,6] output doubles as conic/depth scratch; 4: RAW scratch
+  uint32_t m2d_stride, col_stride, op_stride;  // row strides (floats) of the three arrays above
+  uint32_t cov_stride;     // 6: the [P,6] output doubles as conic/depth scratch; B3GS_SCRATCH_ROW: raw-mode rows
 };
 struct BlendBatch {
   int32_t n;

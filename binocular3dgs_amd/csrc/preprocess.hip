@@ -321,6 +321,22 @@ struct PixSums {
   float gxx, gxy, gyy;  // d/d(conic); gxy is HALF the true xy gradient
   float gdepth, gcol[3], gop;
 };
+
+// Raw-mode scratch row (B3GS_SCRATCH_ROW = 12 floats): conic xx, xy, yy, depth | mean2D x, y | colour r, g, b |
+// opacity | 2 pad.  Returns the sums and leaves the row zero (the scratch is persistent: no per-view memset).
+__device__ __forceinline__ PixSums load_scratch_row(float* scratch, int i) {
+  static_assert(B3GS_SCRATCH_ROW == 12, "three float4 per row");
+  float4* row = reinterpret_cast<float4*>(scratch) + 3 * (size_t)i;
+  const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  row[0] = z; row[1] = z; row[2] = z;
+  PixSums in;
+  in.gxx = r0.x; in.gxy = r0.y; in.gyy = r0.z; in.gdepth = r0.w;
+  in.g2x = r1.x; in.g2y = r1.y;
+  in.gcol[0] = r1.z; in.gcol[1] = r1.w; in.gcol[2] = r2.x;
+  in.gop = r2.y;
+  return in;
+}
 // gradients w.r.t. the (activated) rasterizer inputs of one Gaussian
 struct GaussGrad {
   float dmean[3], dS[6], dscale[3];
@@ -569,25 +585,22 @@ __global__ void __launch_bounds__(256)
   const Mat16 pm = load_mat(sc.projmatrix);
 
   PixSums in;
-  in.g2x = dL_dmeans2D[i3];
-  in.g2y = dL_dmeans2D[i3 + 1];
-  // conic / depth sums: rows of 6 floats in standard mode (dL_dcov3D doubles as scratch), of 4 in RAW mode
-  const size_t cs = RAW ? 4 : 6;
-  in.gxx = dL_dcov3D[cs * i + 0];
-  in.gxy = dL_dcov3D[cs * i + 1];
-  in.gyy = dL_dcov3D[cs * i + 2];
-  in.gdepth = dL_dcov3D[cs * i + 3];
-  in.gcol[0] = dL_dcolors[i3];
-  in.gcol[1] = dL_dcolors[i3 + 1];
-  in.gcol[2] = dL_dcolors[i3 + 2];
-  in.gop = dL_dopacity[i];
-  if (RAW) {  // leave the scratch clean for the next view
-    dL_dmeans2D[i3] = 0.f; dL_dmeans2D[i3 + 1] = 0.f;
-    dL_dcolors[i3] = 0.f; dL_dcolors[i3 + 1] = 0.f; dL_dcolors[i3 + 2] = 0.f;
-    dL_dopacity[i] = 0.f;
-    reinterpret_cast<float4*>(dL_dcov3D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // [P,4] in RAW mode
+  if (RAW) {
+    // dL_dcov3D is the raw-mode scratch: one row per Gaussian (read, and left clean for the next view)
+    in = load_scratch_row(dL_dcov3D, i);
     if (m2d_out) { m2d_out[i3] = in.g2x; m2d_out[i3 + 1] = in.g2y; m2d_out[i3 + 2] = 0.f; }
   } else {
+    in.g2x = dL_dmeans2D[i3];
+    in.g2y = dL_dmeans2D[i3 + 1];
+    // conic / depth sums: rows of 6 floats (dL_dcov3D doubles as scratch)
+    in.gxx = dL_dcov3D[6 * (size_t)i + 0];
+    in.gxy = dL_dcov3D[6 * (size_t)i + 1];
+    in.gyy = dL_dcov3D[6 * (size_t)i + 2];
+    in.gdepth = dL_dcov3D[6 * (size_t)i + 3];
+    in.gcol[0] = dL_dcolors[i3];
+    in.gcol[1] = dL_dcolors[i3 + 1];
+    in.gcol[2] = dL_dcolors[i3 + 2];
+    in.gop = dL_dopacity[i];
     dL_dmeans2D[i3 + 2] = 0.f;
   }
 
@@ -654,7 +667,6 @@ __global__ void __launch_bounds__(256)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= base.P) return;
   const size_t i3 = 3 * (size_t)i;
-  const size_t P = (size_t)base.P;
   SceneX sx_;
   sx_.sc = base;
   sx_.raw = raw;
@@ -686,21 +698,7 @@ __global__ void __launch_bounds__(256)
     sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
     const Mat16 vm = load_mat(vr.viewmatrix);
     const Mat16 pm = load_mat(vr.projmatrix);
-    // scratch layout of b3gs_backward_raw: conic+depth [P,4] | mean2D [P,3] | colour [P,3] | opacity [P]
-    float* s_cov = vr.scratch;
-    float* s_m2d = vr.scratch + 4 * P;
-    float* s_col = vr.scratch + 7 * P;
-    float* s_op = vr.scratch + 10 * P;
-    const float4 cv = reinterpret_cast<float4*>(s_cov)[i];
-    PixSums in;
-    in.gxx = cv.x; in.gxy = cv.y; in.gyy = cv.z; in.gdepth = cv.w;
-    in.g2x = s_m2d[i3]; in.g2y = s_m2d[i3 + 1];
-    in.gcol[0] = s_col[i3]; in.gcol[1] = s_col[i3 + 1]; in.gcol[2] = s_col[i3 + 2];
-    in.gop = s_op[i];
-    reinterpret_cast<float4*>(s_cov)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_m2d[i3] = 0.f; s_m2d[i3 + 1] = 0.f;
-    s_col[i3] = 0.f; s_col[i3 + 1] = 0.f; s_col[i3 + 2] = 0.f;
-    s_op[i] = 0.f;
+    const PixSums in = load_scratch_row(vr.scratch, i);   // read and reset
     if (m2d) { m2d[i3] = in.g2x; m2d[i3 + 1] = in.g2y; m2d[i3 + 2] = 0.f; }
     if (vr.densify_stats) {
       st_norm += sqrtf(in.g2x * in.g2x + in.g2y * in.g2y);

@@ -368,10 +368,10 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   const unsigned rk = lane >> 2, rpart = lane & 3;
   float* red_base;   // destination array + column of this lane's component
   unsigned red_stride;
-  if (rk < 2) { red_base = dL_dmeans2D + rk; red_stride = 3; }
+  if (rk < 2) { red_base = dL_dmeans2D + rk; red_stride = bv.m2d_stride; }
   else if (rk < 5) { red_base = dL_dcov3D + (rk - 2); red_stride = cov_stride; }
-  else if (rk == 5) { red_base = dL_dopacity; red_stride = 1; }
-  else if (rk < 9) { red_base = dL_dcolors + (rk - 6); red_stride = 3; }
+  else if (rk == 5) { red_base = dL_dopacity; red_stride = bv.op_stride; }
+  else if (rk < 9) { red_base = dL_dcolors + (rk - 6); red_stride = bv.col_stride; }
   else { red_base = dL_dcov3D + 3; red_stride = cov_stride; }
   const bool red_writer = (rk < 10u) && (rpart == 0);
   float* const red = sh.red[w];
