@@ -104,6 +104,34 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t
     hit[1] = xr && yt;
     hit[2] = xl && yb;
     hit[3] = xr && yb;
+    // Exact test for the quadrants the bounding box reaches: the smallest value of the quadratic form
+    // over the quadrant's pixel rectangle against tau = ln(255 opacity) (alpha >= 1/255 <=> form <= tau).
+    // One thread does this once per staged Gaussian; every candidate it removes saves a 64-lane evaluation
+    // in each direction.  Conservative: continuous rectangle >= pixel centres, plus a rounding margin.
+    if (hit[0] || hit[1] || hit[2] || hit[3]) {
+      const float cxx = r0.z, cxy = r0.w, cyy = r1.x;
+      const float tau = __logf(255.0f * r1.y) * 1.0005f + 2e-3f;
+      const float icx = __builtin_amdgcn_rcpf(cxx), icy = __builtin_amdgcn_rcpf(cyy);
+      const float ox = tile_px - r0.x, oy = tile_py - r0.y;   // rectangle corner relative to the mean
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float ax = ox + (float)((q & 1) * 8), bx = ax + 7.0f;
+        const float ay = oy + (float)((q >> 1) * 8), by = ay + 7.0f;
+        const bool inside = (ax <= 0.0f) && (bx >= 0.0f) && (ay <= 0.0f) && (by >= 0.0f);
+        float fmin = 3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float dx = e ? bx : ax;                                   // vertical edge
+          const float dy = fminf(fmaxf(-cxy * dx * icy, ay), by);
+          fmin = fminf(fmin, 0.5f * (cxx * dx * dx + cyy * dy * dy) + cxy * dx * dy);
+          const float ey = e ? by : ay;                                   // horizontal edge
+          const float ex = fminf(fmaxf(-cxy * ey * icx, ax), bx);
+          fmin = fminf(fmin, 0.5f * (cxx * ex * ex + cyy * ey * ey) + cxy * ex * ey);
+        }
+        // (a NaN anywhere fails `!(fmin > tau)`'s complement only by keeping the candidate)
+        hit[q] = hit[q] && (inside || !(fmin > tau));
+      }
+    }
   }
   const unsigned w = tid >> 6;
 #pragma unroll
