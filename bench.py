@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched",
                     help="batched: every stage one launch for all 6 views, pairs share a depth sort; "
                          "streams: one stream per view; serial: one stream, per-view launches")
+    ap.add_argument("--viewspace-grads", action="store_true",
+                    help="also write every view's [P,3] screen-space mean gradients (viewspace_points.grad)")
     ap.add_argument("--serial-views", action="store_true",
                     help="render the views one after the other on one stream (un-overlapped kernel times, for profiles)")
     ap.add_argument("--dp-path", action="store_true",
@@ -114,7 +116,11 @@ def main():
     fused = None
     if args.path == "fused":
         from binocular3dgs_amd.fused import FusedRasterizer
-        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs),
+        # the densification statistics (train.py:178-179: the only consumer of the screen-space gradients) are
+        # updated inside the per-Gaussian backward pass, so the per-view [P,3] gradient tensors are not
+        # materialised unless asked for
+        model.init_densification_stats()
+        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=bool(args.viewspace_grads),
                                 schedule="serial" if args.serial_views else args.schedule)
     stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt, fused=fused)
     stepper.slab.force_collective = bool(args.dp_path)
@@ -281,7 +287,7 @@ def main():
                        "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
                        "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
-                       "optimizer_in_step": opt is not None,
+                       "optimizer_in_step": opt is not None, "densify_stats_in_step": fused is not None,
                        "optimizer": None if opt is None else args.optimizer, "path": args.path, "hip_graph": bool(use_graph),
                        "schedule": None if fused is None else fused.schedule,
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
