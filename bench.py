@@ -273,7 +273,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom.replace("_kernel", ""))
+                # per launch of the default schedule (all views of the iteration in one launch)
+                traffic = json.load(open(tpath)).get(dom.replace("_kernel", "")) if (vpl == views_per_iter and (P, W, H) == (1_000_000, 800, 600)) else None
             except Exception:
                 traffic = None
         out = {
@@ -294,7 +295,7 @@ def main():
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
             "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None if traffic is None else traffic * vpl, "bytes_per_launch": dom_bytes * vpl,
+                         "traffic": traffic, "bytes_per_launch": dom_bytes * vpl,
                          "avg_launch_ms": round(single[dom] * vpl, 4), "views_per_launch": vpl,
                          "note": "blend kernels are VALU/LDS-bound (SURVEY 8d caveat); see pixgauss_evals_per_s"},
             "roofline_view": {"bound": "hbm", "bytes_per_view": R + Wt, "read_bytes_per_view": R,

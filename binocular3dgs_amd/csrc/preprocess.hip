@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
         rec[0] = make_float4(mx, my, cxx, cxy);
         rec[1] = make_float4(cyy, op, rgb[0], rgb[1]);
         rec[2] = make_float4(rgb[2], pv[2], ext_x, ext_y);
-        rec[3] = make_float4(a, b, c, 0.f);
+        // (the fourth 16 bytes of the 64-byte record are padding: nothing reads them, so nothing writes them)
         radius_out = (int32_t)fminf(rad_f, 2147483520.0f);
         touched = (uint32_t)area;
         rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
