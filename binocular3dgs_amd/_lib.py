@@ -58,6 +58,15 @@ class B3gsForwardView(C.Structure):
                 ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32)]
 
 
+class B3gsLossIO(C.Structure):
+    _fields_ = [("W", C.c_int32), ("H", C.c_int32), ("image", C.c_void_p), ("depth", C.c_void_p), ("alpha", C.c_void_p),
+                ("gt_image", C.c_void_p), ("shifted_image", C.c_void_p), ("alpha_weight", C.c_void_p),
+                ("focal_x", C.c_float), ("trans_dist", C.c_float), ("lambda_dssim", C.c_float),
+                ("lambda_smooth", C.c_float), ("grad_scale", C.c_float), ("dL_dimage", C.c_void_p),
+                ("dL_ddepth", C.c_void_p), ("dL_dalpha", C.c_void_p), ("dL_dshifted", C.c_void_p),
+                ("parts", C.c_void_p), ("workspace", C.c_void_p)]
+
+
 class B3gsAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("count", C.c_int64), ("lr", C.c_float)]
@@ -83,7 +92,7 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
-           "b3gs_adam_step", "b3gs_forward_raw_batch")
+           "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss")
 
 _lib = None
 
@@ -142,6 +151,10 @@ def lib():
     L.b3gs_forward_raw_batch.argtypes = [C.c_int32, C.POINTER(B3gsForwardView), C.POINTER(B3gsRawParams), C.c_int,
                                          C.c_void_p]
     L.b3gs_forward_raw_batch.restype = C.c_int
+    L.b3gs_loss_workspace_floats.argtypes = [C.c_int32, C.c_int32]
+    L.b3gs_loss_workspace_floats.restype = C.c_size_t
+    L.b3gs_binocular_loss.argtypes = [C.POINTER(B3gsLossIO), C.c_void_p]
+    L.b3gs_binocular_loss.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int

@@ -1,0 +1,348 @@
+// Fused loss block of the binocular training step: value AND pixel gradients of
+//   total = (1-l)*L1(image, gt) + l*(1 - SSIM(image, gt))                         train.py:145-147
+//         + L1(warp(shifted, disparity)*mask, gt*mask) + 0.05*smooth(disparity*mask, gt)   train.py:131-136
+//         + mean(|alpha| * alpha_weight)                                           train.py:139-143
+// with  disparity = focal_x * (-trans_dist) / (depth + 1e-5)                       train.py:131,
+// warp / mask = utils/graphics_utils.py:80-125 (linear interpolation between column c+floor(d) and the
+// next one, zero where either tap leaves the image), smooth = utils/loss_utils.py:68-91 (central
+// differences on the interior, weighted by exp(-0.33 |sum_c d gt|)), SSIM = utils/loss_utils.py:36-66
+// (11x11 Gaussian window, sigma 1.5, zero padding, per channel).
+// The reference runs ~40 PyTorch kernels per pair forward + their autograd (10.1 ms per iteration of 3 pairs
+// at 800x600 on MI355X, four times the whole rasterizer); here: 4 launches per pair, gradients produced
+// in the same pass as the value (the loss is the root of the graph: its upstream gradient is a scalar).
+// Every image is H*W*{1,3} floats: L2-resident; the kernels are launch/latency bound, not HBM bound.
+#include "b3gs_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int LT = 16;          // output tile
+constexpr int LR = 5;           // SSIM window radius
+constexpr int LW = LT + 2 * LR; // 26
+// partial sums: thousands of workgroups adding to ONE address serialise in L2 (measured: 153 us for the SSIM
+// statistics kernel, almost all of it the two atomics per workgroup); each of the 8 sums is spread over 64
+// slots picked by workgroup index and folded by the finalize kernel
+constexpr int SLOTS = 64;
+__device__ __forceinline__ void add_sum(float* sums, int q, float v) {
+  const unsigned b = blockIdx.y * gridDim.x + blockIdx.x + blockIdx.z * 7u;
+  atomicAdd(&sums[q * SLOTS + (b & (SLOTS - 1))], v);
+}
+struct Win { float w[11]; };
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ float block_sum_256(float v, float* tmp) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x;
+  __syncthreads();
+  if ((tid & 63) == 0) tmp[tid >> 6] = v;
+  __syncthreads();
+  return tmp[0] + tmp[1] + tmp[2] + tmp[3];
+}
+
+// sums[0] += sum |x-y|, sums[1] += sum ssim_map; maps: dS/dmu1, dS/dE[x^2], dS/dE[xy] per channel
+__global__ void __launch_bounds__(256) ssim_stats_kernel(int W, int H, const float* __restrict__ img,
+                                                         const float* __restrict__ gt, Win win, float* __restrict__ sums,
+                                                         float* __restrict__ maps) {
+  __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
+  __shared__ float hq[5][LW][LT];
+  __shared__ float red[4];
+  const int ch = blockIdx.z;
+  const size_t hw = (size_t)H * W;
+  const float* __restrict__ x = img + ch * hw;
+  const float* __restrict__ y = gt + ch * hw;
+  const int tid = threadIdx.y * LT + threadIdx.x;
+  const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int r = i / LW, c = i % LW, gr = r0 + r, gc = c0 + c;
+    const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
+    sx[r][c] = in ? x[(size_t)gr * W + gc] : 0.f;
+    sy[r][c] = in ? y[(size_t)gr * W + gc] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < LW * LT; i += 256) {
+    const int r = i / LT, c = i % LT;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const float xv = sx[r][c + k], yv = sy[r][c + k], wk = win.w[k];
+      a0 = fmaf(wk, xv, a0); a1 = fmaf(wk, yv, a1); a2 = fmaf(wk, xv * xv, a2); a3 = fmaf(wk, yv * yv, a3);
+      a4 = fmaf(wk, xv * yv, a4);
+    }
+    hq[0][r][c] = a0; hq[1][r][c] = a1; hq[2][r][c] = a2; hq[3][r][c] = a3; hq[4][r][c] = a4;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int gr = blockIdx.y * LT + ty, gc = blockIdx.x * LT + tx;
+  float l1 = 0.f, ss = 0.f;
+  if (gr < H && gc < W) {
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const float wk = win.w[k];
+      mu1 = fmaf(wk, hq[0][ty + k][tx], mu1); mu2 = fmaf(wk, hq[1][ty + k][tx], mu2);
+      e11 = fmaf(wk, hq[2][ty + k][tx], e11); e22 = fmaf(wk, hq[3][ty + k][tx], e22);
+      e12 = fmaf(wk, hq[4][ty + k][tx], e12);
+    }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+    const float inv = 1.0f / (B1 * B2);
+    const float S = A1 * A2 * inv;
+    ss = S;
+    const size_t p = (size_t)gr * W + gc;
+    // dS/dmu1 (mu1 also enters s1 and s12), dS/dE[x^2], dS/dE[xy]
+    maps[(0 * 3 + ch) * hw + p] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+    maps[(1 * 3 + ch) * hw + p] = -S / B2;
+    maps[(2 * 3 + ch) * hw + p] = 2.f * A1 * inv;
+    l1 = fabsf(sx[ty + LR][tx + LR] - sy[ty + LR][tx + LR]);
+  }
+  const float t0 = block_sum_256(l1, red);
+  const float t1 = block_sum_256(ss, red);
+  if (tid == 0) { add_sum(sums, 0, t0); add_sum(sums, 1, t1); }
+}
+
+// dL/dimage = cS * (w*dmu1 + 2x (w*de11) + y (w*de12)) + cL1 * sign(x - y)
+__global__ void __launch_bounds__(256) ssim_grad_kernel(int W, int H, const float* __restrict__ img,
+                                                        const float* __restrict__ gt, Win win,
+                                                        const float* __restrict__ maps, float cS, float cL1,
+                                                        float* __restrict__ dL_dimage) {
+  __shared__ float sm[3][LW][LW + 1];
+  __shared__ float hq[3][LW][LT];
+  const int ch = blockIdx.z;
+  const size_t hw = (size_t)H * W;
+  const int tid = threadIdx.y * LT + threadIdx.x;
+  const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
+  for (int i = tid; i < LW * LW; i += 256) {
+    const int r = i / LW, c = i % LW, gr = r0 + r, gc = c0 + c;
+    const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
+    const size_t p = in ? (size_t)gr * W + gc : 0;
+#pragma unroll
+    for (int m = 0; m < 3; m++) sm[m][r][c] = in ? maps[(m * 3 + ch) * hw + p] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < LW * LT; i += 256) {
+    const int r = i / LT, c = i % LT;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+      const float wk = win.w[k];
+      a0 = fmaf(wk, sm[0][r][c + k], a0); a1 = fmaf(wk, sm[1][r][c + k], a1); a2 = fmaf(wk, sm[2][r][c + k], a2);
+    }
+    hq[0][r][c] = a0; hq[1][r][c] = a1; hq[2][r][c] = a2;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int gr = blockIdx.y * LT + ty, gc = blockIdx.x * LT + tx;
+  if (gr >= H || gc >= W) return;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; k++) {
+    const float wk = win.w[k];
+    g0 = fmaf(wk, hq[0][ty + k][tx], g0); g1 = fmaf(wk, hq[1][ty + k][tx], g1); g2 = fmaf(wk, hq[2][ty + k][tx], g2);
+  }
+  const size_t p = (size_t)gr * W + gc;
+  const float xv = img[ch * hw + p], yv = gt[ch * hw + p];
+  dL_dimage[ch * hw + p] = cS * (g0 + 2.f * xv * g1 + yv * g2) + cL1 * sgn(xv - yv);
+}
+
+struct BinoArgs {
+  int W, H;
+  const float* depth;
+  const float* alpha;
+  const float* gt;
+  const float* shifted;       // null: no binocular term
+  const float* alpha_weight;  // null: no alpha term
+  float k_disp;               // focal_x * (-trans_dist)
+  float c_l1m, c_smooth, c_alpha;   // scale / (3HW), lambda_smooth*scale / ((H-2)(W-2)), scale / HW
+  float* sums;
+  float* dL_ddepth;
+  float* dL_dalpha;
+  float* dL_dshifted;         // zero on entry (atomics)
+};
+
+struct Disp { float d, m; };
+// disparity of pixel (r,c) and its warp-mask value ((x1-d)+(d-x0) where both taps are inside, else 0)
+__device__ __forceinline__ Disp disparity_at(const BinoArgs& a, int r, int c) {
+  Disp o;
+  o.d = 0.f; o.m = 0.f;
+  if (r < 0 || r >= a.H || c < 0 || c >= a.W) return o;
+  const float d = a.k_disp / (a.depth[(size_t)r * a.W + c] + 1e-5f);
+  o.d = d;
+  if (!(fabsf(d) < 1.0e6f)) return o;
+  const float x0 = floorf(d), x1 = x0 + 1.0f;
+  const int c0 = c + (int)x0, c1 = c0 + 1;
+  if (c0 < 0 || c0 >= a.W || c1 < 0 || c1 >= a.W) return o;
+  o.m = (x1 - d) + (d - x0);
+  return o;
+}
+
+__global__ void __launch_bounds__(256) binocular_kernel(BinoArgs a) {
+  constexpr int HAL = 2, TW = LT + 2 * HAL;
+  __shared__ float sD[TW][TW + 1];   // disparity * mask with a halo of 2
+  __shared__ float red[4];
+  const int W = a.W, H = a.H;
+  const size_t hw = (size_t)H * W;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * LT + tx;
+  const int r = blockIdx.y * LT + ty, c = blockIdx.x * LT + tx;
+  const bool in = r < H && c < W;
+  const size_t p = in ? (size_t)r * W + c : 0;
+  float s_alpha = 0.f, s_l1m = 0.f, s_sx = 0.f, s_sy = 0.f;
+  if (in) {
+    float ga = 0.f;
+    if (a.alpha_weight) {
+      const float al = a.alpha[p], w = a.alpha_weight[p];
+      s_alpha = fabsf(al) * w;
+      ga = sgn(al) * w * a.c_alpha;
+    }
+    a.dL_dalpha[p] = ga;
+  }
+  if (!a.shifted) {   // uniform
+    if (in) a.dL_ddepth[p] = 0.f;
+  } else {
+    for (int i = tid; i < TW * TW; i += 256) {
+      const int rr = i / TW, cc = i % TW;
+      const Disp dd = disparity_at(a, (int)blockIdx.y * LT + rr - HAL, (int)blockIdx.x * LT + cc - HAL);
+      sD[rr][cc] = dd.d * dd.m;
+    }
+    __syncthreads();
+    if (in) {
+      const Disp me = disparity_at(a, r, c);
+      float dLdd = 0.f;
+      if (me.m != 0.f) {   // both taps inside
+        const float x0 = floorf(me.d), x1 = x0 + 1.0f;
+        const int c0 = c + (int)x0, c1 = c0 + 1;
+        const float w0 = x1 - me.d, w1 = me.d - x0;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          const float s0 = a.shifted[ch * hw + (size_t)r * W + c0], s1 = a.shifted[ch * hw + (size_t)r * W + c1];
+          const float warped = w0 * s0 + w1 * s1;
+          const float diff = warped * me.m - a.gt[ch * hw + p] * me.m;
+          s_l1m += fabsf(diff);
+          const float gW = sgn(diff) * me.m * a.c_l1m;   // dL/dwarped
+          if (gW != 0.f) {
+            atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c0], w0 * gW);
+            atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c1], w1 * gW);
+            dLdd += gW * (s1 - s0);
+          }
+        }
+      }
+      // edge-aware smoothness of D' = d*m: |ex * dx(D')| + |ey * dy(D')| on the interior
+      // g at location (rr,cc) along axis: value and d/dD' factor
+      auto gx_at = [&](int rr, int cc, float& val) -> float {   // returns sign(v)*ex*c_smooth, val = |v|
+        val = 0.f;
+        if (rr < 1 || rr > H - 2 || cc < 1 || cc > W - 2) return 0.f;
+        float e = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+          e += 0.5f * (a.gt[ch * hw + (size_t)rr * W + cc + 1] - a.gt[ch * hw + (size_t)rr * W + cc - 1]);
+        const float ex = __expf(fabsf(e) * -0.33f);
+        const int lr = rr - (int)blockIdx.y * LT + HAL, lc = cc - (int)blockIdx.x * LT + HAL;
+        const float v = ex * (0.5f * (sD[lr][lc + 1] - sD[lr][lc - 1]));
+        val = fabsf(v);
+        return sgn(v) * ex * a.c_smooth;
+      };
+      auto gy_at = [&](int rr, int cc, float& val) -> float {
+        val = 0.f;
+        if (rr < 1 || rr > H - 2 || cc < 1 || cc > W - 2) return 0.f;
+        float e = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+          e += 0.5f * (a.gt[ch * hw + (size_t)(rr + 1) * W + cc] - a.gt[ch * hw + (size_t)(rr - 1) * W + cc]);
+        const float ey = __expf(fabsf(e) * -0.33f);
+        const int lr = rr - (int)blockIdx.y * LT + HAL, lc = cc - (int)blockIdx.x * LT + HAL;
+        const float v = ey * (0.5f * (sD[lr + 1][lc] - sD[lr - 1][lc]));
+        val = fabsf(v);
+        return sgn(v) * ey * a.c_smooth;
+      };
+      float v, dDp = 0.f;
+      (void)gx_at(r, c, v); s_sx = v;
+      (void)gy_at(r, c, v); s_sy = v;
+      // D'[r][c] is the +0.5 tap of location (r, c-1) and the -0.5 tap of (r, c+1); rows likewise; the
+      // location's own row/column must be interior as well (dx is taken on rows 1..H-2, dy on columns 1..W-2)
+      dDp += 0.5f * gx_at(r, c - 1, v);
+      dDp -= 0.5f * gx_at(r, c + 1, v);
+      dDp += 0.5f * gy_at(r - 1, c, v);
+      dDp -= 0.5f * gy_at(r + 1, c, v);
+      dLdd += dDp * me.m;
+      a.dL_ddepth[p] = dLdd * (-me.d / (a.depth[p] + 1e-5f));
+    }
+  }
+  const float t0 = block_sum_256(s_alpha, red);
+  const float t1 = block_sum_256(s_l1m, red);
+  const float t2 = block_sum_256(s_sx, red);
+  const float t3 = block_sum_256(s_sy, red);
+  if (tid == 0) {
+    if (t0 != 0.f) add_sum(a.sums, 5, t0);
+    if (t1 != 0.f) add_sum(a.sums, 2, t1);
+    if (t2 != 0.f) add_sum(a.sums, 3, t2);
+    if (t3 != 0.f) add_sum(a.sums, 4, t3);
+  }
+}
+
+__global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restrict__ slots, int W, int H, float lambda_dssim,
+                                                           float lambda_smooth, int has_shift, float* __restrict__ parts) {
+  float sums[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    float v = slots[q * SLOTS + threadIdx.x];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    sums[q] = v;
+  }
+  if (threadIdx.x != 0) return;
+  const float hw = (float)H * (float)W;
+  const float Ll1 = sums[0] / (3.f * hw), ssim = sums[1] / (3.f * hw);
+  const float l1m = has_shift ? sums[2] / (3.f * hw) : 0.f;
+  const float inner = (float)(H - 2) * (float)(W - 2);
+  const float smooth = (has_shift && inner > 0.f) ? (sums[3] + sums[4]) / inner : 0.f;
+  const float al = sums[5] / hw;
+  parts[0] = ((1.f - lambda_dssim) * Ll1 + lambda_dssim * (1.f - ssim)) + (l1m + lambda_smooth * smooth) + al;
+  parts[1] = Ll1; parts[2] = ssim; parts[3] = l1m; parts[4] = smooth; parts[5] = al; parts[6] = 0.f; parts[7] = 0.f;
+}
+
+}  // namespace
+
+extern "C" size_t b3gs_loss_workspace_floats(int32_t W, int32_t H) {
+  return 8 * SLOTS + (size_t)9 * (size_t)(W > 0 ? W : 0) * (size_t)(H > 0 ? H : 0);
+}
+
+extern "C" int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream) {
+  if (!io || io->W <= 0 || io->H <= 0 || !io->image || !io->depth || !io->alpha || !io->gt_image || !io->dL_dimage ||
+      !io->dL_ddepth || !io->dL_dalpha || !io->parts || !io->workspace || (io->shifted_image && !io->dL_dshifted))
+    return B3GS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = io->W, H = io->H;
+  const size_t hw = (size_t)W * H;
+  float* sums = io->workspace;
+  float* maps = io->workspace + 8 * SLOTS;
+  // window exactly as utils/loss_utils.py:23-26: double exp -> float tensor -> normalised in float
+  Win win;
+  float g[11], tot = 0.f;
+  for (int k = 0; k < 11; k++) { g[k] = (float)std::exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); tot += g[k]; }
+  for (int k = 0; k < 11; k++) win.w[k] = g[k] / tot;
+  const float scale = io->grad_scale;
+  (void)hipMemsetAsync(sums, 0, 8 * SLOTS * sizeof(float), s);
+  if (io->shifted_image) (void)hipMemsetAsync(io->dL_dshifted, 0, 3 * hw * sizeof(float), s);
+  const dim3 blk(LT, LT), grid3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), grid1((W + LT - 1) / LT, (H + LT - 1) / LT, 1);
+  hipLaunchKernelGGL(ssim_stats_kernel, grid3, blk, 0, s, W, H, io->image, io->gt_image, win, sums, maps);
+  hipLaunchKernelGGL(ssim_grad_kernel, grid3, blk, 0, s, W, H, io->image, io->gt_image, win, maps,
+                     -io->lambda_dssim * scale / (3.f * (float)hw), (1.f - io->lambda_dssim) * scale / (3.f * (float)hw),
+                     io->dL_dimage);
+  BinoArgs a;
+  a.W = W; a.H = H;
+  a.depth = io->depth; a.alpha = io->alpha; a.gt = io->gt_image; a.shifted = io->shifted_image;
+  a.alpha_weight = io->alpha_weight;
+  a.k_disp = io->focal_x * (-io->trans_dist);
+  a.c_l1m = scale / (3.f * (float)hw);
+  const float inner = (float)(H - 2) * (float)(W - 2);
+  a.c_smooth = inner > 0.f ? io->lambda_smooth * scale / inner : 0.f;
+  a.c_alpha = scale / (float)hw;
+  a.sums = sums;
+  a.dL_ddepth = io->dL_ddepth; a.dL_dalpha = io->dL_dalpha; a.dL_dshifted = io->dL_dshifted;
+  hipLaunchKernelGGL(binocular_kernel, grid1, blk, 0, s, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(SLOTS), 0, s, sums, W, H, io->lambda_dssim, io->lambda_smooth,
+                     io->shifted_image ? 1 : 0, io->parts);
+  return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
+}

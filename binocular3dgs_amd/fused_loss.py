@@ -1,0 +1,89 @@
+"""The per-pair loss block of train.py:123-148 as ONE native call (b3gs_binocular_loss):
+value and all four pixel gradients in 4 kernel launches instead of ~40 PyTorch ops + their autograd
+(MI355X, 800x600, 3 pairs: 10.1 ms -> see tools/loss_time.py).  Same arguments and result as
+`loss.binocular_loss` (which stays as the readable PyTorch statement and the parity reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+class _Workspace:
+    """Per (device, W, H) persistent buffers: the gradients of a pair stay alive until backward uses them, so
+    every call gets its own slot from a small ring (the step calls the loss once per pair per iteration)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, dev, W, H, slot):
+        key = (dev, W, H, slot)
+        if key not in cls._cache:
+            f = dict(dtype=torch.float32, device=dev)
+            n = _lib.lib().b3gs_loss_workspace_floats(W, H)
+            cls._cache[key] = dict(ws=torch.empty(n, **f), parts=torch.zeros(8, **f), g_image=torch.empty((3, H, W), **f),
+                                   g_depth=torch.empty((1, H, W), **f), g_alpha=torch.empty((1, H, W), **f),
+                                   g_shifted=torch.empty((3, H, W), **f))
+        return cls._cache[key]
+
+
+class _BinocularLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, depth, alpha, shifted, gt, alpha_weight, focal_x, trans_dist, lambda_dssim, lambda_smooth,
+                slot, unit_grad, return_parts):
+        if not image.is_cuda:
+            raise _lib.B3gsError("binocular_loss_fused needs device tensors (no CPU fallback)")
+        H, W = image.shape[-2:]
+        buf = _Workspace.get(image.device, W, H, slot)
+        io = _lib.B3gsLossIO()
+        io.W, io.H = W, H
+        cont = [t.contiguous() for t in (image, depth, alpha, gt)]
+        io.image, io.depth, io.alpha, io.gt_image = (t.data_ptr() for t in cont)
+        sh = None if shifted is None else shifted.contiguous()
+        aw = None if alpha_weight is None else alpha_weight.contiguous()
+        io.shifted_image = None if sh is None else sh.data_ptr()
+        io.alpha_weight = None if aw is None else aw.data_ptr()
+        io.focal_x, io.trans_dist = float(focal_x or 0.0), float(trans_dist or 0.0)
+        io.lambda_dssim, io.lambda_smooth, io.grad_scale = float(lambda_dssim), float(lambda_smooth), 1.0
+        io.dL_dimage, io.dL_ddepth, io.dL_dalpha = buf["g_image"].data_ptr(), buf["g_depth"].data_ptr(), buf["g_alpha"].data_ptr()
+        io.dL_dshifted = buf["g_shifted"].data_ptr()
+        io.parts, io.workspace = buf["parts"].data_ptr(), buf["ws"].data_ptr()
+        rc = _lib.lib().b3gs_binocular_loss(C.byref(io), torch.cuda.current_stream(image.device).cuda_stream)
+        _lib.check(rc, "b3gs_binocular_loss")
+        ctx.buf, ctx.has_shift, ctx.unit_grad = buf, sh is not None, bool(unit_grad)
+        total = buf["parts"][0].clone()
+        if not return_parts:
+            return total, None
+        parts = buf["parts"].clone()
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        b = ctx.buf
+        if ctx.unit_grad:   # the loss is the root of the graph (total.backward()): upstream gradient == 1
+            gi, gd, ga, gs = b["g_image"], b["g_depth"], b["g_alpha"], b["g_shifted"]
+        else:
+            gi, gd, ga, gs = (b[k] * g_total for k in ("g_image", "g_depth", "g_alpha", "g_shifted"))
+        return (gi, gd, ga, gs if ctx.has_shift else None) + (None,) * 9
+
+
+def binocular_loss_fused(image, depth, alpha, gt_image, *, lambda_dssim: float = 0.2, shifted_image=None,
+                         focal_x: Optional[float] = None, trans_dist: Optional[float] = None, gt_alpha_mask=None,
+                         bg_mask=None, lambda_smooth: float = 0.05, slot: int = 0, unit_grad: bool = False,
+                         return_parts: bool = False):
+    """Drop-in for loss.binocular_loss(...)[0].  `slot`: index of the pair inside the iteration (gradient
+    buffers are per slot and reused across iterations).  unit_grad=True skips the multiplication by the
+    upstream scalar when the caller does `total.backward()` / sums the pair losses with weight 1.
+    return_parts: also return the device tensor [total, Ll1, ssim, l1_masked, smooth, alpha_loss, -, -]."""
+    aw = None
+    if gt_alpha_mask is not None:
+        aw = 1.0 - gt_alpha_mask
+    elif bg_mask is not None:
+        aw = bg_mask
+    total, parts = _BinocularLoss.apply(image, depth, alpha, shifted_image, gt_image, aw, focal_x, trans_dist,
+                                        lambda_dssim, lambda_smooth, int(slot), unit_grad, bool(return_parts))
+    return (total, parts) if return_parts else total

@@ -22,7 +22,19 @@ def l1_loss(network_output, gt, mask=None):
     return torch.abs(network_output - gt).mean()
 
 
+_WINDOWS = {}
+
+
 def _gaussian_window(window_size: int, sigma: float, channel: int, like: torch.Tensor) -> torch.Tensor:
+    """utils/loss_utils.py:23-34; built once per (size, channels, device, dtype) instead of on every call
+    (a host->device copy per iteration, which also cannot be captured in a HIP graph)."""
+    key = (window_size, sigma, channel, like.device, like.dtype)
+    if key not in _WINDOWS:
+        _WINDOWS[key] = _build_window(window_size, sigma, channel, like)
+    return _WINDOWS[key]
+
+
+def _build_window(window_size: int, sigma: float, channel: int, like: torch.Tensor) -> torch.Tensor:
     g = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
     g = (g / g.sum()).unsqueeze(1)
     w2d = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)

@@ -241,6 +241,35 @@ typedef struct B3gsAdamSegment {
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
                    float eps, float opacity_decay, int32_t opacity_segment, b3gs_stream_t stream);
 
+/* ---- fused loss block ----------------------------------------------------------------
+ * Value and pixel gradients of the per-pair training loss of train.py:123-148 in 4 launches:
+ *   total = (1-lambda_dssim) L1(image, gt) + lambda_dssim (1 - SSIM(image, gt))
+ *         + L1(warp(shifted, disp) mask, gt mask) + lambda_smooth smooth(disp mask, gt)     [shifted_image != NULL]
+ *         + mean(|alpha| alpha_weight)                                                      [alpha_weight  != NULL]
+ * disp = focal_x (-trans_dist) / (depth + 1e-5); warp / mask = utils/graphics_utils.py:80-125; smooth =
+ * utils/loss_utils.py:68-91; SSIM = utils/loss_utils.py:36-66.  alpha_weight is (1 - gt_alpha_mask) or the DTU
+ * background mask (train.py:139-143).  All images are [C,H,W] fp32 device tensors.  The four gradient images are
+ * OVERWRITTEN with d(total)/d(input) * grad_scale; parts (8 device floats) receives total, Ll1, ssim,
+ * l1_masked, smooth, alpha_loss.  No host synchronisation: graph-capturable. */
+typedef struct B3gsLossIO {
+  int32_t W, H;
+  const float* image;          /* [3,H,W] primary render */
+  const float* depth;          /* [1,H,W] */
+  const float* alpha;          /* [1,H,W] */
+  const float* gt_image;       /* [3,H,W] */
+  const float* shifted_image;  /* [3,H,W] or NULL */
+  const float* alpha_weight;   /* [1,H,W] or NULL */
+  float focal_x, trans_dist, lambda_dssim, lambda_smooth, grad_scale;
+  float* dL_dimage;            /* [3,H,W] */
+  float* dL_ddepth;            /* [1,H,W] */
+  float* dL_dalpha;            /* [1,H,W] */
+  float* dL_dshifted;          /* [3,H,W]; required iff shifted_image */
+  float* parts;                /* [8] */
+  float* workspace;            /* b3gs_loss_workspace_floats(W, H) floats */
+} B3gsLossIO;
+size_t b3gs_loss_workspace_floats(int32_t W, int32_t H);
+int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);
