@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched",
                     help="batched: every stage one launch for all 6 views, pairs share a depth sort; "
                          "streams: one stream per view; serial: one stream, per-view launches")
+    ap.add_argument("--loss", choices=("synthetic", "fused", "torch"), default="synthetic",
+                    help="synthetic: fixed pixel gradients (the metric's definition); fused / torch: the loss block of "
+                         "train.py:123-148 through b3gs_binocular_loss / through PyTorch ops")
     ap.add_argument("--viewspace-grads", action="store_true",
                     help="also write every view's [P,3] screen-space mean gradients (viewspace_points.grad)")
     ap.add_argument("--serial-views", action="store_true",
@@ -131,6 +134,24 @@ def main():
             out.append((spkg["render"], gc2))
         return out
 
+    step_kw = dict(pair_grad_fn=grad_fn)
+    if args.loss != "synthetic":
+        # the real loss block of train.py:123-148 on random ground-truth images instead of fixed pixel gradients
+        # (information only: BASELINE.json's metric is the rasterizer fwd+bwd with given pixel gradients)
+        from binocular3dgs_amd.fused_loss import binocular_loss_fused
+        from binocular3dgs_amd.loss import binocular_loss
+        gts = [torch.rand(3, H, W, device=dev) for _ in pairs]
+        bgm = [(g_.max(0, keepdim=True).values < 0.1).float() for g_ in gts]
+
+        def loss_fn(i, cam, pkg, spkg, t):
+            kw = dict(shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t,
+                      bg_mask=bgm[i])
+            if args.loss == "fused":
+                return binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i], slot=i,
+                                            unit_grad=True, **kw)
+            return binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i], **kw)[0]
+        step_kw = dict(loss_fn=loss_fn)
+
     def barrier():
         torch.cuda.synchronize(dev)
         if dp:
@@ -138,12 +159,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(max(args.warmup, 1)):
-        stepper.step(pair_grad_fn=grad_fn)
+        stepper.step(**step_kw)
     if fused is not None:
         while fused.overflowed():          # persistent binning capacity too small: grow once, outside the timed region
             fused.grow()
-            stepper.step(pair_grad_fn=grad_fn)
-    run_step = lambda: stepper.step(pair_grad_fn=grad_fn)  # noqa: E731
+            stepper.step(**step_kw)
+    run_step = lambda: stepper.step(**step_kw)  # noqa: E731
     use_graph = bool(args.graph) and fused is not None
     if use_graph and dp:
         # data parallel: the rendering part of the iteration is one hipGraph; the RCCL all-reduce of
@@ -152,11 +173,11 @@ def main():
             sg = torch.cuda.Stream()
             sg.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(sg):
-                stepper.compute_grads(pair_grad_fn=grad_fn)
+                stepper.compute_grads(**step_kw)
             torch.cuda.current_stream().wait_stream(sg)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                stepper.compute_grads(pair_grad_fn=grad_fn)
+                stepper.compute_grads(**step_kw)
 
             def run_step():
                 graph.replay()
@@ -165,7 +186,7 @@ def main():
             if rank == 0:
                 print(f"[bench] graph capture failed ({exc!r}); running eager", file=sys.stderr)
             use_graph = False
-            run_step = lambda: stepper.step(pair_grad_fn=grad_fn)  # noqa: E731
+            run_step = lambda: stepper.step(**step_kw)  # noqa: E731
     elif use_graph:
         # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
         # (6 views fwd+bwd, slab zero, Adam) is one hipGraph launch
@@ -178,11 +199,11 @@ def main():
         sg = torch.cuda.Stream()
         sg.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(sg):
-            stepper.step(pair_grad_fn=grad_fn)
+            stepper.step(**step_kw)
         torch.cuda.current_stream().wait_stream(sg)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            stepper.step(pair_grad_fn=grad_fn)
+            stepper.step(**step_kw)
         run_step = graph.replay
 
     # stage timing: HIP events recorded by the library on the launch stream, no sync inside.
@@ -213,7 +234,7 @@ def main():
         if was == "streams":
             fused.schedule, fused.concurrent = "serial", False
         for _ in range(min(args.steps, 5)):
-            stepper.step(pair_grad_fn=grad_fn)
+            stepper.step(**step_kw)
         barrier()
         fused.schedule, fused.concurrent = was, was == "streams"
         timed_views = min(args.steps, 5) * 2 * len(pairs)
@@ -288,7 +309,7 @@ def main():
                        "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
                        "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
                        "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
-                       "optimizer_in_step": opt is not None, "densify_stats_in_step": fused is not None,
+                       "loss": args.loss, "optimizer_in_step": opt is not None, "densify_stats_in_step": fused is not None,
                        "optimizer": None if opt is None else args.optimizer, "path": args.path, "hip_graph": bool(use_graph),
                        "schedule": None if fused is None else fused.schedule,
                        "parallelism": f"dp{world} (views sharded, params replicated)"},
