@@ -67,6 +67,13 @@ class B3gsLossIO(C.Structure):
                 ("parts", C.c_void_p), ("workspace", C.c_void_p)]
 
 
+class B3gsDensifyIO(C.Structure):
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("param", C.c_void_p * 6), ("exp_avg", C.c_void_p * 6),
+                ("exp_avg_sq", C.c_void_p * 6), ("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p),
+                ("grad_threshold", C.c_float), ("min_opacity", C.c_float), ("extent", C.c_float),
+                ("percent_dense", C.c_float), ("max_screen_size", C.c_float)]
+
+
 class B3gsAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("count", C.c_int64), ("lr", C.c_float)]
@@ -92,7 +99,8 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_binning_bytes", "b3gs_forward", "b3gs_forward_capacity", "b3gs_backward", "b3gs_mark_visible",
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
-           "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss")
+           "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss",
+           "b3gs_densify_classify", "b3gs_densify_scatter")
 
 _lib = None
 
@@ -155,6 +163,12 @@ def lib():
     L.b3gs_loss_workspace_floats.restype = C.c_size_t
     L.b3gs_binocular_loss.argtypes = [C.POINTER(B3gsLossIO), C.c_void_p]
     L.b3gs_binocular_loss.restype = C.c_int
+    L.b3gs_densify_classify.argtypes = [C.POINTER(B3gsDensifyIO), C.c_void_p, C.c_void_p]
+    L.b3gs_densify_classify.restype = C.c_int
+    L.b3gs_densify_scatter.argtypes = [C.POINTER(B3gsDensifyIO), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.c_void_p]
+    L.b3gs_densify_scatter.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int

@@ -291,6 +291,13 @@ class FusedRasterizer:
             return
         self._accumulate(pend, overwrite)
 
+    def resize(self):
+        """The model's Gaussian count changed (densification): re-create every slot for the new P."""
+        self.P = self.model.get_xyz.shape[0]
+        self.capacity = max(self.capacity, 12 * self.P)
+        for i in range(len(self.slots)):
+            self.slots[i] = self._new_slot(self.slots[i].stream)
+
     def num_rendered(self):
         """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered
         from a truncated list: call grow() and repeat the step."""

@@ -150,6 +150,20 @@ class ViewShardedStep:
             self.slab.rebind()
             self.optimizer.step()
 
+    def densify_and_prune(self, max_grad: float, min_opacity: float, extent: float, max_screen_size=None,
+                          percent_dense: float = 0.01, noise=None, generator=None, group=None) -> int:
+        """train.py:180-185 for this step object: replicas agree on the statistics, the Gaussian set is rebuilt
+        on the device (densify.densify_and_prune) and everything sized by P -- gradient slab, rasterizer
+        slots -- is re-created.  Any HIP graph captured around step() must be re-captured afterwards."""
+        from .densify import densify_and_prune
+        self.sync_densify_stats(group)
+        newP = densify_and_prune(self.model, self.optimizer, max_grad, min_opacity, extent, max_screen_size,
+                                 percent_dense, noise, generator)
+        self.slab = FlatGradSlab(self.model.parameters())
+        if self.fused is not None:
+            self.fused.resize()
+        return newP
+
     def sync_densify_stats(self, group=None):
         """Make the densification statistics identical on every replica before a densify/prune decision
         (SURVEY 8e): sums of xyz_gradient_accum / denom, maximum of max_radii2D.  Call it every

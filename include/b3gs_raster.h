@@ -270,6 +270,32 @@ typedef struct B3gsLossIO {
 size_t b3gs_loss_workspace_floats(int32_t W, int32_t H);
 int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream);
 
+/* ---- densify / clone / split / prune ------------------------------------------------------
+ * Net effect of the reference's densify_and_prune (scene/gaussian_model.py:393-407 with :258-391) including the
+ * Adam-state surgery, as: b3gs_densify_classify (per-Gaussian decisions) -> caller forms the three exclusive prefix
+ * sums and their totals (the only host read-back) -> b3gs_densify_scatter (one pass writes every surviving /
+ * new row of the six parameter tensors and of exp_avg / exp_avg_sq).
+ * Tensor order everywhere: xyz[P,3], features_dc[P,3], features_rest[P,3(M-1)], scaling[P,3], rotation[P,4],
+ * opacity[P] (raw, pre-activation).  flags[i]: bit 0 = original kept, bit 1 = clone appended, bit 2 = two split
+ * children appended.  Output rows: kept originals | clones | children k=0 | children k=1, each in index order
+ * (the reference's order); new rows get zero Adam state.  noise: [2,P,3] standard-normal samples addressed by
+ * the ORIGINAL index (child k of Gaussian i uses noise[k][i]): the caller owns the random stream, so replicas
+ * that share it stay identical.  max_screen_size <= 0: opacity rule only (what train.py passes). */
+typedef struct B3gsDensifyIO {
+  int32_t P, M;
+  const float* param[6];
+  const float* exp_avg[6];        /* all six, or all NULL */
+  const float* exp_avg_sq[6];
+  const float* xyz_gradient_accum; /* [P] */
+  const float* denom;              /* [P] */
+  float grad_threshold, min_opacity, extent, percent_dense, max_screen_size;
+} B3gsDensifyIO;
+int b3gs_densify_classify(const B3gsDensifyIO* io, int32_t* flags, b3gs_stream_t stream);
+int b3gs_densify_scatter(const B3gsDensifyIO* io, const int32_t* flags, const int32_t* off_keep,
+                         const int32_t* off_clone, const int32_t* off_split, int32_t n_keep, int32_t n_clone,
+                         int32_t n_split, const float* noise, float* const* out_param, float* const* out_exp_avg,
+                         float* const* out_exp_avg_sq, b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);

@@ -163,6 +163,36 @@ def test_g7_misc():
     np.testing.assert_allclose(psnr(torch.from_numpy(g["psnr_a"]), torch.from_numpy(g["psnr_b"])).numpy(), g["psnr"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_g8_densify_and_prune_restatement(case):
+    """The formulation the HIP densify kernels implement (per-Gaussian decisions + one scatter, tests/densify_ref.py)
+    reproduces what the reference's densify_and_prune did to parameters and Adam state."""
+    import densify_ref
+    g = load("densify.npz")
+    names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
+    t = lambda k: torch.from_numpy(g[k]).clone()  # noqa: E731
+    params = {n: t(f"{case}_in_{n}") for n in names}
+    m = {n: t(f"{case}_in_{n}_exp_avg") for n in names}
+    v = {n: t(f"{case}_in_{n}_exp_avg_sq") for n in names}
+    thr, min_op, extent, pd, size = [float(x) for x in g[f"{case}_scalars"]]
+    P = params["xyz"].shape[0]
+    grads = torch.nan_to_num(t(f"{case}_accum")[:, 0] / t(f"{case}_denom")[:, 0], nan=0.0)
+    sel = torch.nonzero((grads >= thr) & (torch.exp(params["scaling"]).max(1).values > pd * extent))[:, 0]
+    nz = t(f"{case}_noise")
+    noise = torch.zeros(2, P, 3)
+    noise[0, sel], noise[1, sel] = nz[:len(sel)], nz[len(sel):]
+    op, om, ov = densify_ref.densify_and_prune(params, m, v, t(f"{case}_accum"), t(f"{case}_denom"), thr, min_op, extent,
+                                               None if size < 0 else size, pd, noise)
+    for n in names:
+        ref = g[f"{case}_out_{n}"]
+        assert tuple(op[n].shape) == ref.shape, n
+        np.testing.assert_allclose(op[n].numpy(), ref, rtol=1e-6, atol=1e-7, err_msg=n)
+        np.testing.assert_array_equal(om[n].numpy(), g[f"{case}_out_{n}_exp_avg"], err_msg=n)
+        np.testing.assert_array_equal(ov[n].numpy(), g[f"{case}_out_{n}_exp_avg_sq"], err_msg=n)
+    np.testing.assert_allclose(torch.log(torch.sigmoid(t("decay_in")) * 0.995 / (1 - torch.sigmoid(t("decay_in")) * 0.995)).numpy(),
+                               g["decay_out"], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gaussian_renderer"), reason="reference tree only exists in the build container")
 def test_config1_reference_render_runs_on_top_of_the_boundary():
     """BASELINE config 1 (plumbing): the REFERENCE's own render() (imported read-only under the CPU shim),
