@@ -100,7 +100,7 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
            "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss",
-           "b3gs_densify_classify", "b3gs_densify_scatter")
+           "b3gs_densify_classify", "b3gs_densify_scatter", "b3gs_knn_workspace_bytes", "b3gs_knn_mean_dist2")
 
 _lib = None
 
@@ -169,6 +169,10 @@ def lib():
                                        C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.c_void_p]
     L.b3gs_densify_scatter.restype = C.c_int
+    L.b3gs_knn_workspace_bytes.argtypes = [C.c_int32]
+    L.b3gs_knn_workspace_bytes.restype = C.c_size_t
+    L.b3gs_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.b3gs_knn_mean_dist2.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int

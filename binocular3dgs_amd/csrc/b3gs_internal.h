@@ -191,6 +191,8 @@ struct BinJob {
   const uint32_t* order;  // internal (order_from == -2): explicit depth order
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
+void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,
+                                uint32_t* hist, hipStream_t s);   // hist: b3gs_sort_scratch_words(n) words
 // the two halves, for callers that size the binning buffer from N in between (b3gs_forward)
 void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);  // sort + scan
 void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);   // emit + split + ranges

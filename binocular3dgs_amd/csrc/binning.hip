@@ -484,6 +484,21 @@ static const uint32_t* depth_order_of(const BinJob* jobs, int v) {
   return jb.order_from == -1 ? jb.g.sval[0] : (jb.order_from >= 0 ? jobs[jb.order_from].g.sval[0] : jb.order);
 }
 
+// stable sort of n (u32 key, element index) pairs by all 32 key bits: keys -> skey[1] -> skey[0] -> skey[1] ->
+// skey[0]; sorted keys end in skey[0], the permutation in sval[0] (also used by the k-nearest-neighbour init)
+void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,
+                                uint32_t* hist, hipStream_t s) {
+  SortBatch db;
+  db.n = 1;
+  db.j[0] = SortJob{keys, nullptr, skey[1], sval[1], nullptr, n, b3gs_sort_blocks((int64_t)n), 0, hist, nullptr};
+  for (int pass = 0; pass < 4; pass++) {
+    radix_pass(db, 8 * pass, s);
+    const int dst = pass & 1;  // destination of the NEXT pass
+    db.j[0].kin = skey[dst ^ 1]; db.j[0].vin = sval[dst ^ 1];
+    db.j[0].kout = skey[dst]; db.j[0].vout = sval[dst];
+  }
+}
+
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
   b3gs_launch_depth_order_batch(P, nviews, jobs, s);
   b3gs_launch_tile_lists_batch(P, nviews, jobs, s);

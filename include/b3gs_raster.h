@@ -296,6 +296,13 @@ int b3gs_densify_scatter(const B3gsDensifyIO* io, const int32_t* flags, const in
                          int32_t n_split, const float* noise, float* const* out_param, float* const* out_exp_avg,
                          float* const* out_exp_avg_sq, b3gs_stream_t stream);
 
+/* ---- scale initialisation -------------------------------------------------------------
+ * mean_dist2[i] = mean squared distance from point i to its 3 nearest OTHER points: the distCUDA2 of the
+ * reference's simple-knn extension (scene/gaussian_model.py:134: scales = log(sqrt(max(dist2, 1e-7)))).
+ * Exact; points [P,3] and mean_dist2 [P] on the device; workspace = b3gs_knn_workspace_bytes(P) bytes. */
+size_t b3gs_knn_workspace_bytes(int32_t P);
+int b3gs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, char* workspace, b3gs_stream_t stream);
+
 /* Frustum test only: present[i] = 1 if Gaussian i passes the near-plane cull (view z > 0.2). */
 int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                       uint8_t* present, b3gs_stream_t stream);

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     h = open(os.path.join(ROOT, "include", "b3gs_raster.h")).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
-    return sorted(set(re.findall(r"\b(b3gs_[a-z_]+)\s*\(", h)) - {"b3gs_alloc_fn"})
+    return sorted(set(re.findall(r"\b(b3gs_[a-z0-9_]+)\s*\(", h)) - {"b3gs_alloc_fn"})
 
 
 def test_library_exports_every_declared_symbol():
