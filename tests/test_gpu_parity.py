@@ -40,7 +40,10 @@ def _run_hip_forward(d, mode="sh_sr"):
                 views=views, inputs=(g, sh, colors, scales, rots, cov))
 
 
-def _check_forward(d, st, out, px_tol=1e-3):
+def _check_forward(d, st, out, px_tol=1e-3, flip_frac=0.0):
+    """flip_frac: fraction of pixels allowed above the 2e-5 band (by at most one minimal contribution, 1/255):
+    a Gaussian whose alpha sits within an ulp of the 1/255 skip rule can be taken by one implementation and
+    skipped by the other (GPU exp2-based exp vs libm); over millions of pixels a handful of such pixels exist."""
     P = st.P
     assert out["n"] == st.N
     np.testing.assert_array_equal(out["radii"].cpu().numpy(), st.radii)
@@ -59,11 +62,19 @@ def _check_forward(d, st, out, px_tol=1e-3):
     for name, ref in (("color", st.color), ("depth", st.depth), ("alpha", st.alpha)):
         got = out[name].cpu().numpy()
         err = np.abs(got - ref) / (1 + np.abs(ref))
-        assert err.max() <= 2e-5, f"{name}: max err {err.max():.3e}"
+        if flip_frac > 0:
+            assert float((err > 2e-5).mean()) <= flip_frac and err.max() <= 1.0 / 255, f"{name}: {float((err > 2e-5).mean()):.2e}"
+        else:
+            assert err.max() <= 2e-5, f"{name}: max err {err.max():.3e}"
     nc = v["n_contrib"].cpu().numpy().astype(np.uint32)
     frac = float((nc != st.n_contrib).mean())
     assert frac <= px_tol, f"n_contrib differs at {frac:.4%} of pixels"
-    np.testing.assert_allclose(v["final_T"].cpu().numpy(), st.final_T, rtol=2e-4, atol=2e-6)
+    fT = v["final_T"].cpu().numpy()
+    if flip_frac > 0:
+        bad = np.abs(fT - st.final_T) > 2e-4 * np.abs(st.final_T) + 2e-6
+        assert float(bad.mean()) <= flip_frac and np.abs(fT - st.final_T).max() <= 1.0 / 255
+    else:
+        np.testing.assert_allclose(fT, st.final_T, rtol=2e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("seed,P,W,H", [(0, 500, 64, 48), (1, 3000, 200, 120), (2, 20000, 320, 240), (3, 257, 33, 17)])
@@ -272,3 +283,31 @@ def test_tile_bits_beyond_one_byte_and_two_bytes():
         d, _ = small_scene(P=2000, W=W, H=H, seed=60 + W, scale_mu=0.05)
         st = tile_ref.forward(**oracle_kwargs(d))
         _check_forward(d, st, _run_hip_forward(d))
+
+
+def test_two_word_instances_when_tile_and_index_bits_exceed_32():
+    """bits(P) + bits(tiles) > 32 switches the binning from one packed (tile | index) word per instance to a
+    (tile, index) pair (b3gs_packed_idx_bits): 140k Gaussians need 18 bits, 128 x 129 tiles 15.  Lists, ranges,
+    images and gradients must be the same algorithm."""
+    from oracle import tile_ref
+    from binocular3dgs_amd import _lib
+    import ctypes as C
+    P, W, H = 140000, 2048, 2064
+    d, _ = small_scene(P=P, W=W, H=H, seed=9, scale_mu=0.012)
+    st, ref, got = _backward_both(d, seed=9)
+    out = _run_hip_forward(d)
+    v = _lib.B3gsDebugViews()
+    _lib.check(_lib.lib().b3gs_debug_views(P, W, H, out["n"], out["geom"].data_ptr(), out["binning"].data_ptr(),
+                                           out["img"].data_ptr(), C.byref(v)), "b3gs_debug_views")
+    assert v.packed_idx_bits == -1 and v.tile_ids
+    _check_forward(d, st, out, flip_frac=1e-5)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert rel_l2(got[k].cpu().numpy(), ref[k]) <= 2e-4, k
+    # and the packed flavour just below the limit (17 + 15 bits)
+    d2, _ = small_scene(P=120000, W=W, H=H, seed=10, scale_mu=0.012)
+    st2 = tile_ref.forward(**oracle_kwargs(d2))
+    out2 = _run_hip_forward(d2)
+    _lib.check(_lib.lib().b3gs_debug_views(120000, W, H, out2["n"], out2["geom"].data_ptr(), out2["binning"].data_ptr(),
+                                           out2["img"].data_ptr(), C.byref(v)), "b3gs_debug_views")
+    assert v.packed_idx_bits == 17
+    _check_forward(d2, st2, out2, flip_frac=1e-5)
