@@ -204,7 +204,7 @@ int b3gs_forward(const B3gsScene* sc, b3gs_alloc_fn geometry_alloc, void* geomet
   }
   if ((rc = debug_sync(sc, s, "preprocess"))) return rc;
   tm.mark(0);
-  BinJob job{sc->W, sc->H, g, BinView{}, im, 0, nullptr, -1, nullptr};
+  BinJob job{sc->W, sc->H, g, BinView{}, im, 0, nullptr, -1, nullptr, nullptr, 1};
   b3gs_launch_depth_order_batch(sc->P, 1, &job, s);
   if ((rc = debug_sync(sc, s, "depth sort + scan"))) return rc;
 
@@ -259,7 +259,7 @@ static int forward_capacity_impl(const SceneX& sx, char* geometry, char* binning
     tm.mark(0);
     // every binning kernel clamps to min(N, capacity); an overflowing view renders a truncated
     // list, which the caller detects from *device_num_rendered > capacity and repeats
-    BinJob job{sc->W, sc->H, g, b, im, binning_capacity, device_num_rendered, -1, nullptr};
+    BinJob job{sc->W, sc->H, g, b, im, binning_capacity, device_num_rendered, -1, nullptr, nullptr, 1};
     b3gs_launch_binning_batch(sc->P, 1, &job, s);
     tm.mark(1);
   }
@@ -326,11 +326,27 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     b3gs_bin_view(fv.binning, sc.P, fv.binning_capacity, &b);
     pb.sc[k] = sc;
     pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
-    jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr};
+    jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr,
+                     nullptr, 1};
     bb.v[k] = b3gs_blend_view(sc, g, b, im);
     bb.v[k].out_color = fv.out_color;
     bb.v[k].out_depth = fv.out_depth;
     bb.v[k].out_alpha = fv.out_alpha;
+  }
+  // binocular pairs: the borrower's tile rects go to the odd slots of its donor's [P][2] rect array, so that
+  // the one random access of the binning (rect in depth order) is a single 16-byte load for both views
+  bool has_partner[B3GS_MAX_FUSED_VIEWS] = {};
+  for (int k = 0; k < nviews; k++) {
+    const int d = views[k].depth_order_from;
+    if (d < 0 || has_partner[d]) continue;
+    has_partner[d] = true;
+    pb.out[d].rect_stride = 2;
+    pb.out[k].rect = pb.out[d].rect + 1;
+    pb.out[k].rect_stride = 2;
+  }
+  for (int k = 0; k < nviews; k++) {
+    jobs[k].rect = pb.out[k].rect;
+    jobs[k].rect_stride = pb.out[k].rect_stride;
   }
   pb.raw = *params;
   StageTimer tm(s);

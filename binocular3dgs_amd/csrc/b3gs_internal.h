@@ -22,7 +22,7 @@ struct GeomView {       // sized by P
   float4* rec;          // [P*4] render record: x,y,cxx,cxy | cyy,op,r,g | b,depth,ext_x,ext_y | spare
   uint32_t* depth_key;  // [P]   float bits of view z, 0xFFFFFFFF when culled
   uint32_t* tiles_touched;  // [P]
-  uint2* rect;          // [P]   packed u16 (x0 | y0<<16, x1 | y1<<16)
+  uint2* rect;          // [2P]  packed u16 (x0 | y0<<16, x1 | y1<<16); [P] used unless a partner view interleaves its own
   uint32_t* clamped;    // [P]   bit c set: SH colour channel c clamped at 0
   uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
   uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
@@ -88,7 +88,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.rec = b3gs_carve<float4>(cur, p * 4);
   t.depth_key = b3gs_carve<uint32_t>(cur, p);
   t.tiles_touched = b3gs_carve<uint32_t>(cur, p);
-  t.rect = b3gs_carve<uint2>(cur, p);
+  t.rect = b3gs_carve<uint2>(cur, 2 * p);  // second half: the binocular partner's rects, interleaved (stride 2)
   t.clamped = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.skey[i] = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
@@ -151,7 +151,8 @@ struct PreOut {
   float4* rec;
   uint32_t* depth_key;
   uint32_t* tiles_touched;
-  uint2* rect;
+  uint2* rect;          // element i at rect[i * rect_stride]
+  int32_t rect_stride;  // 1, or 2 when a binocular pair shares one [P][2] array (one 16-byte gather serves both views)
   uint32_t* clamped;
   int32_t* radii;
   uint2* ranges;
@@ -189,6 +190,8 @@ struct BinJob {
   int32_t* n_out;
   int32_t order_from;
   const uint32_t* order;  // internal (order_from == -2): explicit depth order
+  const uint2* rect;      // tile rects as written by the projection (PreOut::rect / rect_stride); null: g.rect, stride 1
+  int32_t rect_stride;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,

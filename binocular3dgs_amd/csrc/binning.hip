@@ -83,7 +83,10 @@ struct SortBatch {
 
 struct ScanJob {
   const uint32_t* order;    // depth order (own or the donor view's)
-  const uint2* rect;        // tile rectangles by Gaussian
+  const uint2* rect;        // tile rectangles by Gaussian (element i at rect[i * rect_stride])
+  int32_t rect_stride;
+  int32_t partner;          // >= 0: job whose rects are interleaved with this one's ([P][2]) and which shares the depth
+                            //       order: this job's workgroups gather both with ONE 16-byte load; -2: done by its partner
   uint2* srect;             // the same in depth order (written by the first scan launch: ONE gather per view)
   uint32_t* soffs;
   uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
@@ -140,18 +143,37 @@ constexpr int SCAN_MAX_CHUNKS = 2048;
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
   const ScanJob& job = sb.j[blockIdx.y];
+  if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
   const uint32_t* __restrict__ order = job.order;
-  const uint2* __restrict__ rect = job.rect;
-  uint2* __restrict__ srect = job.srect;
   const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
-  uint32_t sum = 0, vis = 0;
-  for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-    const uint2 rc = rect[order[i]];  // tiles_touched == area of the rectangle (preprocess keeps them consistent)
-    srect[i] = rc;
-    uint32_t t = rect_area(rc);
-    sum += t;
-    vis += (t != 0);
+  uint32_t sum = 0, vis = 0, sum2 = 0, vis2 = 0;
+  // tiles_touched == area of the rectangle (preprocess keeps them consistent)
+  if (job.partner >= 0) {
+    const ScanJob& pj = sb.j[job.partner];
+    const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
+    uint2* __restrict__ sa = job.srect;
+    uint2* __restrict__ sb2 = pj.srect;
+    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
+      const uint4 rr = rect2[order[i]];   // the random access of the binning: one line for both views of the pair
+      const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
+      sa[i] = ra;
+      sb2[i] = rb;
+      const uint32_t ta = rect_area(ra), tb = rect_area(rb);
+      sum += ta; vis += (ta != 0);
+      sum2 += tb; vis2 += (tb != 0);
+    }
+  } else {
+    const uint2* __restrict__ rect = job.rect;
+    const size_t stride = (size_t)job.rect_stride;
+    uint2* __restrict__ srect = job.srect;
+    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
+      const uint2 rc = rect[order[i] * stride];
+      srect[i] = rc;
+      const uint32_t t = rect_area(rc);
+      sum += t;
+      vis += (t != 0);
+    }
   }
   uint32_t tot, tot2;
   block_excl_scan_256(sum, tmp, &tot);
@@ -159,6 +181,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   if (threadIdx.x == 0) {
     job.chunk_sums[blockIdx.x] = tot;
     job.chunk_vis[blockIdx.x] = tot2;
+  }
+  if (job.partner >= 0) {
+    const ScanJob& pj = sb.j[job.partner];
+    block_excl_scan_256(sum2, tmp, &tot);
+    block_excl_scan_256(vis2, tmp, &tot2);
+    if (threadIdx.x == 0) {
+      pj.chunk_sums[blockIdx.x] = tot;
+      pj.chunk_vis[blockIdx.x] = tot2;
+    }
   }
 }
 
@@ -548,8 +579,20 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
-    sc.j[v] = ScanJob{depth_order_of(jobs, v), jb.g.rect, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
+    const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
+    const int32_t rstride = jb.rect ? jb.rect_stride : 1;
+    sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
                       jb.g.header, jb.im.header, jb.n_out};
+  }
+  // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
+  // into d's gather
+  for (int v = 0; v < nviews; v++) {
+    const int d = jobs[v].order_from;
+    if (d < 0 || sc.j[d].partner != -1 || sc.j[v].rect_stride != 2 || sc.j[d].rect_stride != 2 ||
+        sc.j[v].rect != sc.j[d].rect + 1)
+      continue;
+    sc.j[d].partner = v;
+    sc.j[v].partner = -2;
   }
   hipLaunchKernelGGL(scan_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);

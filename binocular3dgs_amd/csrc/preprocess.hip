@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   g.radii[i] = radius_out;
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
-  g.rect[i] = rect;
+  g.rect[(size_t)i * g.rect_stride] = rect;
   g.clamped[i] = clamp_bits;
   }
 }
@@ -772,6 +772,7 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.depth_key = g.depth_key;
   o.tiles_touched = g.tiles_touched;
   o.rect = g.rect;
+  o.rect_stride = 1;
   o.clamped = g.clamped;
   o.radii = radii;
   o.ranges = im.ranges;
