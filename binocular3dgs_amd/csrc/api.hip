@@ -343,6 +343,10 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     pb.out[d].rect_stride = 2;
     pb.out[k].rect = pb.out[d].rect + 1;
     pb.out[k].rect_stride = 2;
+    if (d == k - 1) {   // adjacent in the batch: the projection kernel writes both rects with one 16-byte store
+      pb.out[d].rect_role = 1;
+      pb.out[k].rect_role = 2;
+    }
   }
   for (int k = 0; k < nviews; k++) {
     jobs[k].rect = pb.out[k].rect;

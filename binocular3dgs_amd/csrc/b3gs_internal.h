@@ -153,6 +153,8 @@ struct PreOut {
   uint32_t* tiles_touched;
   uint2* rect;          // element i at rect[i * rect_stride]
   int32_t rect_stride;  // 1, or 2 when a binocular pair shares one [P][2] array (one 16-byte gather serves both views)
+  int32_t rect_role;    // 0: store rect[i * rect_stride]; 1: first of a pair, the NEXT view of the batch is its partner
+                        //    (keep the rect in a register); 2: second of that pair: store both as one 16-byte word
   uint32_t* clamped;
   int32_t* radii;
   uint2* ranges;

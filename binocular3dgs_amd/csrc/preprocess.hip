@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   const float op = load_opacity<RAW>(sx_, i);
   const ShView sh = sh_view<RAW>(sx_, i);
 
+  uint2 held_rect = make_uint2(0u, 0u);
 #pragma unroll 1
   for (int v = 0; v < pb.n; v++) {
   const B3gsScene& sc = pb.sc[v];
@@ -307,7 +308,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   g.radii[i] = radius_out;
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
-  g.rect[(size_t)i * g.rect_stride] = rect;
+  if (g.rect_role == 1) held_rect = rect;
+  else if (g.rect_role == 2) reinterpret_cast<uint4*>(g.rect - 1)[i] = make_uint4(held_rect.x, held_rect.y, rect.x, rect.y);
+  else g.rect[(size_t)i * g.rect_stride] = rect;
   g.clamped[i] = clamp_bits;
   }
 }
@@ -773,6 +776,7 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.tiles_touched = g.tiles_touched;
   o.rect = g.rect;
   o.rect_stride = 1;
+  o.rect_role = 0;
   o.clamped = g.clamped;
   o.radii = radii;
   o.ranges = im.ranges;
