@@ -30,6 +30,7 @@ int fail(int code, const char* fmt, const char* detail) {
 int check_scene(const B3gsScene* sc) {
   if (!sc) return fail(B3GS_ERR_ARG, "%s", "scene is NULL");
   if (sc->P < 0 || sc->W <= 0 || sc->H <= 0) return fail(B3GS_ERR_ARG, "%s", "bad P/W/H");
+  if (sc->P >= (1 << 24)) return fail(B3GS_ERR_ARG, "%s", "P must be below 2^24 (24-bit row offsets in the blend backward)");
   if (sc->D < 0 || sc->D > 3) return fail(B3GS_ERR_ARG, "%s", "SH degree must be 0..3");
   if ((sc->shs == nullptr) == (sc->colors_precomp == nullptr))
     return fail(B3GS_ERR_ARG, "%s", "provide exactly one of shs / colors_precomp");
@@ -56,6 +57,7 @@ SceneX wrap(const B3gsScene* sc) {
 int check_raw(const B3gsScene* sc, const B3gsRawParams* rp) {
   if (!sc || !rp) return fail(B3GS_ERR_ARG, "%s", "scene / raw params NULL");
   if (sc->P < 0 || sc->W <= 0 || sc->H <= 0) return fail(B3GS_ERR_ARG, "%s", "bad P/W/H");
+  if (sc->P >= (1 << 24)) return fail(B3GS_ERR_ARG, "%s", "P must be below 2^24 (24-bit row offsets in the blend backward)");
   if (sc->D < 0 || sc->D > 3 || sc->M < (sc->D + 1) * (sc->D + 1)) return fail(B3GS_ERR_ARG, "%s", "bad SH degree / M");
   if (((sc->W + B3GS_TILE - 1) / B3GS_TILE) > 65535 || ((sc->H + B3GS_TILE - 1) / B3GS_TILE) > 65535)
     return fail(B3GS_ERR_ARG, "%s", "image too large for the packed tile rect");

@@ -52,7 +52,7 @@ typedef char* (*b3gs_alloc_fn)(void* user, size_t bytes);
 /* One view of one Gaussian cloud.  Field meaning = the 12 settings of
  * gaussian_renderer/__init__.py:36-49 plus the 8 tensors of :85-93. */
 typedef struct B3gsScene {
-  int32_t P;           /* number of Gaussians */
+  int32_t P;           /* number of Gaussians (< 2^24) */
   int32_t D;           /* active SH degree, 0..3 (raster_settings.sh_degree) */
   int32_t M;           /* SH coefficients per channel stored in `shs` (0 when shs == NULL) */
   int32_t W, H;        /* image_width, image_height */
