@@ -66,3 +66,68 @@ def test_training_reduces_loss_and_raises_psnr(use_fused):
     assert p1 > p0 + 3.0, (p0, p1)
     for p in model.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_full_loop_init_train_densify_save_reload():
+    """Every piece a reference user touches, chained as train.py chains them: point-cloud initialisation
+    (create_from_pcd / distCUDA2), batched rasterizer with shared depth sort, fused loss block, one-launch Adam with
+    opacity decay, on-device densification with optimiser surgery, PLY save / load."""
+    import os
+    import tempfile
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.fused_loss import binocular_loss_fused
+    from binocular3dgs_amd.init_points import create_from_points, load_ply, save_ply
+    from binocular3dgs_amd.render import PipelineParams, render
+    from binocular3dgs_amd.step import FusedAdam, ViewShardedStep
+    torch.manual_seed(0)
+    W, H, P = 160, 120, 8000
+    dev = "cuda"
+    gt_model = synth.synth_model(P, seed=21, device=dev, width=W, height=H, requires_grad=False)
+    with torch.no_grad():
+        gt_model._scaling += 0.7
+    pairs = synth.synth_view_set(W, H, device=dev)
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        gts = [render(cam, gt_model, PipelineParams(), bg)["render"].clone() for cam, _, _ in pairs]
+    # "SfM points": a subset of the true centres with grey colours
+    pts = gt_model.get_xyz.detach().cpu().numpy()[::2]
+    model = create_from_points(pts, 0.5 * torch.ones(len(pts), 3).numpy(), sh_degree=1)
+    model.active_sh_degree = 1
+    model.init_densification_stats()
+    lrs = [1.6e-4, 2.5e-2, 2.5e-3, 5e-3, 1e-3, 0.05]
+    opt = FusedAdam(model.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5)
+    fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+    st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr)
+    losses = []
+
+    def loss_fn(i, cam, pkg, spkg, t):
+        total = binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i],
+                                     shifted_image=spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t,
+                                     bg_mask=(gts[i].max(0, keepdim=True).values < 0.02).float(), slot=i, unit_grad=True)
+        losses.append(total.detach())
+        return total
+
+    def psnr_now(m):
+        with torch.no_grad():
+            return sum(_psnr(render(cam, m, PipelineParams(), bg)["render"], gts[i]) for i, (cam, _, _) in enumerate(pairs)) / len(pairs)
+
+    p0 = psnr_now(model)
+    n0 = model.get_xyz.shape[0]
+    for it in range(1, 91):
+        st.step(loss_fn=loss_fn)
+        if it in (30, 60):
+            thr = float((model.xyz_gradient_accum / model.denom.clamp(min=1)).quantile(0.8))
+            st.densify_and_prune(thr, 0.005, 5.0, generator=torch.Generator(device=dev).manual_seed(it))
+    torch.cuda.synchronize()
+    n1 = model.get_xyz.shape[0]
+    p1 = psnr_now(model)
+    assert n1 > n0, (n0, n1)
+    assert float(torch.stack(losses[-3:]).mean()) < 0.7 * float(torch.stack(losses[:3]).mean())
+    assert p1 > p0 + 2.0, (p0, p1)
+    assert all(torch.isfinite(p).all() for p in model.parameters()) and not fr.overflowed()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "point_cloud", "iteration_90", "point_cloud.ply")
+        save_ply(model, path)
+        again = load_ply(path, sh_degree=1)
+    assert abs(psnr_now(again) - p1) < 1e-4
