@@ -114,3 +114,18 @@ def test_permutation_equivariance_1m():
     g = _forward(m2, cam, bg, W, H)
     assert g["n"] == f["n"] and torch.equal(g["radii"], f["radii"][perm])
     assert float((g["color"] - f["color"]).abs().max()) < 2e-5
+
+
+def test_config1_100k_gaussians_800x600_forward_backward_vs_oracle():
+    """BASELINE.json configs[1]: 100k Gaussians, one 800x600 camera, forward + backward on the MI355X against the
+    oracle: tile / bin indices bit-exact, images within 2e-5 (a handful of 1/255-rule flips allowed over 480k
+    pixels), gradients within 2e-4 relative L2."""
+    from helpers import rel_l2, small_scene
+    from test_gpu_parity import _backward_both, _check_forward, _run_hip_forward
+    d, _ = small_scene(P=100_000, W=800, H=600, seed=5, scale_mu=0.03, near_frac=0.02)
+    st, ref, got = _backward_both(d, seed=5)
+    assert st.N > 300_000
+    _check_forward(d, st, _run_hip_forward(d), flip_frac=2e-5)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        e = rel_l2(got[k].cpu().numpy(), ref[k])
+        assert e <= 2e-4, f"{k}: rel L2 {e:.3e}"
