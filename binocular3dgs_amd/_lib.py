@@ -100,7 +100,8 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_debug_views", "b3gs_forward_raw", "b3gs_backward_raw", "b3gs_backward_scratch_floats",
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
            "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss",
-           "b3gs_densify_classify", "b3gs_densify_scatter", "b3gs_knn_workspace_bytes", "b3gs_knn_mean_dist2")
+           "b3gs_densify_classify", "b3gs_densify_scatter", "b3gs_knn_workspace_bytes", "b3gs_knn_mean_dist2",
+           "b3gs_backward_raw_accumulate_range")
 
 _lib = None
 
@@ -156,6 +157,10 @@ def lib():
                                                C.POINTER(B3gsRawGrads), C.c_int32, C.POINTER(B3gsDensifyStats),
                                                C.c_void_p]
     L.b3gs_backward_raw_accumulate.restype = C.c_int
+    L.b3gs_backward_raw_accumulate_range.argtypes = [C.c_int32, C.POINTER(B3gsFusedView), C.POINTER(B3gsRawParams),
+                                                     C.POINTER(B3gsRawGrads), C.c_int32, C.POINTER(B3gsDensifyStats),
+                                                     C.c_int32, C.c_int32, C.c_void_p]
+    L.b3gs_backward_raw_accumulate_range.restype = C.c_int
     L.b3gs_forward_raw_batch.argtypes = [C.c_int32, C.POINTER(B3gsForwardView), C.POINTER(B3gsRawParams), C.c_int,
                                          C.c_void_p]
     L.b3gs_forward_raw_batch.restype = C.c_int
@@ -174,7 +179,7 @@ def lib():
     L.b3gs_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_knn_mean_dist2.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_int32, C.c_void_p]
+                                 C.c_float, C.c_int32, C.c_int32, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int

@@ -540,12 +540,20 @@ int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_s
 int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
                                  const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
                                  b3gs_stream_t stream) {
+  const int32_t P = (nviews > 0 && views && views[0].view) ? views[0].view->P : 0;
+  return b3gs_backward_raw_accumulate_range(nviews, views, params, grads, overwrite, stats, 0, P, stream);
+}
+
+int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
+                                       const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
+                                       int32_t first, int32_t count, b3gs_stream_t stream) {
   if (nviews <= 0 || nviews > B3GS_MAX_FUSED_VIEWS || !views || !params || !grads)
     return fail(B3GS_ERR_ARG, "%s", "bad view count / NULL argument (at most 8 views per call)");
   const B3gsScene* v0 = views[0].view;
   int rc = check_raw(v0, params);
   if (rc) return rc;
-  if (v0->P == 0) return B3GS_OK;
+  if (v0->P == 0 || count == 0) return B3GS_OK;
+  if (first < 0 || count < 0 || (int64_t)first + count > v0->P) return fail(B3GS_ERR_ARG, "%s", "bad Gaussian range");
   if (!grads->xyz || !grads->features_dc || (v0->M > 1 && !grads->features_rest) || !grads->scaling ||
       !grads->rotation || !grads->opacity)
     return fail(B3GS_ERR_ARG, "%s", "NULL gradient buffer");
@@ -566,7 +574,7 @@ int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, con
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, stats, s);
+  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, stats, first, count, s);
   tm.mark(4);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;

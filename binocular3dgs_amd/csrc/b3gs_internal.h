@@ -247,4 +247,5 @@ struct B3gsViewRef {
   int32_t densify_stats;
 };
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
-                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s);
+                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, int first, int count,
+                                  hipStream_t s);

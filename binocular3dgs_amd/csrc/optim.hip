@@ -57,7 +57,8 @@ __global__ void bump_step(int32_t* step_ptr) { *step_ptr += 1; }
 }  // namespace
 
 extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
-                              float eps, float opacity_decay, int32_t opacity_segment, b3gs_stream_t stream) {
+                              float eps, float opacity_decay, int32_t opacity_segment, int32_t bump_step_after,
+                              b3gs_stream_t stream) {
   if (nseg <= 0 || nseg > 8 || !segs || !device_step) return B3GS_ERR_ARG;
   AdamSegs a;
   a.n = nseg;
@@ -76,6 +77,6 @@ extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t
   const unsigned blocks = (unsigned)((tot + 255) / 256 < 256u * 32u ? (tot + 255) / 256 : 256u * 32u);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, a, device_step, beta1, beta2, eps, opacity_decay,
                      opacity_segment);
-  hipLaunchKernelGGL(bump_step, dim3(1), dim3(1), 0, s, device_step);
+  if (bump_step_after) hipLaunchKernelGGL(bump_step, dim3(1), dim3(1), 0, s, device_step);
   return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
 }

@@ -668,10 +668,11 @@ struct MultiViews {
 #define B3GS_ACC_WAVES 3   /* 168 VGPRs (40 B spilled) beats 182 VGPRs at 2 waves per SIMD: 0.060 -> 0.053 ms per view */
 #endif
 __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
-    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite,
-                            B3gsDensifyStats ds) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= base.P) return;
+    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
+                            int count, B3gsDensifyStats ds) {
+  // Gaussians [first, first + count): every pointer is indexed by the GLOBAL Gaussian index
+  const int i = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= first + count) return;
   const size_t i3 = 3 * (size_t)i;
   SceneX sx_;
   sx_.sc = base;
@@ -809,14 +810,15 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
 }
 
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
-                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, hipStream_t s) {
-  if (base.P <= 0 || nviews <= 0) return;
+                                  const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, int first, int count,
+                                  hipStream_t s) {
+  if (base.P <= 0 || nviews <= 0 || count <= 0) return;
   MultiViews mv;
   mv.n = nviews;
   for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
   const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(accumulate_views_kernel, dim3((base.P + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite,
-                     ds);
+  hipLaunchKernelGGL(accumulate_views_kernel, dim3((count + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite,
+                     first, count, ds);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

@@ -227,9 +227,12 @@ class FusedRasterizer:
         else:
             self._accumulate(pend, overwrite=False)
 
-    def _accumulate(self, pend, overwrite: bool):
+    def _accumulate(self, pend, overwrite: bool, grads=None, first: int = 0, count: Optional[int] = None):
+        """grads: a B3gsRawGrads whose pointers are indexed by the global Gaussian index (default: the parameters'
+        .grad); [first, first+count): the Gaussians to process (default: all)."""
         L, m = _lib.lib(), self.model
-        gr = self._bind_grads()
+        gr = grads if grads is not None else self._bind_grads()
+        count = self.P - first if count is None else count
         stats = None
         if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
             stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr())
@@ -244,10 +247,10 @@ class FusedRasterizer:
                 arr[k].scratch = sl.scratch.data_ptr()
                 arr[k].dL_dmeans2D = None if sl.means2D_grad is None else sl.means2D_grad.data_ptr()
                 arr[k].densify_stats = int(bool(sp["densify_stats"]) and stats is not None)
-            rc = L.b3gs_backward_raw_accumulate(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
-                                                int(bool(overwrite) and c0 == 0),
-                                                None if stats is None else C.byref(stats), stream)
-            _lib.check(rc, "b3gs_backward_raw_accumulate")
+            rc = L.b3gs_backward_raw_accumulate_range(len(chunk), arr, C.byref(self._bind_params()), C.byref(gr),
+                                                      int(bool(overwrite) and c0 == 0),
+                                                      None if stats is None else C.byref(stats), first, count, stream)
+            _lib.check(rc, "b3gs_backward_raw_accumulate_range")
 
     # ---- public -----------------------------------------------------------------------------
     def render(self, viewpoint_camera, bg_color: torch.Tensor, slot: int = 0, scaling_modifier: float = 1.0,
@@ -279,6 +282,18 @@ class FusedRasterizer:
         """Open a section in which backward passes only run the blend backward (per-view scratch);
         finish_deferred() then does the per-Gaussian chain rule of ALL their views in one kernel."""
         self._deferred = []
+
+    def take_deferred(self):
+        """Close the deferred section WITHOUT running the chain rule and return the recorded views, for
+        accumulate_range() (the list stays valid for replays of a HIP graph that captured the section)."""
+        pend, self._deferred = self._deferred, None
+        return pend
+
+    def accumulate_range(self, pend, grads, first: int, count: int, overwrite: bool = True):
+        """Per-Gaussian chain rule of the views in `pend` (from take_deferred()) for the Gaussians
+        [first, first+count) only, into `grads` (B3gsRawGrads, pointers indexed by the global Gaussian index).
+        Call it for disjoint ranges covering all Gaussians."""
+        self._accumulate(pend, overwrite, grads, first, count)
 
     def finish_deferred(self, overwrite: bool = True):
         """overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them."""

@@ -85,19 +85,26 @@ class FusedAdam:
         self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
 
     def step(self):
+        P = self.params[0].shape[0]
+        self.step_rows(0, P, [p.grad.data_ptr() for p in self.params], last=True)
+
+    def step_rows(self, first: int, count: int, grad_ptrs: Sequence[int], last: bool):
+        """Adam for rows [first, first+count) of every tensor (row = one Gaussian); grad_ptrs[k] is the address of
+        the gradient of row `first` of tensor k (rows contiguous).  The step counter advances when `last`."""
         C, _lib = self._C, self._lib
         segs = (_lib.B3gsAdamSegment * len(self.params))()
         off = 0
         for k, (p, lr) in enumerate(zip(self.params, self.lrs)):
-            assert p.grad is not None and p.is_contiguous() and p.grad.is_contiguous()
-            segs[k].param, segs[k].grad = p.data_ptr(), p.grad.data_ptr()
-            segs[k].exp_avg = self.exp_avg.data_ptr() + 4 * off
-            segs[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * off
-            segs[k].count, segs[k].lr = p.numel(), lr
+            assert p.is_contiguous()
+            w = p.numel() // max(p.shape[0], 1)
+            segs[k].param, segs[k].grad = p.data_ptr() + 4 * w * first, grad_ptrs[k]
+            segs[k].exp_avg = self.exp_avg.data_ptr() + 4 * (off + w * first)
+            segs[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * (off + w * first)
+            segs[k].count, segs[k].lr = w * count, lr
             off += p.numel()
         dev = self.params[0].device
         rc = _lib.lib().b3gs_adam_step(len(self.params), segs, self.step_count.data_ptr(), self.betas[0], self.betas[1],
-                                       self.eps, self.opacity_decay, self.opacity_index,
+                                       self.eps, self.opacity_decay, self.opacity_index, int(bool(last)),
                                        torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(rc, "b3gs_adam_step")
 
@@ -105,6 +112,47 @@ class FusedAdam:
         for p in self.params:
             if p.grad is not None:
                 p.grad.zero_()
+
+
+class RangeGradSlab:
+    """Gradient buffer laid out RANGE-major for the pipelined data-parallel tail: the Gaussians are cut into K
+    index ranges and all six tensors' gradients of a range are contiguous, so one all-reduce per range can start
+    as soon as that range's chain rule is done, while the next range is still being computed:
+        [range 0: xyz | f_dc | f_rest | scaling | rotation | opacity][range 1: ...] ..."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], num_ranges: int):
+        self.params = list(params)
+        self.P = self.params[0].shape[0]
+        self.widths = [p.numel() // max(self.P, 1) for p in self.params]
+        self.K = max(1, min(int(num_ranges), max(self.P, 1)))
+        self.bounds = [(r * self.P) // self.K for r in range(self.K + 1)]
+        self.row = sum(self.widths)
+        self.flat = torch.zeros(self.row * self.P, dtype=torch.float32, device=self.params[0].device)
+
+    def rows(self, r: int):
+        return self.bounds[r], self.bounds[r + 1] - self.bounds[r]
+
+    def chunk(self, r: int) -> torch.Tensor:
+        s, n = self.rows(r)
+        return self.flat[self.row * s: self.row * (s + n)]
+
+    def grad_ptrs(self, r: int) -> List[int]:
+        """address of the first row of range r for each tensor"""
+        s, n = self.rows(r)
+        base, out, acc = self.flat.data_ptr() + 4 * self.row * s, [], 0
+        for w in self.widths:
+            out.append(base + 4 * n * acc)
+            acc += w
+        return out
+
+    def tensor_view(self, r: int, k: int) -> torch.Tensor:
+        s, n = self.rows(r)
+        off = self.row * s + n * sum(self.widths[:k])
+        return self.flat[off: off + n * self.widths[k]].view((n,) + tuple(self.params[k].shape[1:]))
+
+    def gather(self) -> List[torch.Tensor]:
+        """the gradients as ordinary per-parameter tensors (tests / inspection)"""
+        return [torch.cat([self.tensor_view(r, k) for r in range(self.K)], dim=0) for k in range(len(self.params))]
 
 
 def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
@@ -122,7 +170,7 @@ class ViewShardedStep:
     """
 
     def __init__(self, model, pairs, bg: torch.Tensor, pipe: Optional[PipelineParams] = None, optimizer=None,
-                 average_over_world: bool = False, render_fn: Callable = render, fused=None):
+                 average_over_world: bool = False, render_fn: Callable = render, fused=None, pipeline_ranges: int = 0):
         self.model = model
         self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]
         self.bg = bg
@@ -137,6 +185,12 @@ class ViewShardedStep:
             assert len(fused.slots) >= 2 * len(self.pairs), "FusedRasterizer needs one slot per view of the step"
         self.render = render_fn
         self.last_stats = {}
+        # Pipelined data-parallel tail (fused path + FusedAdam): compute_grads() stops after the blend backward;
+        # reduce_and_update() then walks K Gaussian ranges -- chain rule of range r+1 overlaps the all-reduce of
+        # range r, Adam of range r overlaps the all-reduce of range r+1 -- instead of accumulate -> all-reduce ->
+        # Adam back to back (the all-reduce of 92 B/Gaussian is ~20 % of an iteration on 8 GPUs).
+        self.pipeline_ranges = int(pipeline_ranges) if (fused is not None and isinstance(optimizer, FusedAdam)) else 0
+        self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges > 1 else None
 
     def step(self, pair_grad_fn=None, loss_fn=None):
         n = self.compute_grads(pair_grad_fn, loss_fn)
@@ -145,6 +199,8 @@ class ViewShardedStep:
 
     def reduce_and_update(self):
         """The exchange step of the data-parallel path (one all-reduce of the flat slab) + optimiser."""
+        if self.range_slab is not None:
+            return self._reduce_and_update_pipelined()
         self.slab.all_reduce(self.average)
         if self.optimizer is not None:
             self.slab.rebind()
@@ -160,9 +216,32 @@ class ViewShardedStep:
         newP = densify_and_prune(self.model, self.optimizer, max_grad, min_opacity, extent, max_screen_size,
                                  percent_dense, noise, generator)
         self.slab = FlatGradSlab(self.model.parameters())
+        if self.range_slab is not None:
+            self.range_slab = RangeGradSlab(self.model.parameters(), self.pipeline_ranges)
         if self.fused is not None:
             self.fused.resize()
         return newP
+
+    def _reduce_and_update_pipelined(self, group=None):
+        from . import _lib
+        rs, fr, opt = self.range_slab, self.fused, self.optimizer
+        collective = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.slab.force_collective)
+        works = []
+        for r in range(rs.K):
+            first, count = rs.rows(r)
+            gr = _lib.B3gsRawGrads()
+            for name, ptr, w in zip(("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"),
+                                    rs.grad_ptrs(r), rs.widths):
+                setattr(gr, name, (ptr - 4 * w * first) if w else None)     # indexed by the GLOBAL Gaussian index
+            fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True)
+            works.append(dist.all_reduce(rs.chunk(r), op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None)
+        for r in range(rs.K):
+            if works[r] is not None:
+                works[r].wait()                     # the compute stream waits for that range's all-reduce only
+            if self.average and collective:
+                rs.chunk(r).div_(dist.get_world_size(group))
+            first, count = rs.rows(r)
+            opt.step_rows(first, count, rs.grad_ptrs(r), last=(r == rs.K - 1))
 
     def sync_densify_stats(self, group=None):
         """Make the densification statistics identical on every replica before a densify/prune decision
@@ -225,5 +304,8 @@ class ViewShardedStep:
             total.backward()
         else:
             torch.autograd.backward(outs, grads)
-        self.fused.finish_deferred(overwrite=True)
+        if self.range_slab is None:
+            self.fused.finish_deferred(overwrite=True)
+        else:   # reduce_and_update() runs the chain rule range by range
+            self._pending_views = self.fused.take_deferred()
         return len(views)

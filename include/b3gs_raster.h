@@ -222,12 +222,20 @@ typedef struct B3gsDensifyStats {
 int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
                                  const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
                                  b3gs_stream_t stream);
+/* The same for the Gaussians [first, first + count) only.  Every pointer (parameters, gradients, statistics,
+ * per-view state) is still indexed by the GLOBAL Gaussian index, so a caller that keeps the gradients of a range
+ * in one contiguous block passes block_base - first * row_width.  Disjoint ranges issued back to back let the
+ * gradient all-reduce of one range overlap the chain rule of the next (step.ViewShardedStep, data parallel). */
+int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
+                                       const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
+                                       int32_t first, int32_t count, b3gs_stream_t stream);
 
 /* ---- fused optimiser step -----------------------------------------------------------
  * Adam exactly as torch.optim.Adam (no amsgrad, no weight decay) for up to 8 parameter tensors with their
  * own learning rates in ONE launch: the reference's six parameter groups (scene/gaussian_model.py:154-167,
  * eps = 1e-15) and optimizer.step() at train.py:196-198.  `device_step` (int32 on the device, incremented
- * by the call) keeps the bias correction replayable from a HIP graph.  opacity_decay > 0 additionally
+ * by the call unless bump_step_after == 0: a step issued as several calls over disjoint slices -- the pipelined
+ * data-parallel tail -- bumps on the last one) keeps the bias correction replayable from a HIP graph.  opacity_decay > 0 additionally
  * applies  o <- logit(sigmoid(o) * opacity_decay)  to segment `opacity_segment` after its update
  * (gaussian_model.py:307-309, train.py:171-173). */
 typedef struct B3gsAdamSegment {
@@ -239,7 +247,8 @@ typedef struct B3gsAdamSegment {
   float lr;
 } B3gsAdamSegment;
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
-                   float eps, float opacity_decay, int32_t opacity_segment, b3gs_stream_t stream);
+                   float eps, float opacity_decay, int32_t opacity_segment, int32_t bump_step_after,
+                   b3gs_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------------------
  * Value and pixel gradients of the per-pair training loss of train.py:123-148 in 4 launches:

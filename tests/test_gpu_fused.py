@@ -219,3 +219,34 @@ def test_fused_adam_matches_torch_adam_and_opacity_decay():
     torch.cuda.synchronize()
     s = torch.sigmoid(before) * 0.995
     assert float((b[5] - torch.log(s / (1 - s))).abs().max()) < 1e-5
+
+
+def test_pipelined_data_parallel_tail_equals_the_plain_tail():
+    """Chain rule / all-reduce / Adam walked over Gaussian ranges (range-major gradient slab, the 8-GPU tail) must
+    give the parameters and gradients of the plain accumulate -> all-reduce -> Adam sequence."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam, ViewShardedStep
+    W, H = 160, 120
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    fn = lambda i, pkg, spkg: [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]  # noqa: E731
+    res = []
+    for K in (0, 3, 7):
+        model, pairs, bg = _setup(P=10007, W=W, H=H)
+        model.init_densification_stats()
+        opt = FusedAdam(model.parameters(), [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05], eps=1e-15)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, pipeline_ranges=K)
+        assert (st.range_slab is not None) == (K > 1)
+        for _ in range(3):
+            st.step(pair_grad_fn=fn)
+        torch.cuda.synchronize()
+        grads = st.range_slab.gather() if K > 1 else [p.grad.clone() for p in model.parameters()]
+        res.append(([p.detach().clone() for p in model.parameters()], grads, int(opt.step_count.item()), model.denom.clone()))
+    for params, grads, steps, denom in res[1:]:
+        assert steps == res[0][2] == 3
+        assert torch.equal(denom, res[0][3])
+        for a, b in zip(grads, res[0][1]):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        for a, b in zip(params, res[0][0]):
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
