@@ -332,7 +332,7 @@ def main():
                               "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only: the other ranks would wait ~7 s at the barrier
             out["cpu_baseline"] = cpu_baseline(P, W, H, args.seed)
         result_line = json.dumps(out)
     if dp:
