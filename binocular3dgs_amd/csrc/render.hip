@@ -13,10 +13,14 @@
 //    quadrant's masks with scalar bit ops (s_ff1/s_flbit) -- ballot compaction without moving data.
 //    The footprint test is conservative, so the per-pixel arithmetic, skip rules and
 //    n_contrib are exactly those of the sequential algorithm (oracle/tile_ref.c).
+//    An exact test (minimum of the quadratic form over the quadrant's pixel rectangle vs ln(255 opacity)) follows
+//    the bounding-box test: every candidate it removes saves a 64-lane evaluation in each direction.
 //  * record fields are read from LDS with broadcast ds_read_b128 (all lanes, one address)
-//  * backward: lanes hold per-pixel partials; a 4-step DPP reduction folds each 16-lane row, rows and
-//    the four quadrant waves merge in LDS (ds_add_f32) and each (tile, Gaussian) issues ONE set of
-//    global atomics instead of one per pixel
+//  * backward: lanes hold per-pixel partials of 10 gradient components; they are transposed through a per-wave
+//    LDS scratch (ds_write_addtid_b32 rows, 4 x ds_read_b128 per lane, 15 adds + 2 quad DPP) and each (quadrant,
+//    Gaussian) issues ONE 10-lane global_atomic_add_f32 onto one 48-byte scratch row (details at the kernel)
+//  * one launch covers all views of a training iteration (BlendBatch): ~11k tiles pack the 256 CUs, one view's
+//    1900 tiles would fill them once and pay their own tail
 //  * workgroup -> tile map keeps raster-adjacent tiles (which share Gaussians) on one XCD's L2
 #include "b3gs_internal.h"
 #include <cstdlib>
@@ -58,16 +62,6 @@ __device__ __forceinline__ float dpp_add(float v) {
   int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
   return v + __int_as_float(t);
 }
-// sum within each row of 16 lanes (4 DPP steps, each folds into one v_add_f32_dpp); afterwards
-// EVERY lane holds its row's sum, so one lane per row (4 per wave) carries a partial total
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);  // row_mirror
-  return v;
-}
-
 // CHUNK = Gaussians staged per round (a multiple of 64, at most the 256 threads of the workgroup)
 template <int CHUNK>
 struct TileShared {
@@ -247,18 +241,19 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
 // backward
 // ---------------------------------------------------------------------------------------------
 // ---- backward -------------------------------------------------------------------------------
-// Cross-lane reduction is THE cost of this kernel: on gfx950 a DPP add issues at ~8 cycles per wave
-// (tools/ubench/valu_rate.hip: v_add_f32_dpp 8 cyc, v_permlane32_swap 8, plain fma/mul/min 2), so
-// the textbook 6-step butterfly over 10 gradient components costs ~480 cycles per Gaussian -- more
-// than twice the per-pixel arithmetic.  The partials are therefore TRANSPOSED THROUGH LDS instead:
-//   10 x ds_write_b32   row k of a per-wave [10][68]-float scratch <- component k of every lane
-//    4 x ds_read_b128   lane (k,part) = (lane>>2, lane&3) reads elements [16 part, 16 part+16) of
-//                       row k  (row stride 68 dwords: the 16-lane groups of ds_read_b128 hit 64
-//                       distinct banks, and the row writes are conflict free)
+// Cross-lane reduction is what this kernel is organised around: on gfx950 (tools/ubench/valu_rate.hip) a plain
+// fp32 VALU op issues at ~2 cycles per wave64 instruction, v_pk_*_f32 at ~4 (packing buys nothing), v_add_f32_dpp,
+// v_permlane32_swap, v_exp and v_rcp at ~8, so the textbook 6-step butterfly over 10 gradient components costs
+// ~480 cycles per Gaussian -- more than twice the per-pixel arithmetic.  The partials are TRANSPOSED THROUGH LDS:
+//   10 x ds_write_addtid_b32  row k of a per-wave [10][68]-float scratch <- component k of every lane
+//                             (address = M0 + offset + 4*lane: no address VGPR, half the LDS-path cycles of ds_write_b32)
+//    4 x ds_read_b128         lane (k,part) = (lane>>2, lane&3) reads elements [16 part, 16 part+16) of row k
+//                             (row stride 68 dwords: the 16-lane groups of ds_read_b128 hit 64 distinct banks)
 //   15 plain adds + 2 quad DPP adds -> lanes 4k..4k+3 hold component k summed over the 64 pixels
-//    1 x global_atomic_add_f32 with 10 active lanes (lane 4k adds component k of this Gaussian)
-// i.e. ~60 LDS-pipe clocks and ~70 VALU cycles per Gaussian instead of ~480 VALU cycles, and no
-// accumulator tile, no second barrier phase: LDS holds only the staged chunk + 2.7 KB per wave.
+//    1 x global_atomic_add_f32 with 10 active lanes onto ONE 48-byte scratch row of this Gaussian
+// Measured ablations: without the atomic the kernel ran 26 % faster while its 10 lanes went to four separate
+// arrays; on one row the atomic is free.  PMC: VALU busy 66 % of all SIMD cycles (incl. the tail), i.e. the
+// kernel is VALU/issue bound; trimming 15 % of the VALU instructions bought 1-2 %.
 constexpr int RED_STRIDE = 68;
 #ifndef B3GS_BWD_WAVES
 #define B3GS_BWD_WAVES 5  /* waves per SIMD the register allocator must leave room for */
