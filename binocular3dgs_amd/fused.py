@@ -1,5 +1,5 @@
 """Fast path of the build's own training step: fused activations, persistent scratch, no host sync,
-the views of an iteration binned concurrently and blended in ONE launch.
+every stage of the forward and of the backward ONE launch for all views of an iteration.
 
 `FusedRasterizer.render_batch()` returns, per view, the same dict as the drop-in `render()`
 (render.py / gaussian_renderer/__init__.py:97-103) but goes through the raw-parameter entry points of
@@ -9,9 +9,10 @@ include/b3gs_raster.h:
   * geometry / binning / image state lives in persistent per-slot buffers sized once (288 GB of HBM
     make over-allocation free), N stays on the device: zero allocations and zero host syncs per
     view, so a whole iteration can be captured in one HIP graph (torch.cuda.graph);
-  * forward: projection + binning of every view on its own HIP stream (the binning kernels are a few
-    hundred workgroups each and leave most of the 256 CUs idle), then ONE blend launch for all
-    views (b3gs_blend_forward_batch);
+  * forward: ONE b3gs_forward_raw_batch for all views (a single view's binning kernels are a few hundred
+    workgroups each and leave most of the 256 CUs idle): multi-view projection, batched radix / scan / emit /
+    blend launches, one depth sort per binocular pair (schedule="batched"; "streams" = one HIP stream per
+    view and "serial" are kept for A/B);
   * backward: ONE blend-backward launch for all views (b3gs_blend_backward_batch, per-view scratch),
     then ONE pass over the Gaussians for all views (b3gs_backward_raw_accumulate): gradients are
     stored (or accumulated) straight into the `.grad` views of the flat slab, together with the
