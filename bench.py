@@ -158,6 +158,15 @@ def main():
                                             unit_grad=True, **kw)
             return binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i], **kw)[0]
         step_kw = dict(loss_fn=loss_fn)
+        if args.loss == "fused":
+            from binocular3dgs_amd.fused_loss import binocular_loss_fused_batch
+
+            def batch_loss_fn(items):
+                return binocular_loss_fused_batch(
+                    [dict(image=pkg["render"], depth=pkg["rendered_depth"], alpha=pkg["rendered_alpha"], gt_image=gts[i],
+                          shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t,
+                          bg_mask=bgm[i]) for i, cam, pkg, spkg, t in items], unit_grad=True)
+            step_kw = dict(batch_loss_fn=batch_loss_fn)
 
     def barrier():
         torch.cuda.synchronize(dev)

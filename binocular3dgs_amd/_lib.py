@@ -101,7 +101,7 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
            "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss",
            "b3gs_densify_classify", "b3gs_densify_scatter", "b3gs_knn_workspace_bytes", "b3gs_knn_mean_dist2",
-           "b3gs_backward_raw_accumulate_range")
+           "b3gs_backward_raw_accumulate_range", "b3gs_binocular_loss_batch")
 
 _lib = None
 
@@ -168,6 +168,8 @@ def lib():
     L.b3gs_loss_workspace_floats.restype = C.c_size_t
     L.b3gs_binocular_loss.argtypes = [C.POINTER(B3gsLossIO), C.c_void_p]
     L.b3gs_binocular_loss.restype = C.c_int
+    L.b3gs_binocular_loss_batch.argtypes = [C.c_int32, C.POINTER(B3gsLossIO), C.c_void_p]
+    L.b3gs_binocular_loss_batch.restype = C.c_int
     L.b3gs_densify_classify.argtypes = [C.POINTER(B3gsDensifyIO), C.c_void_p, C.c_void_p]
     L.b3gs_densify_classify.restype = C.c_int
     L.b3gs_densify_scatter.argtypes = [C.POINTER(B3gsDensifyIO), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

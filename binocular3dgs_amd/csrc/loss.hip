@@ -29,6 +29,32 @@ __device__ __forceinline__ void add_sum(float* sums, int q, float v) {
 }
 struct Win { float w[11]; };
 
+// one (input view, shifted view) pair; every kernel takes up to B3GS_MAX_FUSED_VIEWS pairs per launch (blockIdx.z)
+struct PairArgs {
+  int W, H;
+  const float* image;
+  const float* gt;
+  const float* depth;
+  const float* alpha;
+  const float* shifted;       // null: no binocular term
+  const float* alpha_weight;  // null: no alpha term
+  float k_disp;               // focal_x * (-trans_dist)
+  float cS, cL1;              // -lambda_dssim*scale/(3HW), (1-lambda_dssim)*scale/(3HW)
+  float c_l1m, c_smooth, c_alpha;   // scale/(3HW), lambda_smooth*scale/((H-2)(W-2)), scale/HW
+  float lambda_dssim, lambda_smooth;
+  float* sums;                // [8 * SLOTS]
+  float* maps;                // [9 * HW]
+  float* dL_dimage;
+  float* dL_ddepth;
+  float* dL_dalpha;
+  float* dL_dshifted;         // zero on entry (atomics)
+  float* parts;
+};
+struct LossBatch {
+  int n;
+  PairArgs p[B3GS_MAX_FUSED_VIEWS];
+};
+
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
 __device__ __forceinline__ float block_sum_256(float v, float* tmp) {
@@ -42,16 +68,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* tmp) {
 }
 
 // sums[0] += sum |x-y|, sums[1] += sum ssim_map; maps: dS/dmu1, dS/dE[x^2], dS/dE[xy] per channel
-__global__ void __launch_bounds__(256) ssim_stats_kernel(int W, int H, const float* __restrict__ img,
-                                                         const float* __restrict__ gt, Win win, float* __restrict__ sums,
-                                                         float* __restrict__ maps) {
+__global__ void __launch_bounds__(256) ssim_stats_kernel(LossBatch lb, Win win) {
   __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
   __shared__ float hq[5][LW][LT];
   __shared__ float red[4];
-  const int ch = blockIdx.z;
+  const PairArgs& a = lb.p[blockIdx.z / 3];
+  const int ch = blockIdx.z % 3;
+  const int W = a.W, H = a.H;
+  if ((int)blockIdx.x * LT >= W || (int)blockIdx.y * LT >= H) return;   // grid sized for the largest pair
+  float* __restrict__ sums = a.sums;
+  float* __restrict__ maps = a.maps;
   const size_t hw = (size_t)H * W;
-  const float* __restrict__ x = img + ch * hw;
-  const float* __restrict__ y = gt + ch * hw;
+  const float* __restrict__ x = a.image + ch * hw;
+  const float* __restrict__ y = a.gt + ch * hw;
   const int tid = threadIdx.y * LT + threadIdx.x;
   const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
   for (int i = tid; i < LW * LW; i += 256) {
@@ -104,13 +133,18 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(int W, int H, const flo
 }
 
 // dL/dimage = cS * (w*dmu1 + 2x (w*de11) + y (w*de12)) + cL1 * sign(x - y)
-__global__ void __launch_bounds__(256) ssim_grad_kernel(int W, int H, const float* __restrict__ img,
-                                                        const float* __restrict__ gt, Win win,
-                                                        const float* __restrict__ maps, float cS, float cL1,
-                                                        float* __restrict__ dL_dimage) {
+__global__ void __launch_bounds__(256) ssim_grad_kernel(LossBatch lb, Win win) {
   __shared__ float sm[3][LW][LW + 1];
   __shared__ float hq[3][LW][LT];
-  const int ch = blockIdx.z;
+  const PairArgs& a = lb.p[blockIdx.z / 3];
+  const int ch = blockIdx.z % 3;
+  const int W = a.W, H = a.H;
+  if ((int)blockIdx.x * LT >= W || (int)blockIdx.y * LT >= H) return;
+  const float* __restrict__ img = a.image;
+  const float* __restrict__ gt = a.gt;
+  const float* __restrict__ maps = a.maps;
+  float* __restrict__ dL_dimage = a.dL_dimage;
+  const float cS = a.cS, cL1 = a.cL1;
   const size_t hw = (size_t)H * W;
   const int tid = threadIdx.y * LT + threadIdx.x;
   const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
@@ -147,24 +181,10 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(int W, int H, const floa
   dL_dimage[ch * hw + p] = cS * (g0 + 2.f * xv * g1 + yv * g2) + cL1 * sgn(xv - yv);
 }
 
-struct BinoArgs {
-  int W, H;
-  const float* depth;
-  const float* alpha;
-  const float* gt;
-  const float* shifted;       // null: no binocular term
-  const float* alpha_weight;  // null: no alpha term
-  float k_disp;               // focal_x * (-trans_dist)
-  float c_l1m, c_smooth, c_alpha;   // scale / (3HW), lambda_smooth*scale / ((H-2)(W-2)), scale / HW
-  float* sums;
-  float* dL_ddepth;
-  float* dL_dalpha;
-  float* dL_dshifted;         // zero on entry (atomics)
-};
 
 struct Disp { float d, m; };
 // disparity of pixel (r,c) and its warp-mask value ((x1-d)+(d-x0) where both taps are inside, else 0)
-__device__ __forceinline__ Disp disparity_at(const BinoArgs& a, int r, int c) {
+__device__ __forceinline__ Disp disparity_at(const PairArgs& a, int r, int c) {
   Disp o;
   o.d = 0.f; o.m = 0.f;
   if (r < 0 || r >= a.H || c < 0 || c >= a.W) return o;
@@ -178,7 +198,9 @@ __device__ __forceinline__ Disp disparity_at(const BinoArgs& a, int r, int c) {
   return o;
 }
 
-__global__ void __launch_bounds__(256) binocular_kernel(BinoArgs a) {
+__global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
+  const PairArgs& a = lb.p[blockIdx.z];
+  if ((int)blockIdx.x * LT >= a.W || (int)blockIdx.y * LT >= a.H) return;
   constexpr int HAL = 2, TW = LT + 2 * HAL;
   __shared__ float sD[TW][TW + 1];   // disparity * mask with a halo of 2
   __shared__ float red[4];
@@ -281,8 +303,12 @@ __global__ void __launch_bounds__(256) binocular_kernel(BinoArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(64) loss_finalize_kernel(const float* __restrict__ slots, int W, int H, float lambda_dssim,
-                                                           float lambda_smooth, int has_shift, float* __restrict__ parts) {
+__global__ void __launch_bounds__(64) loss_finalize_kernel(LossBatch lb) {
+  const PairArgs& a = lb.p[blockIdx.x];
+  const float* __restrict__ slots = a.sums;
+  const int W = a.W, H = a.H, has_shift = a.shifted != nullptr;
+  const float lambda_dssim = a.lambda_dssim, lambda_smooth = a.lambda_smooth;
+  float* __restrict__ parts = a.parts;
   float sums[8];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
@@ -309,40 +335,52 @@ extern "C" size_t b3gs_loss_workspace_floats(int32_t W, int32_t H) {
 }
 
 extern "C" int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream) {
-  if (!io || io->W <= 0 || io->H <= 0 || !io->image || !io->depth || !io->alpha || !io->gt_image || !io->dL_dimage ||
-      !io->dL_ddepth || !io->dL_dalpha || !io->parts || !io->workspace || (io->shifted_image && !io->dL_dshifted))
-    return B3GS_ERR_ARG;
+  return b3gs_binocular_loss_batch(1, io, stream);
+}
+
+extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, b3gs_stream_t stream) {
+  if (npairs <= 0 || npairs > B3GS_MAX_FUSED_VIEWS || !ios) return B3GS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int W = io->W, H = io->H;
-  const size_t hw = (size_t)W * H;
-  float* sums = io->workspace;
-  float* maps = io->workspace + 8 * SLOTS;
   // window exactly as utils/loss_utils.py:23-26: double exp -> float tensor -> normalised in float
   Win win;
   float g[11], tot = 0.f;
   for (int k = 0; k < 11; k++) { g[k] = (float)std::exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); tot += g[k]; }
   for (int k = 0; k < 11; k++) win.w[k] = g[k] / tot;
-  const float scale = io->grad_scale;
-  (void)hipMemsetAsync(sums, 0, 8 * SLOTS * sizeof(float), s);
-  if (io->shifted_image) (void)hipMemsetAsync(io->dL_dshifted, 0, 3 * hw * sizeof(float), s);
-  const dim3 blk(LT, LT), grid3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), grid1((W + LT - 1) / LT, (H + LT - 1) / LT, 1);
-  hipLaunchKernelGGL(ssim_stats_kernel, grid3, blk, 0, s, W, H, io->image, io->gt_image, win, sums, maps);
-  hipLaunchKernelGGL(ssim_grad_kernel, grid3, blk, 0, s, W, H, io->image, io->gt_image, win, maps,
-                     -io->lambda_dssim * scale / (3.f * (float)hw), (1.f - io->lambda_dssim) * scale / (3.f * (float)hw),
-                     io->dL_dimage);
-  BinoArgs a;
-  a.W = W; a.H = H;
-  a.depth = io->depth; a.alpha = io->alpha; a.gt = io->gt_image; a.shifted = io->shifted_image;
-  a.alpha_weight = io->alpha_weight;
-  a.k_disp = io->focal_x * (-io->trans_dist);
-  a.c_l1m = scale / (3.f * (float)hw);
-  const float inner = (float)(H - 2) * (float)(W - 2);
-  a.c_smooth = inner > 0.f ? io->lambda_smooth * scale / inner : 0.f;
-  a.c_alpha = scale / (float)hw;
-  a.sums = sums;
-  a.dL_ddepth = io->dL_ddepth; a.dL_dalpha = io->dL_dalpha; a.dL_dshifted = io->dL_dshifted;
-  hipLaunchKernelGGL(binocular_kernel, grid1, blk, 0, s, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(SLOTS), 0, s, sums, W, H, io->lambda_dssim, io->lambda_smooth,
-                     io->shifted_image ? 1 : 0, io->parts);
+  LossBatch lb;
+  lb.n = npairs;
+  int gx = 0, gy = 0;
+  for (int k = 0; k < npairs; k++) {
+    const B3gsLossIO* io = ios + k;
+    if (io->W <= 0 || io->H <= 0 || !io->image || !io->depth || !io->alpha || !io->gt_image || !io->dL_dimage ||
+        !io->dL_ddepth || !io->dL_dalpha || !io->parts || !io->workspace || (io->shifted_image && !io->dL_dshifted))
+      return B3GS_ERR_ARG;
+    const int W = io->W, H = io->H;
+    const size_t hw = (size_t)W * H;
+    const float scale = io->grad_scale, inner = (float)(H - 2) * (float)(W - 2);
+    PairArgs& a = lb.p[k];
+    a.W = W; a.H = H;
+    a.image = io->image; a.gt = io->gt_image; a.depth = io->depth; a.alpha = io->alpha;
+    a.shifted = io->shifted_image; a.alpha_weight = io->alpha_weight;
+    a.k_disp = io->focal_x * (-io->trans_dist);
+    a.cS = -io->lambda_dssim * scale / (3.f * (float)hw);
+    a.cL1 = (1.f - io->lambda_dssim) * scale / (3.f * (float)hw);
+    a.c_l1m = scale / (3.f * (float)hw);
+    a.c_smooth = inner > 0.f ? io->lambda_smooth * scale / inner : 0.f;
+    a.c_alpha = scale / (float)hw;
+    a.lambda_dssim = io->lambda_dssim; a.lambda_smooth = io->lambda_smooth;
+    a.sums = io->workspace;
+    a.maps = io->workspace + 8 * SLOTS;
+    a.dL_dimage = io->dL_dimage; a.dL_ddepth = io->dL_ddepth; a.dL_dalpha = io->dL_dalpha; a.dL_dshifted = io->dL_dshifted;
+    a.parts = io->parts;
+    (void)hipMemsetAsync(a.sums, 0, 8 * SLOTS * sizeof(float), s);
+    if (io->shifted_image) (void)hipMemsetAsync(io->dL_dshifted, 0, 3 * hw * sizeof(float), s);
+    gx = (W + LT - 1) / LT > gx ? (W + LT - 1) / LT : gx;
+    gy = (H + LT - 1) / LT > gy ? (H + LT - 1) / LT : gy;
+  }
+  const dim3 blk(LT, LT);
+  hipLaunchKernelGGL(ssim_stats_kernel, dim3(gx, gy, 3 * npairs), blk, 0, s, lb, win);
+  hipLaunchKernelGGL(ssim_grad_kernel, dim3(gx, gy, 3 * npairs), blk, 0, s, lb, win);
+  hipLaunchKernelGGL(binocular_kernel, dim3(gx, gy, npairs), blk, 0, s, lb);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(npairs), dim3(SLOTS), 0, s, lb);
   return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
 }

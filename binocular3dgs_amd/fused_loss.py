@@ -87,3 +87,72 @@ def binocular_loss_fused(image, depth, alpha, gt_image, *, lambda_dssim: float =
     total, parts = _BinocularLoss.apply(image, depth, alpha, shifted_image, gt_image, aw, focal_x, trans_dist,
                                         lambda_dssim, lambda_smooth, int(slot), unit_grad, bool(return_parts))
     return (total, parts) if return_parts else total
+
+
+class _BinocularLossBatch(torch.autograd.Function):
+    """All pairs of an iteration in one call: inputs (image, depth, alpha, shifted) x npairs, output = sum of the
+    pair losses (+ the per-pair parts [npairs, 8], non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, meta, unit_grad, *tensors):
+        n = len(meta)
+        L = _lib.lib()
+        ios = (_lib.B3gsLossIO * n)()
+        bufs, keep, has_shift = [], [], []
+        dev = tensors[0].device
+        for k, m in enumerate(meta):
+            image, depth, alpha, shifted = tensors[4 * k: 4 * k + 4]
+            H, W = image.shape[-2:]
+            buf = _Workspace.get(dev, W, H, m["slot"])
+            cont = [t.contiguous() for t in (image, depth, alpha, m["gt"])]
+            sh = None if shifted is None else shifted.contiguous()
+            aw = None if m["alpha_weight"] is None else m["alpha_weight"].contiguous()
+            keep += cont + [sh, aw]
+            io = ios[k]
+            io.W, io.H = W, H
+            io.image, io.depth, io.alpha, io.gt_image = (t.data_ptr() for t in cont)
+            io.shifted_image = None if sh is None else sh.data_ptr()
+            io.alpha_weight = None if aw is None else aw.data_ptr()
+            io.focal_x, io.trans_dist = float(m["focal_x"] or 0.0), float(m["trans_dist"] or 0.0)
+            io.lambda_dssim, io.lambda_smooth, io.grad_scale = float(m["lambda_dssim"]), float(m["lambda_smooth"]), 1.0
+            io.dL_dimage, io.dL_ddepth, io.dL_dalpha = buf["g_image"].data_ptr(), buf["g_depth"].data_ptr(), buf["g_alpha"].data_ptr()
+            io.dL_dshifted = buf["g_shifted"].data_ptr()
+            io.parts, io.workspace = buf["parts"].data_ptr(), buf["ws"].data_ptr()
+            bufs.append(buf)
+            has_shift.append(sh is not None)
+        rc = L.b3gs_binocular_loss_batch(n, ios, torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "b3gs_binocular_loss_batch")
+        del keep
+        ctx.bufs, ctx.has_shift, ctx.unit_grad = bufs, has_shift, bool(unit_grad)
+        parts = torch.stack([b["parts"] for b in bufs])
+        ctx.mark_non_differentiable(parts)
+        return parts[:, 0].sum(), parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        out = []
+        for b, hs in zip(ctx.bufs, ctx.has_shift):
+            gs = [b["g_image"], b["g_depth"], b["g_alpha"], b["g_shifted"] if hs else None]
+            if not ctx.unit_grad:
+                gs = [None if g is None else g * g_total for g in gs]
+            out += gs
+        return (None, None) + tuple(out)
+
+
+def binocular_loss_fused_batch(pairs, lambda_dssim: float = 0.2, lambda_smooth: float = 0.05, unit_grad: bool = False,
+                               return_parts: bool = False):
+    """Sum of binocular_loss_fused over `pairs` with one launch per stage for all of them.  pairs: list of dicts with
+    keys image, depth, alpha, gt_image and optionally shifted_image, focal_x, trans_dist, gt_alpha_mask | bg_mask.
+    Pair k uses gradient-buffer slot k."""
+    meta, tensors = [], []
+    for k, p in enumerate(pairs):
+        aw = None
+        if p.get("gt_alpha_mask") is not None:
+            aw = 1.0 - p["gt_alpha_mask"]
+        elif p.get("bg_mask") is not None:
+            aw = p["bg_mask"]
+        meta.append(dict(gt=p["gt_image"], alpha_weight=aw, focal_x=p.get("focal_x"), trans_dist=p.get("trans_dist"),
+                         lambda_dssim=p.get("lambda_dssim", lambda_dssim), lambda_smooth=lambda_smooth, slot=k))
+        tensors += [p["image"], p["depth"], p["alpha"], p.get("shifted_image")]
+    total, parts = _BinocularLossBatch.apply(meta, unit_grad, *tensors)
+    return (total, parts) if return_parts else total

@@ -192,8 +192,10 @@ class ViewShardedStep:
         self.pipeline_ranges = int(pipeline_ranges) if (fused is not None and isinstance(optimizer, FusedAdam)) else 0
         self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges > 1 else None
 
-    def step(self, pair_grad_fn=None, loss_fn=None):
-        n = self.compute_grads(pair_grad_fn, loss_fn)
+    def step(self, pair_grad_fn=None, loss_fn=None, batch_loss_fn=None):
+        """batch_loss_fn([(pair_index, camera, pkg, shifted_pkg, trans_dist), ...]) -> scalar: all pairs' loss in one
+        call (fused path only; e.g. fused_loss.binocular_loss_fused_batch)."""
+        n = self.compute_grads(pair_grad_fn, loss_fn, batch_loss_fn)
         self.reduce_and_update()
         return n
 
@@ -254,14 +256,15 @@ class ViewShardedStep:
         dist.all_reduce(m.denom, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, group=group)
 
-    def compute_grads(self, pair_grad_fn=None, loss_fn=None):
+    def compute_grads(self, pair_grad_fn=None, loss_fn=None, batch_loss_fn=None):
         """Render this rank's views forward+backward; leaves the summed gradients in the slab.  Contains
         no collective, no host sync and (fused path) no allocation: capturable as one HIP graph."""
-        assert (pair_grad_fn is None) != (loss_fn is None)
+        assert sum(f is not None for f in (pair_grad_fn, loss_fn, batch_loss_fn)) == 1
+        assert batch_loss_fn is None or self.fused is not None
         if self.fused is not None:
             # the fused multi-view accumulate STORES the gradients: no zero-fill of the slab
             self.slab.rebind()
-            n_rendered = self._step_fused(pair_grad_fn, loss_fn)
+            n_rendered = self._step_fused(pair_grad_fn, loss_fn, batch_loss_fn)
         else:
             self.slab.zero()
             n_rendered = 0
@@ -277,7 +280,7 @@ class ViewShardedStep:
         self.last_stats = {"views": n_rendered}
         return n_rendered
 
-    def _step_fused(self, pair_grad_fn, loss_fn):
+    def _step_fused(self, pair_grad_fn, loss_fn, batch_loss_fn=None):
         """All views of the step in one render_batch() (binning concurrent, one blend launch), the loss /
         upstream gradients of every pair formed on the current stream, ONE backward call (one blend-
         backward launch for all views), then one per-Gaussian pass for all views (finish_deferred)."""
@@ -290,6 +293,17 @@ class ViewShardedStep:
         self.fused.begin_deferred()
         pkgs = iter(self.fused.render_batch(views, self.bg))
         outs, grads, total = [], [], None
+        if batch_loss_fn is not None:
+            items = []
+            for i, (cam, scam, t) in enumerate(self.pairs):
+                pkg = next(pkgs)
+                items.append((i, cam, pkg, next(pkgs) if scam is not None else None, t))
+            batch_loss_fn(items).backward()
+            if self.range_slab is None:
+                self.fused.finish_deferred(overwrite=True)
+            else:
+                self._pending_views = self.fused.take_deferred()
+            return len(views)
         for i, (cam, scam, t) in enumerate(self.pairs):
             pkg = next(pkgs)
             spkg = next(pkgs) if scam is not None else None

@@ -278,6 +278,8 @@ typedef struct B3gsLossIO {
 } B3gsLossIO;
 size_t b3gs_loss_workspace_floats(int32_t W, int32_t H);
 int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream);
+/* The same for up to 8 pairs (ios[0..npairs)) with ONE launch per stage: the images of one pair are ~1900 tiles. */
+int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, b3gs_stream_t stream);
 
 /* ---- densify / clone / split / prune ------------------------------------------------------
  * Net effect of the reference's densify_and_prune (scene/gaussian_model.py:393-407 with :258-391) including the

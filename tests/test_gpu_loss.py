@@ -86,3 +86,34 @@ def test_unit_grad_shortcut_and_slots_are_independent():
     binocular_loss_fused(x, dp[1].detach(), al[1].detach(), gts[1], shifted_image=sh[1].detach(), focal_x=40.0,
                          trans_dist=0.3, slot=7).backward()
     assert torch.allclose(x.grad, ims[1].grad, rtol=1e-5, atol=1e-10)
+
+
+def test_batched_pairs_equal_single_pair_calls():
+    from binocular3dgs_amd.fused_loss import binocular_loss_fused, binocular_loss_fused_batch
+    gen = torch.Generator().manual_seed(11)
+    H, W = 72, 100
+    mk = lambda *s: torch.rand(*s, generator=gen).cuda()  # noqa: E731
+    pairs = []
+    for k in range(3):
+        pairs.append(dict(image=mk(3, H, W), depth=2 + 5 * mk(1, H, W), alpha=mk(1, H, W), gt_image=mk(3, H, W),
+                          shifted_image=None if k == 1 else mk(3, H, W), focal_x=70.0, trans_dist=0.3 - 0.25 * k,
+                          bg_mask=(mk(1, H, W) > 0.5).float() if k != 2 else None))
+    names = ("image", "depth", "alpha", "shifted_image")
+    res = []
+    for batched in (False, True):
+        ps = [{k: (v.clone().requires_grad_(True) if k in names and v is not None else v) for k, v in p.items()} for p in pairs]
+        if batched:
+            total, parts = binocular_loss_fused_batch(ps, return_parts=True)
+        else:
+            total = sum(binocular_loss_fused(p["image"], p["depth"], p["alpha"], p["gt_image"], shifted_image=p["shifted_image"],
+                                             focal_x=p["focal_x"], trans_dist=p["trans_dist"], bg_mask=p["bg_mask"], slot=k)
+                        for k, p in enumerate(ps))
+        (1.5 * total).backward()
+        res.append((float(total), [[None if p[n] is None or p[n].grad is None else p[n].grad.clone() for n in names] for p in ps]))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
+    for ga, gb in zip(res[0][1], res[1][1]):
+        for a, b in zip(ga, gb):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-10)
+    assert parts.shape == (3, 8) and float(parts[1, 3]) == 0.0      # pair 1 has no binocular term
