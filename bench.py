@@ -270,6 +270,14 @@ def main():
         pkg = render(pairs[0][0], model, PipelineParams(), bg)
         V = int((pkg["radii"] > 0).sum().item())
     n_views = max(timed_views, 1)
+    # (pixel, Gaussian) pairs the sequential algorithm visits: sum over pixels of the position of their last
+    # contributor (n_contrib) -- the work unit of the blend kernels (they are not HBM bound)
+    pairs_per_view = None
+    if fused is not None:
+        from binocular3dgs_amd.debug import state_views
+        s0 = fused.slots[0]
+        n0 = fused.num_rendered()[0]
+        pairs_per_view = int(state_views(P, W, H, n0, s0.geom, s0.binning, s0.img)["n_contrib"].to(torch.int64).sum().item())
     # N: read back from one more forward through the C ABI surface
     from binocular3dgs_amd import _C
     with torch.no_grad():
@@ -334,7 +342,10 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "bytes_per_launch": dom_bytes * vpl,
                          "avg_launch_ms": round(single[dom] * vpl, 4), "views_per_launch": vpl,
-                         "note": "blend kernels are VALU/LDS-bound (SURVEY 8d caveat); see pixgauss_evals_per_s"},
+                         "note": "blend kernels are VALU-bound (SURVEY 8d caveat): see pixgauss_pairs_per_s",
+                         "pixgauss_pairs_per_view": pairs_per_view,
+                         "pixgauss_pairs_per_s": (None if not pairs_per_view or ms["render_bwd"] <= 0
+                                                  else round(pairs_per_view / (ms["render_bwd"] / 1e3), 1))},
             "roofline_view": {"bound": "hbm", "bytes_per_view": R + Wt, "read_bytes_per_view": R,
                               "kernel_ms_per_view": round(view_ms, 4),
                               "achieved": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
