@@ -282,15 +282,17 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_hist(SortBatch sb, in
   const int shift = pass_shift + job.shift_base;
   const uint32_t* __restrict__ keys = job.kin;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
+  const uint32_t base = blockIdx.x * B3GS_SORT_TILE;
+  // The grid is sized by the CAPACITY (n lives on the device); workgroups past n write nothing -- the digit-major
+  // store below is 256 scattered 4-byte writes per workgroup, and row scan / scatter only look at the first
+  // ceil(n / tile) columns
+  if (base >= n) return;
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * B3GS_SORT_TILE;
-  if (base < n) {
 #pragma unroll
-    for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
-      uint32_t i = base + k * B3GS_SORT_THREADS + threadIdx.x;
-      if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
-    }
+  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+    uint32_t i = base + k * B3GS_SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
   }
   __syncthreads();
   job.hist[threadIdx.x * job.nblk + blockIdx.x] = h[threadIdx.x];
@@ -300,14 +302,16 @@ __global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
   __shared__ uint32_t tmp[8];
   const SortJob& job = sb.j[blockIdx.y];
   const uint32_t nblk = job.nblk;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
+  const uint32_t used = min(nblk, (n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);   // columns the histogram pass wrote
   uint32_t* row = job.hist + (size_t)blockIdx.x * nblk;
   uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
+  for (uint32_t b0 = 0; b0 < used; b0 += 256) {
     uint32_t i = b0 + threadIdx.x;
-    uint32_t v = i < nblk ? row[i] : 0u;
+    uint32_t v = i < used ? row[i] : 0u;
     uint32_t tot;
     uint32_t ex = block_excl_scan_256(v, tmp, &tot);
-    if (i < nblk) row[i] = carry + ex;
+    if (i < used) row[i] = carry + ex;
     carry += tot;
   }
   if (threadIdx.x == 0) job.hist[(size_t)256 * nblk + blockIdx.x] = carry;  // totals
