@@ -174,16 +174,20 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   if (range.y <= range.x) range = make_uint2(0u, 0u);  // empty tiles hold (0xFFFFFFFF, 0)
   const int nchunks = (int)((range.y - range.x + CHUNK - 1) / CHUNK);
 
-  bool done = !inside;
+  // A finished pixel is encoded as Tw == 0 (working transmittance): every later weight is then exactly zero, the
+  // saturation test fires again harmlessly, and "is anyone still active" is one compare -- no lane-mask
+  // bookkeeping (the mask logic cost ~30 scalar instructions per candidate on the CU's shared scalar unit).
+  // T holds the transmittance that is reported (the value before the Gaussian that saturated the pixel).
+  float Tw = inside ? 1.0f : 0.0f;
   float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f, Ac = 0.f;
   uint32_t last_contributor = 0;
 
   for (int c = 0; c < nchunks; c++) {
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(Tw == 0.0f)) break;
     stage_chunk(sh, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
     if (TRACE) n_chunks++;
-    if (__builtin_amdgcn_ballot_w64(!done) == 0) continue;  // this quadrant is finished; keep pace with the barriers
+    if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) continue;  // this quadrant is finished; keep pace with the barriers
 #pragma unroll 1
     for (int pw = 0; pw < CHUNK / 64; pw++) {
       u64 m = uniform_u64(sh.mask[w][pw]);
@@ -198,14 +202,13 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
         const float dx = A.x - fpx, dy = A.y - fpy;
         const float power = blend_power(A, B.x, dx, dy);
         const float alpha = fminf(B3GS_ALPHA_MAX, B.y * __expf(power));
-        // branch-free: a pixel this Gaussian does not touch (or a finished pixel) blends alpha = 0,
-        // which leaves T, the sums and last_contributor unchanged
-        const bool live = !done && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
-        const float test_T = T * (1.0f - (live ? alpha : 0.0f));
-        const bool stop = live && (test_T < B3GS_T_EPS);  // would saturate: not blended, pixel done
-        done = done || stop;
+        // branch-free: a pixel this Gaussian does not touch blends weight 0, which leaves T, the sums and
+        // last_contributor unchanged; so does a finished pixel (Tw == 0)
+        const bool live = !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN);
+        const float test_T = Tw * (1.0f - (live ? alpha : 0.0f));
+        const bool stop = test_T < B3GS_T_EPS;  // would saturate: not blended, pixel done (an active pixel has Tw >= eps)
         const bool blend = live && !stop;
-        const float wgt = blend ? alpha * T : 0.0f;
+        const float wgt = blend ? alpha * Tw : 0.0f;
         Cr = __builtin_fmaf(B.z, wgt, Cr);
         Cg = __builtin_fmaf(B.w, wgt, Cg);
         Cb = __builtin_fmaf(Cc.x, wgt, Cb);
@@ -213,9 +216,10 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
         Ac += wgt;
         T = blend ? test_T : T;
         last_contributor = blend ? (uint32_t)(c * CHUNK + gidx + 1) : last_contributor;
-        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        Tw = stop ? 0.0f : test_T;
+        if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
       }
-      if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+      if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
     }
   }
   if (inside) {
