@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   __shared__ uint32_t s_max_last[4];
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  unsigned n_iter = 0, n_live = 0;
+  unsigned n_iter = 0, n_live = 0, n_lanes = 0;
   const BlendView bv = select_view(batch, (int)blockIdx.x);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
   const uint2* __restrict__ ranges = bv.ranges;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
     if (TRACE) n_iter++;                                                                         \
     if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
-      if (TRACE) n_live++;                                                                       \
+      if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
       float p[10];                                                                               \
       bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);                                         \
       B3GS_ROW_WRITES(p);                                                                        \
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     t[0] = __builtin_readcyclecounter() - t_start;            // shader cycles this wave lived
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);  // 100 MHz wall clock: start | end
     t[2] = n_iter;
-    t[3] = n_live;
+    t[3] = (unsigned long long)n_live | ((unsigned long long)n_lanes << 32);   // live iterations | live lanes summed
   }
 }
 

@@ -31,7 +31,8 @@ t = t[t[:, 0] > 0]
 cyc = t[:, 0].astype(np.int64)
 rs = (t[:, 1] >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF
 re = (t[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-it, live = t[:, 2].astype(np.int64), t[:, 3].astype(np.int64)
+it, live = t[:, 2].astype(np.int64), (t[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+lanes = (t[:, 3] >> np.uint64(32)).astype(np.int64)
 t0 = rs.min()
 start_us, end_us = (rs - t0) / 100.0, (re - t0) / 100.0
 dur_us = end_us - start_us
@@ -42,4 +43,6 @@ for name, a in (("start_us", start_us), ("duration_us", dur_us), ("end_us", end_
 print("cycles per iteration per wave: p50 %.0f" % np.median(cyc / np.maximum(it, 1)))
 print("fraction of waves finished by 50%% / 75%% / 90%% of span: %.2f %.2f %.2f" % tuple((end_us < f * end_us.max()).mean() for f in (0.5, 0.75, 0.9)))
 print("fraction of waves started after 10 us: %.2f" % (start_us > 10).mean())
+if WHICH == "bwd":
+    print("live lanes per live iteration: mean %.1f of 64 (%.0f%% of the evaluated lanes)" % (lanes.sum() / max(live.sum(), 1), 100.0 * lanes.sum() / max(live.sum(), 1) / 64))
 print("corr(iters, duration) = %.3f" % np.corrcoef(it, dur_us)[0, 1])
