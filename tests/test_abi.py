@@ -68,3 +68,33 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libtile_ref" not in src, f
+
+
+def test_argument_errors_are_reported_without_touching_a_device():
+    """Every entry point validates its arguments before the first HIP call and returns B3GS_ERR_ARG (-1):
+    checkable on a machine without a GPU."""
+    from binocular3dgs_amd import _lib
+    L = _lib.lib()
+    ERR_ARG = -1
+    assert L.b3gs_binocular_loss(None, None) == ERR_ARG
+    assert L.b3gs_binocular_loss_batch(0, None, None) == ERR_ARG
+    io = _lib.B3gsLossIO()
+    io.W, io.H = 16, 16                                   # all image pointers NULL
+    assert L.b3gs_binocular_loss_batch(1, C.byref(io), None) == ERR_ARG
+    assert L.b3gs_binocular_loss_batch(9, C.byref(io), None) == ERR_ARG
+    assert L.b3gs_densify_classify(None, None, None) == ERR_ARG
+    dio = _lib.B3gsDensifyIO()
+    dio.P, dio.M = 5, 4                                   # parameters missing
+    assert L.b3gs_densify_classify(C.byref(dio), None, None) == ERR_ARG
+    assert L.b3gs_knn_mean_dist2(-1, None, None, None, None) == ERR_ARG
+    assert L.b3gs_knn_mean_dist2(10, None, None, None, None) == ERR_ARG
+    assert L.b3gs_knn_mean_dist2(0, None, None, None, None) == 0          # empty set: nothing to do
+    assert L.b3gs_adam_step(0, None, None, 0.9, 0.999, 1e-15, 0.0, -1, 1, None) == ERR_ARG
+    assert L.b3gs_forward_raw_batch(0, None, None, 3, None) == ERR_ARG
+    assert L.b3gs_forward_raw_batch(9, None, None, 3, None) == ERR_ARG
+    assert L.b3gs_backward_raw_accumulate_range(0, None, None, None, 1, None, 0, 0, None) == ERR_ARG
+    sc = _lib.B3gsScene()
+    sc.P, sc.W, sc.H = 1 << 24, 64, 64                    # too many Gaussians for the 24-bit row offsets
+    assert L.b3gs_forward_capacity(C.byref(sc), None, None, 0, None, None, None, None, None, None, None) == ERR_ARG
+    assert b"2^24" in L.b3gs_last_error()
+    assert L.b3gs_knn_workspace_bytes(1000) > 0 and L.b3gs_loss_workspace_floats(800, 600) == 8 * 64 + 9 * 800 * 600
