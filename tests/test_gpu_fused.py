@@ -250,3 +250,101 @@ def test_pipelined_data_parallel_tail_equals_the_plain_tail():
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
         for a, b in zip(params, res[0][0]):
             assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("P,W,H", [(1, 16, 16), (63, 16, 16), (65, 40, 24), (257, 200, 16), (1000, 16, 200), (3000, 33, 17)])
+def test_fused_batch_edge_sizes_match_dropin(P, W, H):
+    """Tiny Gaussian counts, a single tile (no tile-sort pass: tile_ranges kernel), one-tile-wide and one-tile-high
+    images, ragged borders: the batched fused path against the drop-in path, images and gradients."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.render import PipelineParams, render
+    model = synth.synth_model(P, seed=P, device="cuda", width=W, height=H)
+    with torch.no_grad():
+        model._scaling += 1.0
+    pairs = synth.synth_view_set(W, H, device="cuda")
+    bg = torch.tensor([0.2, 0.1, 0.0], device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=2, device="cuda")
+    views = [pairs[0][0], pairs[0][1], pairs[1][0]]
+    ref_imgs, ref_grads = [], None
+    for p in model.parameters():
+        p.grad = None
+    for cam in views:
+        pkg = render(cam, model, PipelineParams(), bg)
+        torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+        ref_imgs.append([pkg[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha")])
+    ref_grads = [p.grad.clone() for p in model.parameters()]
+    for p in model.parameters():
+        p.grad = None
+    fr = FusedRasterizer(model, W, H, num_slots=3)
+    outs = fr.render_batch([(c, k) for k, c in enumerate(views)], bg)
+    flat_o, flat_g = [], []
+    for o in outs:
+        flat_o += [o["render"], o["rendered_depth"], o["rendered_alpha"]]
+        flat_g += [gc, gd, ga]
+    torch.autograd.backward(flat_o, flat_g)
+    torch.cuda.synchronize()
+    assert not fr.overflowed()
+    for o, r in zip(outs, ref_imgs):
+        for k, t in zip(("render", "rendered_depth", "rendered_alpha"), r):
+            assert float((o[k] - t).abs().max()) <= 2e-5 * (1 + float(t.abs().max())), k
+    for p, r in zip(model.parameters(), ref_grads):
+        if float(r.abs().max()) == 0:
+            assert float(p.grad.abs().max()) == 0
+        else:
+            assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 2e-4
+
+
+def test_views_of_different_tile_sort_depth_in_one_forward_batch():
+    """b3gs_forward_raw_batch with W x H that need a different number of tile-sort passes (the launcher then bins the
+    views one by one): same results as two single-view forwards."""
+    import ctypes as C
+    import math
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.camera import Camera, look_at_orbit
+    P = 4000
+    model = synth.synth_model(P, seed=4, device="cuda", width=64, height=48)
+    L = _lib.lib()
+    rp = _lib.B3gsRawParams()
+    rp.xyz, rp.features_dc, rp.features_rest = model._xyz.data_ptr(), model._features_dc.data_ptr(), model._features_rest.data_ptr()
+    rp.scaling, rp.rotation, rp.opacity = model._scaling.data_ptr(), model._rotation.data_ptr(), model._opacity.data_ptr()
+    bg = torch.zeros(3, device="cuda")
+    sizes = [(16, 16), (320, 240)]            # 1 tile (0 passes) and 300 tiles (2 passes)
+    K = model._features_dc.shape[1] + model._features_rest.shape[1]
+
+    def make(W, H):
+        R, T = look_at_orbit(2.0)
+        fovx = math.radians(60.0)
+        cam = Camera(R, T, fovx, synth.fovy_from(fovx, W, H), W, H, device="cuda")
+        sc = _lib.B3gsScene(P, 1, K, W, H, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), 1.0, 0, 0, bg.data_ptr(), None, None,
+                            None, None, None, None, None, cam.world_view_transform.data_ptr(),
+                            cam.full_proj_transform.data_ptr(), cam.camera_center.data_ptr())
+        u8 = dict(dtype=torch.uint8, device="cuda")
+        bufs = dict(geom=torch.empty(L.b3gs_geometry_bytes(P), **u8), binning=torch.empty(L.b3gs_binning_bytes(P, 200000), **u8),
+                    img=torch.empty(L.b3gs_image_bytes(W, H), **u8), color=torch.empty(3, H, W, device="cuda"),
+                    depth=torch.empty(1, H, W, device="cuda"), alpha=torch.empty(1, H, W, device="cuda"),
+                    radii=torch.zeros(P, dtype=torch.int32, device="cuda"), n=torch.zeros(1, dtype=torch.int32, device="cuda"))
+        return cam, sc, bufs
+
+    res = {}
+    for mode in ("single", "batch"):
+        items = [make(W, H) for W, H in sizes]
+        arr = (_lib.B3gsForwardView * len(items))()
+        for k, (_cam, sc, b) in enumerate(items):
+            arr[k].view = C.pointer(sc)
+            arr[k].geometry, arr[k].binning, arr[k].image = b["geom"].data_ptr(), b["binning"].data_ptr(), b["img"].data_ptr()
+            arr[k].binning_capacity = 200000
+            arr[k].out_color, arr[k].out_depth, arr[k].out_alpha = b["color"].data_ptr(), b["depth"].data_ptr(), b["alpha"].data_ptr()
+            arr[k].radii, arr[k].device_num_rendered, arr[k].depth_order_from = b["radii"].data_ptr(), b["n"].data_ptr(), -1
+        stream = torch.cuda.current_stream().cuda_stream
+        if mode == "batch":
+            _lib.check(L.b3gs_forward_raw_batch(len(items), arr, C.byref(rp), 3, stream), "batch")
+        else:
+            for k in range(len(items)):
+                one = (_lib.B3gsForwardView * 1)(arr[k])
+                _lib.check(L.b3gs_forward_raw_batch(1, one, C.byref(rp), 3, stream), "single")
+        torch.cuda.synchronize()
+        res[mode] = [(int(b["n"].item()), b["color"].clone(), b["radii"].clone()) for _c, _s, b in items]
+    for a, b in zip(res["single"], res["batch"]):
+        assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert res["batch"][1][0] > 0
