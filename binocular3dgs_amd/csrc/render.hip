@@ -277,11 +277,12 @@ struct BwdPixel {
 // Per-pixel reverse step for one Gaussian; writes this lane's 10 partial gradients to p[].
 // Branch-free: a lane the Gaussian does not touch uses alpha = G = 0, which leaves T and the
 // "behind" composites unchanged and makes every partial an exact zero.
+// dx, dy and the products u = cxx dx, v = cyy dy, nw = -cxy dx come from the evaluation of the exponent.
 __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const float4& B, float col_b, float depth,
-                                         float G, float alpha, bool live, float (&p)[10]) {
+                                         float dx, float dy, float u, float v, float nw, float G, float alpha, bool live,
+                                         float (&p)[10]) {
   G = live ? G : 0.0f;
   alpha = live ? alpha : 0.0f;
-  const float dx = A.x - px.fpx, dy = A.y - px.fpy;
   // 1/(1-alpha): hardware reciprocal (1 ulp); alpha <= 0.99 keeps it well conditioned
   const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
   px.T = px.T * inv_one_m_a;
@@ -302,14 +303,15 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   }
   dL_da = dL_da * px.T;
   dL_da = __builtin_fmaf(-px.T_final * inv_one_m_a, px.bg_dot, dL_da);
-  const float dL_dG = B.y * dL_da;
-  const float gdx = G * dx, gdy = G * dy;
-  p[0] = dL_dG * (-gdx * A.z - gdy * A.w) * px.half_w;
-  p[1] = dL_dG * (-gdy * B.x - gdx * A.w) * px.half_h;
-  const float hx = -0.5f * gdx * dL_dG, hy = -0.5f * gdy * dL_dG;
-  p[2] = hx * dx;
-  p[3] = hx * dy;
-  p[4] = hy * dy;
+  // s = dL/d(exponent): mean gets -s Q d (scaled to NDC units), the conic entries -0.5 s d d^T
+  const float s = G * (B.y * dL_da);
+  p[0] = (s * px.half_w) * -__builtin_fmaf(A.w, dy, u);   // -(cxx dx + cxy dy)
+  p[1] = (s * px.half_h) * (nw - v);                       // -(cyy dy + cxy dx)
+  const float sh = -0.5f * s;
+  const float shx = sh * dx;
+  p[2] = shx * dx;
+  p[3] = shx * dy;
+  p[4] = (sh * dy) * dy;
   p[5] = G * dL_da;
   p[6] = wgt * px.dCr;
   p[7] = wgt * px.dCg;
@@ -430,7 +432,10 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
 #define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
   do {                                                                                           \
-    const float power = blend_power(A, B.x, A.x - px.fpx, A.y - px.fpy);                         \
+    const float dx_ = A.x - px.fpx, dy_ = A.y - px.fpy;                                          \
+    const float u_ = A.z * dx_, v_ = B.x * dy_, nw_ = -A.w * dx_;                                \
+    /* == blend_power(): same products, same order (the forward must agree on every skip decision) */ \
+    const float power = __builtin_fmaf(nw_, dy_, -0.5f * __builtin_fmaf(v_, dy_, u_ * dx_));     \
     const float G = __expf(power);                                                               \
     const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);                                          \
     const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
@@ -438,7 +443,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
       if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
       float p[10];                                                                               \
-      bwd_eval(px, A, B, Cc.x, Cc.y, G, alpha, live, p);                                         \
+      bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
       B3GS_ROW_WRITES(p);                                                                        \
       if (pending) B3GS_RETIRE_PENDING();                                                        \
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
