@@ -270,7 +270,7 @@ struct TileSharedBwd {
 };
 
 struct BwdPixel {
-  float fpx, fpy, T, T_final, bg_dot, dCr, dCg, dCb, dD, dA, Br, Bg, Bb, Bd, Ba, half_w, half_h;
+  float fpx, fpy, T, T_final, bg_dot, dCr, dCg, dCb, dD, dA, Bw, half_w, half_h;
   uint32_t last;
 };
 
@@ -287,21 +287,18 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   const float inv_one_m_a = __builtin_amdgcn_rcpf(1.0f - alpha);
   px.T = px.T * inv_one_m_a;
   const float wgt = alpha * px.T;
-  const float dr = B.z - px.Br, dg = B.w - px.Bg, db = col_b - px.Bb;
-  float dL_da = dr * px.dCr;
-  dL_da = __builtin_fmaf(dg, px.dCg, dL_da);
-  dL_da = __builtin_fmaf(db, px.dCb, dL_da);
-  px.Br = __builtin_fmaf(alpha, dr, px.Br);
-  px.Bg = __builtin_fmaf(alpha, dg, px.Bg);
-  px.Bb = __builtin_fmaf(alpha, db, px.Bb);
-  {
-    const float dd = depth - px.Bd, da = 1.0f - px.Ba;
-    dL_da = __builtin_fmaf(dd, px.dD, dL_da);
-    dL_da = __builtin_fmaf(da, px.dA, dL_da);
-    px.Bd = __builtin_fmaf(alpha, dd, px.Bd);
-    px.Ba = __builtin_fmaf(alpha, da, px.Ba);
-  }
-  dL_da = dL_da * px.T;
+  // dL/dalpha = T * sum_ch (c_ch - behind_ch) dL/dpixel_ch over the five output channels (r, g, b, depth, alpha).
+  // The composite behind the current Gaussian only ever enters through that dot product, and its update
+  // behind' = behind + alpha (c - behind) is linear, so ONE scalar Bw = sum_ch behind_ch dL/dpixel_ch is carried
+  // instead of five channels.
+  float cw = B.z * px.dCr;
+  cw = __builtin_fmaf(B.w, px.dCg, cw);
+  cw = __builtin_fmaf(col_b, px.dCb, cw);
+  cw = __builtin_fmaf(depth, px.dD, cw);
+  cw += px.dA;
+  const float diff = cw - px.Bw;
+  px.Bw = __builtin_fmaf(alpha, diff, px.Bw);
+  float dL_da = diff * px.T;
   dL_da = __builtin_fmaf(-px.T_final * inv_one_m_a, px.bg_dot, dL_da);
   // s = dL/d(exponent): mean gets -s Q d (scaled to NDC units), the conic entries -0.5 s d d^T
   const float s = G * (B.y * dL_da);
@@ -373,7 +370,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   }
   px.bg_dot = (bg[0] * px.dCr + bg[1] * px.dCg) + bg[2] * px.dCb;
   px.T = px.T_final;
-  px.Br = px.Bg = px.Bb = px.Bd = px.Ba = 0.f;  // composite "behind" the current Gaussian
+  px.Bw = 0.f;  // composite "behind" the current Gaussian, dotted with the pixel gradients
 
   // deepest list position any pixel of the quadrant / tile used
   {
