@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   } while (0)
 
   // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
-#define B3GS_BWD_CANDIDATE(A, B, SC, J)                                                          \
+#define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
   do {                                                                                           \
     const float dx_ = A.x - px.fpx, dy_ = A.y - px.fpy;                                          \
     const float u_ = A.z * dx_, v_ = B.x * dy_, nw_ = -A.w * dx_;                                \
@@ -439,7 +439,6 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     if (TRACE) n_iter++;                                                                         \
     if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
       if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
-      const float4 Cc = SC[J];   /* b, depth, Gaussian index: only a live candidate needs them */  \
       float p[10];                                                                               \
       bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
       B3GS_ROW_WRITES(p);                                                                        \
@@ -494,20 +493,20 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       const float4* const sA = sh.f.A + pw * 64;
       const float4* const sB = sh.f.B + pw * 64;
       const float4* const sC = sh.f.C + pw * 64;
-      float4 A0 = sA[j], B0 = sB[j], A1, B1;
+      float4 A0 = sA[j], B0 = sB[j], C0 = sC[j], A1, B1, C1;
       while (true) {
         bool more = m != 0;
         int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
         m &= ~(1ull << jn);
-        A1 = sA[jn]; B1 = sB[jn];
-        B3GS_BWD_CANDIDATE(A0, B0, sC, j);
+        A1 = sA[jn]; B1 = sB[jn]; C1 = sC[jn];
+        B3GS_BWD_CANDIDATE(A0, B0, C0, j);
         if (!more) break;
         j = jn;
         more = m != 0;
         jn = more ? 63 - __builtin_clzll(m) : j;
         m &= ~(1ull << jn);
-        A0 = sA[jn]; B0 = sB[jn];
-        B3GS_BWD_CANDIDATE(A1, B1, sC, j);
+        A0 = sA[jn]; B0 = sB[jn]; C0 = sC[jn];
+        B3GS_BWD_CANDIDATE(A1, B1, C1, j);
         if (!more) break;
         j = jn;
       }
