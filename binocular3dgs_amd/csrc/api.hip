@@ -371,9 +371,9 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   return B3GS_OK;
 }
 
-// Raw-mode scratch: one row of B3GS_SCRATCH_ROW floats (48 bytes) per Gaussian -- conic xx, xy, yy, depth |
-// mean2D x, y | colour r, g, b | opacity | 2 pad -- so the 10-lane atomic of the blend backward lands on one
-// row (one or two cache lines) instead of four arrays, and the per-Gaussian pass reads three float4.
+// Raw-mode scratch: one row of B3GS_SCRATCH_ROW floats (40 bytes) per Gaussian -- conic xx, xy, yy, depth |
+// mean2D x, y | colour r, g, b | opacity -- so the 10-lane atomic of the blend backward lands on one
+// row (one or two cache lines) instead of four arrays, and the per-Gaussian pass reads five float2.
 size_t b3gs_backward_scratch_floats(int32_t P) { return (size_t)B3GS_SCRATCH_ROW * (size_t)(P > 0 ? P : 0); }
 
 int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const int32_t* radii, const char* geometry,

@@ -138,7 +138,7 @@ struct SceneX {
 };
 
 #define B3GS_MAX_FUSED_VIEWS 8
-#define B3GS_SCRATCH_ROW 12   /* floats per Gaussian in the raw-mode backward scratch (api.hip) */
+#define B3GS_SCRATCH_ROW 10   /* floats per Gaussian in the raw-mode backward scratch (api.hip) */
 
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)

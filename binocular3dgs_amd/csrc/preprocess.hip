@@ -325,19 +325,19 @@ struct PixSums {
   float gdepth, gcol[3], gop;
 };
 
-// Raw-mode scratch row (B3GS_SCRATCH_ROW = 12 floats): conic xx, xy, yy, depth | mean2D x, y | colour r, g, b |
-// opacity | 2 pad.  Returns the sums and leaves the row zero (the scratch is persistent: no per-view memset).
+// Raw-mode scratch row (B3GS_SCRATCH_ROW = 10 floats, 40 bytes, no padding: 8-byte aligned, five float2): conic xx,
+// xy, yy, depth | mean2D x, y | colour r, g, b | opacity.  Returns the sums and leaves the row zero (the scratch is persistent: no per-view memset).
 __device__ __forceinline__ PixSums load_scratch_row(float* scratch, int i) {
-  static_assert(B3GS_SCRATCH_ROW == 12, "three float4 per row");
-  float4* row = reinterpret_cast<float4*>(scratch) + 3 * (size_t)i;
-  const float4 r0 = row[0], r1 = row[1], r2 = row[2];
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  row[0] = z; row[1] = z; row[2] = z;
+  static_assert(B3GS_SCRATCH_ROW == 10, "five float2 per row");
+  float2* row = reinterpret_cast<float2*>(scratch) + 5 * (size_t)i;
+  const float2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+  const float2 z = make_float2(0.f, 0.f);
+  row[0] = z; row[1] = z; row[2] = z; row[3] = z; row[4] = z;
   PixSums in;
-  in.gxx = r0.x; in.gxy = r0.y; in.gyy = r0.z; in.gdepth = r0.w;
-  in.g2x = r1.x; in.g2y = r1.y;
-  in.gcol[0] = r1.z; in.gcol[1] = r1.w; in.gcol[2] = r2.x;
-  in.gop = r2.y;
+  in.gxx = r0.x; in.gxy = r0.y; in.gyy = r1.x; in.gdepth = r1.y;
+  in.g2x = r2.x; in.g2y = r2.y;
+  in.gcol[0] = r3.x; in.gcol[1] = r3.y; in.gcol[2] = r4.x;
+  in.gop = r4.y;
   return in;
 }
 // gradients w.r.t. the (activated) rasterizer inputs of one Gaussian

@@ -18,7 +18,7 @@
 //  * record fields are read from LDS with broadcast ds_read_b128 (all lanes, one address)
 //  * backward: lanes hold per-pixel partials of 10 gradient components; they are transposed through a per-wave
 //    LDS scratch (ds_write_addtid_b32 rows, 4 x ds_read_b128 per lane, 15 adds + 2 quad DPP) and each (quadrant,
-//    Gaussian) issues ONE 10-lane global_atomic_add_f32 onto one 48-byte scratch row (details at the kernel)
+//    Gaussian) issues ONE 10-lane global_atomic_add_f32 onto one 40-byte scratch row (details at the kernel)
 //  * one launch covers all views of a training iteration (BlendBatch): ~11k tiles pack the 256 CUs, one view's
 //    1900 tiles would fill them once and pay their own tail
 //  * workgroup -> tile map keeps raster-adjacent tiles (which share Gaussians) on one XCD's L2
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
 //    4 x ds_read_b128         lane (k,part) = (lane>>2, lane&3) reads elements [16 part, 16 part+16) of row k
 //                             (row stride 68 dwords: the 16-lane groups of ds_read_b128 hit 64 distinct banks)
 //   15 plain adds + 2 quad DPP adds -> lanes 4k..4k+3 hold component k summed over the 64 pixels
-//    1 x global_atomic_add_f32 with 10 active lanes onto ONE 48-byte scratch row of this Gaussian
+//    1 x global_atomic_add_f32 with 10 active lanes onto ONE 40-byte scratch row of this Gaussian
 // Measured ablations: without the atomic the kernel ran 26 % faster while its 10 lanes went to four separate
 // arrays; on one row the atomic is free.  PMC: VALU busy 66 % of all SIMD cycles (incl. the tail), i.e. the
 // kernel is VALU/issue bound; trimming 15 % of the VALU instructions bought 1-2 %.
