@@ -327,12 +327,19 @@ struct PixSums {
 
 // Raw-mode scratch row (B3GS_SCRATCH_ROW = 10 floats, 40 bytes, no padding: 8-byte aligned, five float2): conic xx,
 // xy, yy, depth | mean2D x, y | colour r, g, b | opacity.  Returns the sums and leaves the row zero (the scratch is persistent: no per-view memset).
-__device__ __forceinline__ PixSums load_scratch_row(float* scratch, int i) {
+__device__ __forceinline__ PixSums load_scratch_row(float* scratch, int i, bool* touched = nullptr) {
   static_assert(B3GS_SCRATCH_ROW == 10, "five float2 per row");
   float2* row = reinterpret_cast<float2*>(scratch) + 5 * (size_t)i;
   const float2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
-  const float2 z = make_float2(0.f, 0.f);
-  row[0] = z; row[1] = z; row[2] = z; row[3] = z; row[4] = z;
+  // sums are never -0.0 (atomic adds onto +0.0), so the bit pattern tells "nothing arrived"
+  const uint32_t any = ((__float_as_uint(r0.x) | __float_as_uint(r0.y)) | (__float_as_uint(r1.x) | __float_as_uint(r1.y))) |
+                       ((__float_as_uint(r2.x) | __float_as_uint(r2.y)) | (__float_as_uint(r3.x) | __float_as_uint(r3.y))) |
+                       (__float_as_uint(r4.x) | __float_as_uint(r4.y));
+  if (touched) *touched = any != 0u;
+  if (!touched || any != 0u) {
+    const float2 z = make_float2(0.f, 0.f);
+    row[0] = z; row[1] = z; row[2] = z; row[3] = z; row[4] = z;
+  }
   PixSums in;
   in.gxx = r0.x; in.gxy = r0.y; in.gyy = r1.x; in.gdepth = r1.y;
   in.g2x = r2.x; in.g2y = r2.y;
@@ -707,13 +714,17 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
     sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
     const Mat16 vm = load_mat(vr.viewmatrix);
     const Mat16 pm = load_mat(vr.projmatrix);
-    const PixSums in = load_scratch_row(vr.scratch, i);   // read and reset
+    // read the row; only a row that received something is reset (and only it has a gradient to push through the
+    // chain rule): most visible Gaussians of a view lie behind the saturation point of every pixel they cover
+    bool touched;
+    const PixSums in = load_scratch_row(vr.scratch, i, &touched);
     if (m2d) { m2d[i3] = in.g2x; m2d[i3 + 1] = in.g2y; m2d[i3 + 2] = 0.f; }
-    if (vr.densify_stats) {
+    if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
       st_norm += sqrtf(in.g2x * in.g2x + in.g2y * in.g2y);
       st_cnt += 1.0f;
       st_rad = max(st_rad, rad);
     }
+    if (!touched) continue;
     GaussGrad gg;
     gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
     dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
