@@ -18,7 +18,6 @@ namespace {
 
 constexpr int LT = 16;          // output tile
 constexpr int LR = 5;           // SSIM window radius
-constexpr int LW = LT + 2 * LR; // 26
 // partial sums: thousands of workgroups adding to ONE address serialise in L2 (measured: 153 us for the SSIM
 // statistics kernel, almost all of it the two atomics per workgroup); each of the 8 sums is spread over 64
 // slots picked by workgroup index and folded by the finalize kernel
@@ -67,65 +66,113 @@ __device__ __forceinline__ float block_sum_256(float v, float* tmp) {
   return tmp[0] + tmp[1] + tmp[2] + tmp[3];
 }
 
+// ---- SSIM: separable 11-tap window through LDS, 32x32 outputs per workgroup, 4 outputs per thread in both passes
+// (a sliding window of 14 LDS values feeds 4 outputs: 3.4x fewer LDS reads than one output per thread)
+constexpr int ST = 32;            // outputs per workgroup side
+constexpr int SW = ST + 2 * LR;   // 42 inputs per side
+
+// horizontal pass for NQ quantities: item = (row, group of 4 columns); in[q][row][col] -> out[q][row][col]
+template <int NQ>
+__device__ __forceinline__ void hpass4(const float (*in)[SW][SW + 1], float (*out)[SW][ST + 1], const Win& win, int tid) {
+  for (int it = tid; it < SW * (ST / 4); it += 256) {
+    const int r = it / (ST / 4), c0 = (it % (ST / 4)) * 4;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      float v[14];
+#pragma unroll
+      for (int j = 0; j < 14; j++) v[j] = in[q][r][c0 + j];
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc = fmaf(win.w[k], v[o + k], acc);
+        out[q][r][c0 + o] = acc;
+      }
+    }
+  }
+}
+// vertical pass: thread = (column tx, group of 4 rows): res[q][o] for rows 4*tg + o
+template <int NQ>
+__device__ __forceinline__ void vpass4(const float (*hq)[SW][ST + 1], const Win& win, int tx, int tg, float (&res)[NQ][4]) {
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    float v[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) v[j] = hq[q][4 * tg + j][tx];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc = fmaf(win.w[k], v[o + k], acc);
+      res[q][o] = acc;
+    }
+  }
+}
+
 // sums[0] += sum |x-y|, sums[1] += sum ssim_map; maps: dS/dmu1, dS/dE[x^2], dS/dE[xy] per channel
 __global__ void __launch_bounds__(256) ssim_stats_kernel(LossBatch lb, Win win) {
-  __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
-  __shared__ float hq[5][LW][LT];
+  __shared__ float sin[2][SW][SW + 1];   // x, y with halo (the three products are formed in registers)
+  __shared__ float hq[5][SW][ST + 1];
   __shared__ float red[4];
   const PairArgs& a = lb.p[blockIdx.z / 3];
   const int ch = blockIdx.z % 3;
   const int W = a.W, H = a.H;
-  if ((int)blockIdx.x * LT >= W || (int)blockIdx.y * LT >= H) return;   // grid sized for the largest pair
+  if ((int)blockIdx.x * ST >= W || (int)blockIdx.y * ST >= H) return;   // grid sized for the largest pair
   float* __restrict__ sums = a.sums;
   float* __restrict__ maps = a.maps;
   const size_t hw = (size_t)H * W;
   const float* __restrict__ x = a.image + ch * hw;
   const float* __restrict__ y = a.gt + ch * hw;
   const int tid = threadIdx.y * LT + threadIdx.x;
-  const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
-  for (int i = tid; i < LW * LW; i += 256) {
-    const int r = i / LW, c = i % LW, gr = r0 + r, gc = c0 + c;
+  const int r0 = blockIdx.y * ST - LR, c0 = blockIdx.x * ST - LR;
+  for (int i = tid; i < SW * SW; i += 256) {
+    const int r = i / SW, c = i - r * SW, gr = r0 + r, gc = c0 + c;
     const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
-    sx[r][c] = in ? x[(size_t)gr * W + gc] : 0.f;
-    sy[r][c] = in ? y[(size_t)gr * W + gc] : 0.f;
+    const float xv = in ? x[(size_t)gr * W + gc] : 0.f, yv = in ? y[(size_t)gr * W + gc] : 0.f;
+    sin[0][r][c] = xv; sin[1][r][c] = yv;
   }
   __syncthreads();
-  for (int i = tid; i < LW * LT; i += 256) {
-    const int r = i / LT, c = i % LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+  for (int it = tid; it < SW * (ST / 4); it += 256) {   // horizontal pass: (row, group of 4 columns)
+    const int r = it / (ST / 4), c0 = (it % (ST / 4)) * 4;
+    float xv[14], yv[14];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float xv = sx[r][c + k], yv = sy[r][c + k], wk = win.w[k];
-      a0 = fmaf(wk, xv, a0); a1 = fmaf(wk, yv, a1); a2 = fmaf(wk, xv * xv, a2); a3 = fmaf(wk, yv * yv, a3);
-      a4 = fmaf(wk, xv * yv, a4);
+    for (int j = 0; j < 14; j++) { xv[j] = sin[0][r][c0 + j]; yv[j] = sin[1][r][c0 + j]; }
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float wk = win.w[k], xx = xv[o + k], yy = yv[o + k];
+        a0 = fmaf(wk, xx, a0); a1 = fmaf(wk, yy, a1); a2 = fmaf(wk, xx * xx, a2); a3 = fmaf(wk, yy * yy, a3);
+        a4 = fmaf(wk, xx * yy, a4);
+      }
+      hq[0][r][c0 + o] = a0; hq[1][r][c0 + o] = a1; hq[2][r][c0 + o] = a2; hq[3][r][c0 + o] = a3; hq[4][r][c0 + o] = a4;
     }
-    hq[0][r][c] = a0; hq[1][r][c] = a1; hq[2][r][c] = a2; hq[3][r][c] = a3; hq[4][r][c] = a4;
   }
   __syncthreads();
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int gr = blockIdx.y * LT + ty, gc = blockIdx.x * LT + tx;
+  const int tx = tid & 31, tg = tid >> 5;
+  float res[5][4];
+  vpass4<5>(hq, win, tx, tg, res);
   float l1 = 0.f, ss = 0.f;
-  if (gr < H && gc < W) {
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  const int gc = blockIdx.x * ST + tx;
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float wk = win.w[k];
-      mu1 = fmaf(wk, hq[0][ty + k][tx], mu1); mu2 = fmaf(wk, hq[1][ty + k][tx], mu2);
-      e11 = fmaf(wk, hq[2][ty + k][tx], e11); e22 = fmaf(wk, hq[3][ty + k][tx], e22);
-      e12 = fmaf(wk, hq[4][ty + k][tx], e12);
+  for (int o = 0; o < 4; o++) {
+    const int lr = 4 * tg + o, gr = blockIdx.y * ST + lr;
+    if (gr < H && gc < W) {
+      const float mu1 = res[0][o], mu2 = res[1][o], e11 = res[2][o], e22 = res[3][o], e12 = res[4][o];
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+      const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+      const float inv = 1.0f / (B1 * B2);
+      const float S = A1 * A2 * inv;
+      ss += S;
+      const size_t p = (size_t)gr * W + gc;
+      // dS/dmu1 (mu1 also enters s1 and s12), dS/dE[x^2], dS/dE[xy]
+      maps[(0 * 3 + ch) * hw + p] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+      maps[(1 * 3 + ch) * hw + p] = -S / B2;
+      maps[(2 * 3 + ch) * hw + p] = 2.f * A1 * inv;
+      l1 += fabsf(sin[0][lr + LR][tx + LR] - sin[1][lr + LR][tx + LR]);
     }
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
-    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
-    const float inv = 1.0f / (B1 * B2);
-    const float S = A1 * A2 * inv;
-    ss = S;
-    const size_t p = (size_t)gr * W + gc;
-    // dS/dmu1 (mu1 also enters s1 and s12), dS/dE[x^2], dS/dE[xy]
-    maps[(0 * 3 + ch) * hw + p] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
-    maps[(1 * 3 + ch) * hw + p] = -S / B2;
-    maps[(2 * 3 + ch) * hw + p] = 2.f * A1 * inv;
-    l1 = fabsf(sx[ty + LR][tx + LR] - sy[ty + LR][tx + LR]);
   }
   const float t0 = block_sum_256(l1, red);
   const float t1 = block_sum_256(ss, red);
@@ -134,12 +181,12 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(LossBatch lb, Win win) 
 
 // dL/dimage = cS * (w*dmu1 + 2x (w*de11) + y (w*de12)) + cL1 * sign(x - y)
 __global__ void __launch_bounds__(256) ssim_grad_kernel(LossBatch lb, Win win) {
-  __shared__ float sm[3][LW][LW + 1];
-  __shared__ float hq[3][LW][LT];
+  __shared__ float sm[3][SW][SW + 1];
+  __shared__ float hq[3][SW][ST + 1];
   const PairArgs& a = lb.p[blockIdx.z / 3];
   const int ch = blockIdx.z % 3;
   const int W = a.W, H = a.H;
-  if ((int)blockIdx.x * LT >= W || (int)blockIdx.y * LT >= H) return;
+  if ((int)blockIdx.x * ST >= W || (int)blockIdx.y * ST >= H) return;
   const float* __restrict__ img = a.image;
   const float* __restrict__ gt = a.gt;
   const float* __restrict__ maps = a.maps;
@@ -147,38 +194,30 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(LossBatch lb, Win win) {
   const float cS = a.cS, cL1 = a.cL1;
   const size_t hw = (size_t)H * W;
   const int tid = threadIdx.y * LT + threadIdx.x;
-  const int r0 = blockIdx.y * LT - LR, c0 = blockIdx.x * LT - LR;
-  for (int i = tid; i < LW * LW; i += 256) {
-    const int r = i / LW, c = i % LW, gr = r0 + r, gc = c0 + c;
+  const int r0 = blockIdx.y * ST - LR, c0 = blockIdx.x * ST - LR;
+  for (int i = tid; i < SW * SW; i += 256) {
+    const int r = i / SW, c = i - r * SW, gr = r0 + r, gc = c0 + c;
     const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
     const size_t p = in ? (size_t)gr * W + gc : 0;
 #pragma unroll
     for (int m = 0; m < 3; m++) sm[m][r][c] = in ? maps[(m * 3 + ch) * hw + p] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < LW * LT; i += 256) {
-    const int r = i / LT, c = i % LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 11; k++) {
-      const float wk = win.w[k];
-      a0 = fmaf(wk, sm[0][r][c + k], a0); a1 = fmaf(wk, sm[1][r][c + k], a1); a2 = fmaf(wk, sm[2][r][c + k], a2);
-    }
-    hq[0][r][c] = a0; hq[1][r][c] = a1; hq[2][r][c] = a2;
-  }
+  hpass4<3>(sm, hq, win, tid);
   __syncthreads();
-  const int tx = threadIdx.x, ty = threadIdx.y;
-  const int gr = blockIdx.y * LT + ty, gc = blockIdx.x * LT + tx;
-  if (gr >= H || gc >= W) return;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  const int tx = tid & 31, tg = tid >> 5;
+  float res[3][4];
+  vpass4<3>(hq, win, tx, tg, res);
+  const int gc = blockIdx.x * ST + tx;
 #pragma unroll
-  for (int k = 0; k < 11; k++) {
-    const float wk = win.w[k];
-    g0 = fmaf(wk, hq[0][ty + k][tx], g0); g1 = fmaf(wk, hq[1][ty + k][tx], g1); g2 = fmaf(wk, hq[2][ty + k][tx], g2);
+  for (int o = 0; o < 4; o++) {
+    const int gr = blockIdx.y * ST + 4 * tg + o;
+    if (gr < H && gc < W) {
+      const size_t p = (size_t)gr * W + gc;
+      const float xv = img[ch * hw + p], yv = gt[ch * hw + p];
+      dL_dimage[ch * hw + p] = cS * (res[0][o] + 2.f * xv * res[1][o] + yv * res[2][o]) + cL1 * sgn(xv - yv);
+    }
   }
-  const size_t p = (size_t)gr * W + gc;
-  const float xv = img[ch * hw + p], yv = gt[ch * hw + p];
-  dL_dimage[ch * hw + p] = cS * (g0 + 2.f * xv * g1 + yv * g2) + cL1 * sgn(xv - yv);
 }
 
 
@@ -378,8 +417,9 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
     gy = (H + LT - 1) / LT > gy ? (H + LT - 1) / LT : gy;
   }
   const dim3 blk(LT, LT);
-  hipLaunchKernelGGL(ssim_stats_kernel, dim3(gx, gy, 3 * npairs), blk, 0, s, lb, win);
-  hipLaunchKernelGGL(ssim_grad_kernel, dim3(gx, gy, 3 * npairs), blk, 0, s, lb, win);
+  const dim3 sgrid((gx * LT + ST - 1) / ST, (gy * LT + ST - 1) / ST, 3 * npairs);   // SSIM: 32x32 outputs per workgroup
+  hipLaunchKernelGGL(ssim_stats_kernel, sgrid, blk, 0, s, lb, win);
+  hipLaunchKernelGGL(ssim_grad_kernel, sgrid, blk, 0, s, lb, win);
   hipLaunchKernelGGL(binocular_kernel, dim3(gx, gy, npairs), blk, 0, s, lb);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(npairs), dim3(SLOTS), 0, s, lb);
   return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
