@@ -242,6 +242,7 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
   if ((int)blockIdx.x * LT >= a.W || (int)blockIdx.y * LT >= a.H) return;
   constexpr int HAL = 2, TW = LT + 2 * HAL;
   __shared__ float sD[TW][TW + 1];   // disparity * mask with a halo of 2
+  __shared__ float sG[TW][TW + 1];   // sum over channels of gt, same halo (edge weights: one value per pixel)
   __shared__ float red[4];
   const int W = a.W, H = a.H;
   const size_t hw = (size_t)H * W;
@@ -266,6 +267,13 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
       const int rr = i / TW, cc = i % TW;
       const Disp dd = disparity_at(a, (int)blockIdx.y * LT + rr - HAL, (int)blockIdx.x * LT + cc - HAL);
       sD[rr][cc] = dd.d * dd.m;
+      const int gr = (int)blockIdx.y * LT + rr - HAL, gc = (int)blockIdx.x * LT + cc - HAL;
+      float gsum = 0.f;
+      if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+        const size_t q = (size_t)gr * W + gc;
+        gsum = (a.gt[q] + a.gt[hw + q]) + a.gt[2 * hw + q];
+      }
+      sG[rr][cc] = gsum;
     }
     __syncthreads();
     if (in) {
@@ -294,12 +302,9 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
       auto gx_at = [&](int rr, int cc, float& val) -> float {   // returns sign(v)*ex*c_smooth, val = |v|
         val = 0.f;
         if (rr < 1 || rr > H - 2 || cc < 1 || cc > W - 2) return 0.f;
-        float e = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-          e += 0.5f * (a.gt[ch * hw + (size_t)rr * W + cc + 1] - a.gt[ch * hw + (size_t)rr * W + cc - 1]);
-        const float ex = __expf(fabsf(e) * -0.33f);
         const int lr = rr - (int)blockIdx.y * LT + HAL, lc = cc - (int)blockIdx.x * LT + HAL;
+        const float e = 0.5f * (sG[lr][lc + 1] - sG[lr][lc - 1]);   // sum_c dx(gt_c) = dx(sum_c gt_c)
+        const float ex = __expf(fabsf(e) * -0.33f);
         const float v = ex * (0.5f * (sD[lr][lc + 1] - sD[lr][lc - 1]));
         val = fabsf(v);
         return sgn(v) * ex * a.c_smooth;
@@ -307,12 +312,9 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
       auto gy_at = [&](int rr, int cc, float& val) -> float {
         val = 0.f;
         if (rr < 1 || rr > H - 2 || cc < 1 || cc > W - 2) return 0.f;
-        float e = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++)
-          e += 0.5f * (a.gt[ch * hw + (size_t)(rr + 1) * W + cc] - a.gt[ch * hw + (size_t)(rr - 1) * W + cc]);
-        const float ey = __expf(fabsf(e) * -0.33f);
         const int lr = rr - (int)blockIdx.y * LT + HAL, lc = cc - (int)blockIdx.x * LT + HAL;
+        const float e = 0.5f * (sG[lr + 1][lc] - sG[lr - 1][lc]);
+        const float ey = __expf(fabsf(e) * -0.33f);
         const float v = ey * (0.5f * (sD[lr + 1][lc] - sD[lr - 1][lc]));
         val = fabsf(v);
         return sgn(v) * ey * a.c_smooth;
