@@ -526,7 +526,10 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   }
 }
 
-constexpr int FWD_CHUNK = 256;
+#ifndef B3GS_FWD_CHUNK
+#define B3GS_FWD_CHUNK 256
+#endif
+constexpr int FWD_CHUNK = B3GS_FWD_CHUNK;
 unsigned long long* g_bwd_trace = nullptr;
 size_t g_bwd_trace_words = 0;
 unsigned long long* trace_buffer(int nblocks) {  // debug (B3GS_FWD_TRACE / B3GS_BWD_TRACE): per-wave cycle trace
