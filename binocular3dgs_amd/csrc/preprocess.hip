@@ -600,18 +600,17 @@ __global__ void __launch_bounds__(256)
     in = load_scratch_row(dL_dcov3D, i);
     if (m2d_out) { m2d_out[i3] = in.g2x; m2d_out[i3 + 1] = in.g2y; m2d_out[i3 + 2] = 0.f; }
   } else {
-    in.g2x = dL_dmeans2D[i3];
-    in.g2y = dL_dmeans2D[i3 + 1];
-    // conic / depth sums: rows of 6 floats (dL_dcov3D doubles as scratch)
-    in.gxx = dL_dcov3D[6 * (size_t)i + 0];
-    in.gxy = dL_dcov3D[6 * (size_t)i + 1];
-    in.gyy = dL_dcov3D[6 * (size_t)i + 2];
-    in.gdepth = dL_dcov3D[6 * (size_t)i + 3];
-    in.gcol[0] = dL_dcolors[i3];
-    in.gcol[1] = dL_dcolors[i3 + 1];
-    in.gcol[2] = dL_dcolors[i3 + 2];
-    in.gop = dL_dopacity[i];
-    dL_dmeans2D[i3 + 2] = 0.f;
+    // the blend backward left this Gaussian's ten sums in one row of the geometry buffer's scratch region (zeroed
+    // by b3gs_backward before the launch); the three accumulated outputs of the reference API are written here
+    const float2* row = reinterpret_cast<const float2*>(g.bwd_rows) + 5 * (size_t)i;
+    const float2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+    in.gxx = r0.x; in.gxy = r0.y; in.gyy = r1.x; in.gdepth = r1.y;
+    in.g2x = r2.x; in.g2y = r2.y;
+    in.gcol[0] = r3.x; in.gcol[1] = r3.y; in.gcol[2] = r4.x;
+    in.gop = r4.y;
+    dL_dmeans2D[i3] = in.g2x; dL_dmeans2D[i3 + 1] = in.g2y; dL_dmeans2D[i3 + 2] = 0.f;
+    dL_dcolors[i3] = in.gcol[0]; dL_dcolors[i3 + 1] = in.gcol[1]; dL_dcolors[i3 + 2] = in.gcol[2];
+    dL_dopacity[i] = in.gop;
   }
 
   GaussGrad gg;
