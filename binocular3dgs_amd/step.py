@@ -235,7 +235,8 @@ class ViewShardedStep:
             for name, ptr, w in zip(("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"),
                                     rs.grad_ptrs(r), rs.widths):
                 setattr(gr, name, (ptr - 4 * w * first) if w else None)     # indexed by the GLOBAL Gaussian index
-            fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True)
+            if self._pending_views:
+                fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True)
             works.append(dist.all_reduce(rs.chunk(r), op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None)
         for r in range(rs.K):
             if works[r] is not None:
@@ -261,6 +262,14 @@ class ViewShardedStep:
         no collective, no host sync and (fused path) no allocation: capturable as one HIP graph."""
         assert sum(f is not None for f in (pair_grad_fn, loss_fn, batch_loss_fn)) == 1
         assert batch_loss_fn is None or self.fused is not None
+        if not self.pairs:
+            # a rank without views (more ranks than pairs) contributes zeros to the all-reduce
+            self.slab.zero()
+            if self.range_slab is not None:
+                self.range_slab.flat.zero_()
+                self._pending_views = []
+            self.last_stats = {"views": 0}
+            return 0
         if self.fused is not None:
             # the fused multi-view accumulate STORES the gradients: no zero-fill of the slab
             self.slab.rebind()

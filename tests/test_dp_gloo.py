@@ -115,3 +115,14 @@ def test_two_ranks_equal_one_rank(tmp_path):
     np.testing.assert_allclose(r0["grad"], ref, rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(r0["params"], torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy(),
                                rtol=1e-6, atol=1e-7)
+
+
+def test_rank_without_pairs_contributes_zero_gradients():
+    """More ranks than (input, shifted) pairs: the idle rank still owns a zeroed slab for the all-reduce."""
+    from binocular3dgs_amd.step import ViewShardedStep, shard_pairs
+    model, pairs, gts, render = _build()
+    assert shard_pairs(3, 3, 4) == []
+    st = ViewShardedStep(model, [], torch.zeros(3), render_fn=render)
+    st.slab.flat.fill_(7.0)
+    assert st.compute_grads(loss_fn=lambda *a: None) == 0
+    assert float(st.slab.flat.abs().max()) == 0.0
