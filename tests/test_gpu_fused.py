@@ -348,3 +348,54 @@ def test_views_of_different_tile_sort_depth_in_one_forward_batch():
     for a, b in zip(res["single"], res["batch"]):
         assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert res["batch"][1][0] > 0
+
+
+def test_single_view_raw_entry_points_match_the_batched_path():
+    """b3gs_forward_raw + b3gs_backward_raw (one view per call, both backward phases in one call, gradients
+    ACCUMULATED into the given buffers) against the batched entry points the FusedRasterizer uses."""
+    import ctypes as C
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H = 176, 128
+    model, pairs, bg = _setup(P=7000, W=W, H=H)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+    cam = pairs[2][0]
+    fr = FusedRasterizer(model, W, H, num_slots=1)
+    out = fr.render(cam, bg, slot=0)
+    torch.autograd.backward([out["render"], out["rendered_depth"], out["rendered_alpha"]], [gc, gd, ga])
+    torch.cuda.synchronize()
+    ref = [p.grad.clone() for p in model.parameters()]
+    ref_img = out["render"].detach().clone()
+    ref_m2d = out["viewspace_points_grad"].clone()
+    # the same through the single-view C entry points, into fresh buffers
+    L = _lib.lib()
+    P = model.get_xyz.shape[0]
+    sc = fr._scene(dict(cam=cam, bg=bg, scaling_modifier=1.0, debug=False))
+    rp = fr._bind_params()
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
+    binning = torch.empty(L.b3gs_binning_bytes(P, 400000), **u8)
+    img = torch.empty(L.b3gs_image_bytes(W, H), **u8)
+    color, depth, alpha = torch.empty(3, H, W, device="cuda"), torch.empty(1, H, W, device="cuda"), torch.empty(1, H, W, device="cuda")
+    radii = torch.zeros(P, dtype=torch.int32, device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.b3gs_forward_raw(C.byref(sc), C.byref(rp), geom.data_ptr(), binning.data_ptr(), 400000, img.data_ptr(),
+                                  color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), n.data_ptr(), 3,
+                                  stream), "b3gs_forward_raw")
+    assert torch.equal(color, ref_img) and 0 < int(n.item()) <= 400000
+    grads = [torch.zeros_like(p) for p in model.parameters()]              # += semantics: two calls give twice the gradient
+    gr = _lib.B3gsRawGrads()
+    for name, g in zip(("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"), grads):
+        setattr(gr, name, g.data_ptr())
+    scratch = torch.zeros(L.b3gs_backward_scratch_floats(P), device="cuda")
+    m2d = torch.empty(P, 3, device="cuda")
+    for _ in range(2):                                                       # twice: the scratch must come back clean
+        _lib.check(L.b3gs_backward_raw(C.byref(sc), C.byref(rp), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(),
+                                       img.data_ptr(), gc.data_ptr(), gd.data_ptr(), ga.data_ptr(), scratch.data_ptr(),
+                                       C.byref(gr), m2d.data_ptr(), 3, stream), "b3gs_backward_raw")
+    torch.cuda.synchronize()
+    assert float(scratch.abs().max()) == 0.0
+    assert rel_l2(m2d.cpu().numpy(), ref_m2d.cpu().numpy()) < 1e-5
+    for g, r in zip(grads, ref):
+        assert rel_l2((g / 2).cpu().numpy(), r.cpu().numpy()) < 2e-5
