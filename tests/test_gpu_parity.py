@@ -311,3 +311,38 @@ def test_two_word_instances_when_tile_and_index_bits_exceed_32():
                                            out2["img"].data_ptr(), C.byref(v)), "b3gs_debug_views")
     assert v.packed_idx_bits == 17
     _check_forward(d2, st2, out2, flip_frac=1e-5)
+
+
+def test_forward_capacity_entry_point_and_overflow():
+    """b3gs_forward_capacity (reference-shaped scene, caller-presized buffers, N stays on the device) reproduces
+    b3gs_forward; capacity overflow is visible in the device-side N."""
+    import ctypes as C
+    from binocular3dgs_amd import _lib
+    d, _ = small_scene(P=3000, W=200, H=120, seed=21)
+    out = _run_hip_forward(d)
+    g, sh, colors, scales, rots, cov = out["inputs"]
+    L = _lib.lib()
+    P, W, H = 3000, d["W"], d["H"]
+    ptr = lambda t: t.data_ptr() if t.numel() else None  # noqa: E731
+    sc = _lib.B3gsScene(P, d["sh_degree"], sh.shape[1], W, H, d["tanfovx"], d["tanfovy"], 1.0, 0, 0, ptr(g["bg"]), ptr(g["means3D"]),
+                        ptr(sh), None, ptr(g["opacities"]), ptr(scales), ptr(rots), None, ptr(g["viewmatrix"]),
+                        ptr(g["projmatrix"]), ptr(g["campos"]))
+    u8 = dict(dtype=torch.uint8, device="cuda")
+    for cap in (out["n"] + 1000, max(out["n"] // 3, 1)):
+        geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
+        binning = torch.empty(L.b3gs_binning_bytes(P, cap), **u8)
+        img = torch.empty(L.b3gs_image_bytes(W, H), **u8)
+        color, depth, alpha = torch.empty(3, H, W, device="cuda"), torch.empty(1, H, W, device="cuda"), torch.empty(1, H, W, device="cuda")
+        radii = torch.zeros(P, dtype=torch.int32, device="cuda")
+        n = torch.zeros(1, dtype=torch.int32, device="cuda")
+        rc = L.b3gs_forward_capacity(C.byref(sc), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), color.data_ptr(),
+                                     depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), n.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "b3gs_forward_capacity")
+        torch.cuda.synchronize()
+        assert int(n.item()) == out["n"]                       # the true N even when it does not fit
+        assert torch.equal(radii, out["radii"])
+        if cap >= out["n"]:
+            assert torch.equal(color, out["color"]) and torch.equal(depth, out["depth"]) and torch.equal(alpha, out["alpha"])
+        else:
+            assert int(n.item()) > cap and torch.isfinite(color).all()   # truncated lists: caller must grow and repeat
