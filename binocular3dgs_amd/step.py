@@ -2,19 +2,29 @@
 
 Reference semantics (train.py:92-149,196-198): one input view per iteration, optionally a second
 render of its binocular-shifted partner; the per-Gaussian gradients of the renders simply add up
-in autograd, then Adam steps.  Here every rank owns whole (input view, shifted view) PAIRS --
-the binocular loss couples the two members of a pair through the primary depth map, so a pair is
-never split -- the Gaussian parameters are replicated, and the only exchange is ONE all-reduce
-(sum) of a flat, pre-packed fp32 gradient slab (92 B per Gaussian at K=4) over RCCL/xGMI
-(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  There is no reference
-counterpart for the collective (the reference is single-GPU): semantics are defined in
-SURVEY.md section 8e / DESIGN.md "Multi-GPU".
+in autograd, then Adam steps.  Here the VIEWS of an iteration are spread over the ranks
+(SURVEY.md section 8e), the Gaussian parameters are replicated, and the only per-Gaussian exchange
+is the sum of a flat, pre-packed fp32 gradient slab (92 B per Gaussian at K=4) over RCCL/xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests):
 
-`views_per_step == 1` on one rank reproduces the reference schedule.
+  * `ViewShardedStep(model, pairs, ...)`        this rank's whole (input, shifted) pairs (`shard_pairs`);
+  * `ViewShardedStep.from_global(...)`          VIEW-granular: `assign_views` cuts the iteration's view list
+    [in0, sh0, in1, sh1, ...] into balanced contiguous blocks, so a pair may straddle two ranks (6 views on 4
+    GPUs: 2,2,1,1; 8 views on 8 GPUs: one each).  The binocular loss couples the members of a pair through
+    the primary's depth map (train.py:128-136): the rank that owns the shifted view sends its rendered image
+    (3 H W floats) to the rank that owns the input view, which forms the loss and sends d(loss)/d(shifted image)
+    back -- two point-to-point messages per split pair over the direct xGMI link, no collective;
+  * gradient sum + optimiser: either ONE all-reduce + replicated Adam (`FusedAdam`), or `ShardedAdam`:
+    reduce-scatter of the slab, Adam on this rank's 1/N of the flat parameter buffer (Adam state and its
+    28 B per float of traffic shrink by N), all-gather of the updated parameters -- the same bytes on the
+    links as the all-reduce.
+
+There is no reference counterpart for the exchange (the reference is single-GPU): semantics are defined in
+SURVEY.md section 8e / DESIGN.md "Multi-GPU".  One rank with one pair reproduces the reference schedule.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -22,17 +32,23 @@ import torch.distributed as dist
 from .render import PipelineParams, render
 
 
+def _dist_on(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 class FlatGradSlab:
     """All parameter gradients live in one contiguous fp32 buffer: `p.grad` of every parameter is
     a view into it, so autograd accumulates the views of all renders in place, zeroing is one
-    memset and the data-parallel exchange is one all-reduce without a pack step."""
+    memset and the data-parallel exchange is one collective without a pack step.  `padded_numel`
+    (>= the number of gradient floats) lets a sharded optimiser cut the buffer into equal chunks."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter]):
+    def __init__(self, params: Sequence[torch.nn.Parameter], padded_numel: int = 0):
         self.params = list(params)
         self.force_collective = False   # issue the all-reduce even in a 1-rank group (path check)
         total = sum(p.numel() for p in self.params)
+        self.numel = total
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(max(total, int(padded_numel)), dtype=torch.float32, device=dev)
         off = 0
         self.views: List[torch.Tensor] = []
         for p in self.params:
@@ -51,8 +67,7 @@ class FlatGradSlab:
         self.rebind()
 
     def all_reduce(self, average: bool = False, group=None):
-        if dist.is_available() and dist.is_initialized() and \
-                (dist.get_world_size(group) > 1 or self.force_collective):
+        if _dist_on() and (dist.get_world_size(group) > 1 or self.force_collective):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
@@ -61,18 +76,29 @@ class FlatGradSlab:
         return self.flat.numel() * 4
 
 
+def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev):
+    """One b3gs_adam_step launch over [(param_ptr, grad_ptr, m_ptr, v_ptr, count, lr), ...] (at most 8)."""
+    from . import _lib
+    segs = (_lib.B3gsAdamSegment * max(len(segs_py), 1))()
+    for k, (p, g, m, v, n, lr) in enumerate(segs_py):
+        segs[k].param, segs[k].grad, segs[k].exp_avg, segs[k].exp_avg_sq = p or None, g or None, m or None, v or None
+        segs[k].count, segs[k].lr = int(n), float(lr)
+    rc = _lib.lib().b3gs_adam_step(len(segs_py), segs, step_count.data_ptr(), betas[0], betas[1], eps,
+                                   float(opacity_decay), int(opacity_seg), int(bool(decay_first)), int(bool(bump)),
+                                   torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc, "b3gs_adam_step")
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (betas, eps, per-tensor learning rates; no weight decay / amsgrad) for
     all parameter tensors of the model in one HIP launch (b3gs_adam_step), step counter on the device
     (graph-replayable).  `opacity_decay` (e.g. 0.995, train.py:171-173,278-279) is applied to the tensor
-    with index `opacity_index` after its update when set.  State lives in two flat fp32 buffers."""
+    with index `opacity_index` when set: after the Adam update by default, or -- `decay_first=True`, the
+    reference's order (train.py:171-173 runs before optimizer.step() at :196-198) -- to the value the
+    update is then subtracted from.  State lives in two flat fp32 buffers."""
 
     def __init__(self, params: Sequence[torch.nn.Parameter], lrs: Sequence[float], betas=(0.9, 0.999), eps=1e-15,
-                 opacity_decay: float = 0.0, opacity_index: int = -1):
-        import ctypes as C
-
-        from . import _lib
-        self._C, self._lib = C, _lib
+                 opacity_decay: float = 0.0, opacity_index: int = -1, decay_first: bool = False):
         self.params = list(params)
         self.lrs = [float(x) for x in lrs]
         assert len(self.params) == len(self.lrs) <= 8
@@ -83,6 +109,7 @@ class FusedAdam:
         self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.betas, self.eps = betas, float(eps)
         self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
+        self.decay_first = bool(decay_first)
 
     def step(self):
         P = self.params[0].shape[0]
@@ -91,27 +118,136 @@ class FusedAdam:
     def step_rows(self, first: int, count: int, grad_ptrs: Sequence[int], last: bool):
         """Adam for rows [first, first+count) of every tensor (row = one Gaussian); grad_ptrs[k] is the address of
         the gradient of row `first` of tensor k (rows contiguous).  The step counter advances when `last`."""
-        C, _lib = self._C, self._lib
-        segs = (_lib.B3gsAdamSegment * len(self.params))()
-        off = 0
-        for k, (p, lr) in enumerate(zip(self.params, self.lrs)):
+        segs, off = [], 0
+        for p, lr, gp in zip(self.params, self.lrs, grad_ptrs):
             assert p.is_contiguous()
             w = p.numel() // max(p.shape[0], 1)
-            segs[k].param, segs[k].grad = p.data_ptr() + 4 * w * first, grad_ptrs[k]
-            segs[k].exp_avg = self.exp_avg.data_ptr() + 4 * (off + w * first)
-            segs[k].exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * (off + w * first)
-            segs[k].count, segs[k].lr = w * count, lr
+            segs.append((p.data_ptr() + 4 * w * first, gp, self.exp_avg.data_ptr() + 4 * (off + w * first),
+                         self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr))
             off += p.numel()
-        dev = self.params[0].device
-        rc = _lib.lib().b3gs_adam_step(len(self.params), segs, self.step_count.data_ptr(), self.betas[0], self.betas[1],
-                                       self.eps, self.opacity_decay, self.opacity_index, int(bool(last)),
-                                       torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(rc, "b3gs_adam_step")
+        _adam_launch(segs, self.step_count, self.betas, self.eps, self.opacity_decay, self.opacity_index,
+                     self.decay_first, last, self.params[0].device)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
             if p.grad is not None:
                 p.grad.zero_()
+
+
+class ShardedAdam:
+    """Adam with the state sharded over the ranks (ZeRO-1 style) on top of flat buffers:
+
+        reduce_scatter(gradient slab)  ->  Adam on this rank's 1/N of the flat parameter buffer  ->  all_gather(parameters)
+
+    The six parameter tensors become views into ONE flat fp32 buffer `pflat` (tensor-major, padded to N equal
+    chunks of a multiple of 64 floats); rank r owns flat[r*chunk, (r+1)*chunk) whatever tensors that range cuts
+    through (the one-launch kernel takes up to 8 (pointer, count, lr) segments).  Same link bytes as an all-reduce
+    (2 (N-1)/N of the slab), but exp_avg / exp_avg_sq and the 28 B per float the Adam kernel moves are divided by N.
+    With one rank it degenerates to FusedAdam on flat buffers.  `adam_impl` replaces the HIP launch in the CPU
+    tests of the host logic (tests/test_dp_gloo.py); the product default has no CPU path."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], lrs: Sequence[float], betas=(0.9, 0.999), eps=1e-15,
+                 opacity_decay: float = 0.0, opacity_index: int = -1, decay_first: bool = False, group=None,
+                 adam_impl: Optional[Callable] = None):
+        self.lrs = [float(x) for x in lrs]
+        self.betas, self.eps = betas, float(eps)
+        self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
+        self.decay_first = bool(decay_first)
+        self.group = group
+        self.world = dist.get_world_size(group) if _dist_on() else 1
+        self.rank = dist.get_rank(group) if _dist_on() else 0
+        self.adam_impl = adam_impl
+        self.step_count = None
+        self._flatten(list(params), None, None)
+
+    # ---- layout ---------------------------------------------------------------------------------
+    def _flatten(self, params, full_m, full_v):
+        assert len(params) == len(self.lrs) <= 8
+        self.params = params
+        dev = params[0].device
+        if dev.type != "cuda" and self.adam_impl is None:
+            from . import _lib
+            raise _lib.B3gsError("ShardedAdam needs the parameters on the HIP device (no CPU fallback)")
+        total = sum(p.numel() for p in params)
+        per = -(-total // self.world)
+        self.chunk = -(-per // 64) * 64
+        self.padded_numel = self.chunk * self.world
+        self.numel = total
+        self.pflat = torch.zeros(self.padded_numel, dtype=torch.float32, device=dev)
+        self.bounds, off = [], 0
+        for p in params:
+            n = p.numel()
+            self.pflat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = self.pflat[off:off + n].view(p.shape)          # the parameter now lives in the flat buffer
+            self.bounds.append((off, off + n))
+            off += n
+        lo = self.rank * self.chunk
+        f = dict(dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(self.chunk, **f)
+        self.exp_avg_sq = torch.zeros(self.chunk, **f)
+        if full_m is not None:                                     # carried state (densification): take this rank's part
+            n = max(0, min(total, lo + self.chunk) - lo)
+            self.exp_avg[:n].copy_(full_m[lo:lo + n])
+            self.exp_avg_sq[:n].copy_(full_v[lo:lo + n])
+        self.gshard = torch.zeros(self.chunk, **f) if self.world > 1 else None
+        if self.step_count is None:
+            self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def my_segments(self) -> List[Tuple[int, int, int]]:
+        """[(tensor index, lo, hi)] in flat coordinates: the pieces of the tensors inside this rank's chunk."""
+        lo, hi = self.rank * self.chunk, (self.rank + 1) * self.chunk
+        out = []
+        for k, (a, b) in enumerate(self.bounds):
+            s, e = max(a, lo), min(b, hi)
+            if e > s:
+                out.append((k, s, e))
+        return out
+
+    # ---- one optimisation step ----------------------------------------------------------------------
+    def step(self, slab: FlatGradSlab, average: bool = False):
+        assert slab.flat.numel() == self.padded_numel, "gradient slab must be padded to ShardedAdam.padded_numel"
+        lo = self.rank * self.chunk
+        if self.world > 1:
+            dist.reduce_scatter_tensor(self.gshard, slab.flat, op=dist.ReduceOp.SUM, group=self.group)
+            g = self.gshard
+            if average:
+                g.div_(self.world)
+        else:
+            g = slab.flat[:self.chunk]
+        segs, opacity_seg = [], -1
+        for k, s, e in self.my_segments():
+            if k == self.opacity_index:
+                opacity_seg = len(segs)
+            segs.append((self.pflat[s:e], g[s - lo:e - lo], self.exp_avg[s - lo:e - lo], self.exp_avg_sq[s - lo:e - lo],
+                         self.lrs[k]))
+        decay = self.opacity_decay if opacity_seg >= 0 else 0.0
+        if self.adam_impl is not None:
+            self.adam_impl(segs, self.step_count, self.betas, self.eps, decay, opacity_seg, self.decay_first)
+        else:
+            _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr)
+                          for p, gg, m, v, lr in segs], self.step_count, self.betas, self.eps, decay, opacity_seg,
+                         self.decay_first, True, self.pflat.device)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.pflat, self.pflat[lo:lo + self.chunk], group=self.group)
+
+    def zero_grad(self, set_to_none: bool = False):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    # ---- densification support (densify.py): the full moments, tensor-major ----------------------------
+    def gather_full_state(self):
+        if self.world == 1:
+            return self.exp_avg, self.exp_avg_sq
+        m = torch.empty(self.padded_numel, dtype=torch.float32, device=self.pflat.device)
+        v = torch.empty_like(m)
+        dist.all_gather_into_tensor(m, self.exp_avg, group=self.group)
+        dist.all_gather_into_tensor(v, self.exp_avg_sq, group=self.group)
+        return m, v
+
+    def rebuild(self, new_params, full_m=None, full_v=None):
+        """New parameter tensors (densification changed P): re-flatten, keep the carried moments."""
+        self._flatten(list(new_params), full_m, full_v)
 
 
 class RangeGradSlab:
@@ -156,35 +292,83 @@ class RangeGradSlab:
 
 
 def shard_pairs(num_pairs: int, rank: int, world: int) -> List[int]:
-    """Round-robin assignment of view pairs to ranks (pair i -> rank i % world)."""
+    """Round-robin assignment of whole view pairs to ranks (pair i -> rank i % world)."""
     return [i for i in range(num_pairs) if i % world == rank]
 
 
-class ViewShardedStep:
-    """One optimisation step over this rank's view pairs.
+def assign_views(has_partner: Sequence[bool], world: int) -> List[List[Tuple[int, int]]]:
+    """View-granular sharding.  The iteration's views in order [(pair, role)] -- role 0 = input view, 1 = its
+    binocular partner -- are cut into `world` contiguous blocks whose sizes differ by at most one, larger blocks
+    first: 6 views on 2 ranks -> 3+3 (pair 1 split), on 4 ranks -> 2,2,1,1 (only pair 2 split), on 8 ranks -> one
+    view each and two idle ranks; 8 partner-less views on 8 ranks -> one each.  A block boundary splits at most one
+    pair, so two ranks exchange at most one image each way.  Returns the block of every rank."""
+    views = []
+    for i, hp in enumerate(has_partner):
+        views.append((i, 0))
+        if hp:
+            views.append((i, 1))
+    base, extra = divmod(len(views), world)
+    out, pos = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append(views[pos:pos + n])
+        pos += n
+    return out
 
-    pair_grad_fn(pair_index, primary_pkg, shifted_pkg_or_None) -> list of (output_tensor, grad_tensor)
-    supplies the upstream pixel gradients (bench: seeded synthetic gradients; training: autograd of
-    the loss block).  When `loss_fn` is given instead, it returns a scalar loss per pair and
-    ordinary autograd is used.
+
+class _View:
+    __slots__ = ("key", "pair", "role", "cam", "t", "peer", "slot", "mate")
+
+    def __init__(self, key, pair, role, cam, t, peer):
+        self.key, self.pair, self.role, self.cam, self.t, self.peer = key, pair, role, cam, t, peer
+        self.slot = None   # FusedRasterizer slot
+        self.mate = None   # index (in the local view list) of the other member of the pair when it is local
+
+
+class ViewShardedStep:
+    """One optimisation step over this rank's views.
+
+    pair_grad_fn(pair_index, primary_pkg_or_None, shifted_pkg_or_None) -> list of (output_tensor, grad_tensor)
+    supplies the upstream pixel gradients (bench: seeded synthetic gradients; a member of a pair that lives on
+    another rank arrives as None).  `loss_fn(pair_index, camera, primary_pkg, shifted_pkg_or_None, trans_dist)`
+    returns a scalar loss per pair, `batch_loss_fn([(pair_index, camera, pkg, shifted_pkg, trans_dist), ...])` the
+    sum over all pairs in one call; both see detached leaves of the rendered images, so that the pixel gradients
+    of a split pair can travel between the ranks before the rasterizer backward runs.
     """
 
     def __init__(self, model, pairs, bg: torch.Tensor, pipe: Optional[PipelineParams] = None, optimizer=None,
-                 average_over_world: bool = False, render_fn: Callable = render, fused=None, pipeline_ranges: int = 0):
+                 average_over_world: bool = False, render_fn: Callable = render, fused=None, pipeline_ranges: int = 0,
+                 group=None, _views: Optional[List[_View]] = None, overflow_check_every: int = 32):
         self.model = model
-        self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]
+        self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]  (whole local pairs)
         self.bg = bg
         self.pipe = pipe or PipelineParams()
-        self.slab = FlatGradSlab(model.parameters())
         self.optimizer = optimizer
         self.average = average_over_world
+        self.group = group
         self.fused = fused                # FusedRasterizer: fused activations + persistent scratch
+        if _views is None:
+            _views = []
+            for i, (cam, scam, t) in enumerate(self.pairs):
+                _views.append(_View(i, i, 0, cam, t, None))
+                if scam is not None:
+                    _views.append(_View(i, i, 1, scam, t, None))
+        self.views = _views
+        by_pair = {}
+        for k, v in enumerate(self.views):
+            by_pair.setdefault(v.pair, {})[v.role] = k
+        for k, v in enumerate(self.views):
+            v.mate = by_pair[v.pair].get(1 - v.role)
+            v.slot = k
+        self.slab = FlatGradSlab(model.parameters(), getattr(optimizer, "padded_numel", 0))
         if fused is not None:
-            slot = iter(range(10 ** 9))
-            self._slots = [(next(slot), next(slot) if sc is not None else None) for _, sc, _ in self.pairs]
-            assert len(fused.slots) >= 2 * len(self.pairs), "FusedRasterizer needs one slot per view of the step"
+            assert len(fused.slots) >= len(self.views), "FusedRasterizer needs one slot per view of the step"
         self.render = render_fn
         self.last_stats = {}
+        self.overflow_check_every = int(overflow_check_every)
+        self._steps_since_check = 0
+        self._recv_img = {}               # primary view index -> persistent receive buffer for the partner's image
+        self._recv_grad = {}              # shifted view index -> persistent receive buffer for d(loss)/d(image)
         # Pipelined data-parallel tail (fused path + FusedAdam): compute_grads() stops after the blend backward;
         # reduce_and_update() then walks K Gaussian ranges -- chain rule of range r+1 overlaps the all-reduce of
         # range r, Adam of range r overlaps the all-reduce of range r+1 -- instead of accumulate -> all-reduce ->
@@ -192,18 +376,60 @@ class ViewShardedStep:
         self.pipeline_ranges = int(pipeline_ranges) if (fused is not None and isinstance(optimizer, FusedAdam)) else 0
         self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges > 1 else None
 
+    @classmethod
+    def from_global(cls, model, global_pairs, bg, rank: Optional[int] = None, world: Optional[int] = None, **kw):
+        """View-granular sharding of the GLOBAL pair list (identical on every rank): this rank takes block `rank` of
+        assign_views().  Pair indices handed to the loss / gradient callbacks are GLOBAL."""
+        group = kw.get("group")
+        if world is None:
+            world = dist.get_world_size(group) if _dist_on() else 1
+        if rank is None:
+            rank = dist.get_rank(group) if _dist_on() else 0
+        blocks = assign_views([scam is not None for _, scam, _ in global_pairs], world)
+        owner = {v: r for r, blk in enumerate(blocks) for v in blk}
+        views = []
+        for (i, role) in blocks[rank]:
+            cam, scam, t = global_pairs[i]
+            peer = owner.get((i, 1 - role))
+            views.append(_View(i, i, role, cam if role == 0 else scam, t, None if peer in (None, rank) else peer))
+        st = cls(model, [], bg, _views=views, **kw)
+        st.global_pairs, st.rank, st.world, st.blocks = list(global_pairs), rank, world, blocks
+        return st
+
+    # ---- the iteration ------------------------------------------------------------------------------------
     def step(self, pair_grad_fn=None, loss_fn=None, batch_loss_fn=None):
-        """batch_loss_fn([(pair_index, camera, pkg, shifted_pkg, trans_dist), ...]) -> scalar: all pairs' loss in one
-        call (fused path only; e.g. fused_loss.binocular_loss_fused_batch)."""
         n = self.compute_grads(pair_grad_fn, loss_fn, batch_loss_fn)
         self.reduce_and_update()
+        self._steps_since_check += 1
+        if self.fused is not None and self.overflow_check_every > 0 and \
+                self._steps_since_check >= self.overflow_check_every and not torch.cuda.is_current_stream_capturing():
+            self.check_capacity()
         return n
 
+    def check_capacity(self):
+        """The persistent binning buffers hold `capacity` tile instances per view; a view with more renders (and
+        back-propagates) a truncated list.  The largest N seen since the last check is kept on the device
+        (FusedRasterizer.high_water): one small read-back here -- every `overflow_check_every` steps, at every
+        densification, at resize -- grows the buffers and raises, so the caller never trains on truncated lists
+        unknowingly.  (The reference sizes the binning buffer from N on every render: one host sync per view.)"""
+        self._steps_since_check = 0
+        if self.fused is None:
+            return
+        over = self.fused.check_overflow()
+        if over:
+            from . import _lib
+            raise _lib.B3gsError(f"B3GS_ERR_CAPACITY: a view needed {over} tile instances, the binning buffers held "
+                                 f"fewer; they have been grown to {self.fused.capacity} -- repeat the steps since the "
+                                 f"last check (at most {self.overflow_check_every})")
+
     def reduce_and_update(self):
-        """The exchange step of the data-parallel path (one all-reduce of the flat slab) + optimiser."""
+        """The exchange step of the data-parallel path (one collective over the flat slab) + optimiser."""
         if self.range_slab is not None:
             return self._reduce_and_update_pipelined()
-        self.slab.all_reduce(self.average)
+        if isinstance(self.optimizer, ShardedAdam):
+            self.slab.rebind()
+            return self.optimizer.step(self.slab, average=self.average)
+        self.slab.all_reduce(self.average, self.group)
         if self.optimizer is not None:
             self.slab.rebind()
             self.optimizer.step()
@@ -214,10 +440,18 @@ class ViewShardedStep:
         on the device (densify.densify_and_prune) and everything sized by P -- gradient slab, rasterizer
         slots -- is re-created.  Any HIP graph captured around step() must be re-captured afterwards."""
         from .densify import densify_and_prune
+        group = group if group is not None else self.group
+        self.check_capacity()
         self.sync_densify_stats(group)
+        if noise is None and generator is None and _dist_on() and dist.get_world_size(group) > 1:
+            # the split offsets must be the same on every replica (scene/gaussian_model.py:364 draws them from the
+            # device RNG): rank 0 draws, everybody else receives
+            P, dev = self.model.get_xyz.shape[0], self.model.get_xyz.device
+            noise = torch.randn((2, P, 3), device=dev) if dist.get_rank(group) == 0 else torch.empty((2, P, 3), device=dev)
+            dist.broadcast(noise, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         newP = densify_and_prune(self.model, self.optimizer, max_grad, min_opacity, extent, max_screen_size,
                                  percent_dense, noise, generator)
-        self.slab = FlatGradSlab(self.model.parameters())
+        self.slab = FlatGradSlab(self.model.parameters(), getattr(self.optimizer, "padded_numel", 0))
         if self.range_slab is not None:
             self.range_slab = RangeGradSlab(self.model.parameters(), self.pipeline_ranges)
         if self.fused is not None:
@@ -227,7 +461,8 @@ class ViewShardedStep:
     def _reduce_and_update_pipelined(self, group=None):
         from . import _lib
         rs, fr, opt = self.range_slab, self.fused, self.optimizer
-        collective = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.slab.force_collective)
+        group = group if group is not None else self.group
+        collective = _dist_on() and (dist.get_world_size(group) > 1 or self.slab.force_collective)
         works = []
         for r in range(rs.K):
             first, count = rs.rows(r)
@@ -251,19 +486,36 @@ class ViewShardedStep:
         (SURVEY 8e): sums of xyz_gradient_accum / denom, maximum of max_radii2D.  Call it every
         densification interval, not every step."""
         m = self.model
-        if not (dist.is_available() and dist.is_initialized()) or getattr(m, "denom", None) is None:
+        if not _dist_on() or getattr(m, "denom", None) is None:
             return
+        group = group if group is not None else self.group
         dist.all_reduce(m.xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(m.denom, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX, group=group)
 
+    # ---- rendering + pixel gradients --------------------------------------------------------------------------
+    def _exchange(self, sends, recvs):
+        """Point-to-point messages of the split pairs: [(tensor, peer)] each way, one batch (deadlock-free)."""
+        if not sends and not recvs:
+            return
+        ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in sends] + \
+              [dist.P2POp(dist.irecv, t, p, self.group) for t, p in recvs]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    def _render_views(self):
+        if self.fused is not None:
+            return self.fused.render_batch([(v.cam, v.slot, v.role == 0) for v in self.views], self.bg)
+        return [self.render(v.cam, self.model, self.pipe, self.bg) for v in self.views]
+
     def compute_grads(self, pair_grad_fn=None, loss_fn=None, batch_loss_fn=None):
-        """Render this rank's views forward+backward; leaves the summed gradients in the slab.  Contains
-        no collective, no host sync and (fused path) no allocation: capturable as one HIP graph."""
+        """Render this rank's views forward+backward; leaves the summed gradients in the slab.  Without split
+        pairs it contains no communication, no host sync and (fused path) no allocation: capturable as one HIP
+        graph."""
         assert sum(f is not None for f in (pair_grad_fn, loss_fn, batch_loss_fn)) == 1
         assert batch_loss_fn is None or self.fused is not None
-        if not self.pairs:
-            # a rank without views (more ranks than pairs) contributes zeros to the all-reduce
+        if not self.views:
+            # a rank without views (more ranks than views) contributes zeros to the collective
             self.slab.zero()
             if self.range_slab is not None:
                 self.range_slab.flat.zero_()
@@ -273,62 +525,96 @@ class ViewShardedStep:
         if self.fused is not None:
             # the fused multi-view accumulate STORES the gradients: no zero-fill of the slab
             self.slab.rebind()
-            n_rendered = self._step_fused(pair_grad_fn, loss_fn, batch_loss_fn)
+            self.fused.begin_deferred()
         else:
             self.slab.zero()
-            n_rendered = 0
-            for i, (cam, scam, t) in enumerate(self.pairs):
-                pkg = self.render(cam, self.model, self.pipe, self.bg)
-                spkg = self.render(scam, self.model, self.pipe, self.bg) if scam is not None else None
-                n_rendered += 1 + (scam is not None)
-                if loss_fn is not None:
-                    loss_fn(i, cam, pkg, spkg, t).backward()
-                else:
-                    outs, grads = zip(*pair_grad_fn(i, pkg, spkg))
-                    torch.autograd.backward(list(outs), list(grads))
-        self.last_stats = {"views": n_rendered}
-        return n_rendered
-
-    def _step_fused(self, pair_grad_fn, loss_fn, batch_loss_fn=None):
-        """All views of the step in one render_batch() (binning concurrent, one blend launch), the loss /
-        upstream gradients of every pair formed on the current stream, ONE backward call (one blend-
-        backward launch for all views), then one per-Gaussian pass for all views (finish_deferred)."""
-        views = []
-        for i, (cam, scam, t) in enumerate(self.pairs):
-            a, b = self._slots[i]
-            views.append((cam, a, True))      # densification statistics come from the primary view only
-            if scam is not None:             # (train.py:102-104,128: the shifted render's are discarded)
-                views.append((scam, b, False))
-        self.fused.begin_deferred()
-        pkgs = iter(self.fused.render_batch(views, self.bg))
-        outs, grads, total = [], [], None
-        if batch_loss_fn is not None:
-            items = []
-            for i, (cam, scam, t) in enumerate(self.pairs):
-                pkg = next(pkgs)
-                items.append((i, cam, pkg, next(pkgs) if scam is not None else None, t))
-            batch_loss_fn(items).backward()
+        pkgs = self._render_views()
+        outs, grads = [], []
+        if pair_grad_fn is not None:
+            for k, v in enumerate(self.views):
+                if v.role == 1 and v.mate is not None:
+                    continue                                  # handled together with its primary
+                prim = pkgs[k] if v.role == 0 else None
+                shif = pkgs[v.mate] if (v.role == 0 and v.mate is not None) else (pkgs[k] if v.role == 1 else None)
+                for o, g in pair_grad_fn(v.key, prim, shif):
+                    outs.append(o)
+                    grads.append(g)
+        else:
+            outs, grads = self._loss_pixel_grads(pkgs, loss_fn, batch_loss_fn)
+        if outs:
+            torch.autograd.backward(outs, grads)
+        if self.fused is not None:
             if self.range_slab is None:
                 self.fused.finish_deferred(overwrite=True)
-            else:
+            else:   # reduce_and_update() runs the chain rule range by range
                 self._pending_views = self.fused.take_deferred()
-            return len(views)
-        for i, (cam, scam, t) in enumerate(self.pairs):
-            pkg = next(pkgs)
-            spkg = next(pkgs) if scam is not None else None
-            if loss_fn is not None:
-                li = loss_fn(i, cam, pkg, spkg, t)
-                total = li if total is None else total + li
+        self.last_stats = {"views": len(self.views)}
+        return len(self.views)
+
+    def _loss_pixel_grads(self, pkgs, loss_fn, batch_loss_fn):
+        """Loss of every pair whose INPUT view lives here, on detached leaves of the rendered images; returns the
+        rasterizer outputs of the local views with their pixel gradients.  Split pairs: the partner's image is
+        received before the loss, its gradient sent back afterwards (and vice versa for a local shifted view whose
+        input view is remote)."""
+        def leaf(t):
+            return t.detach().requires_grad_(True)
+
+        dev = self.bg.device
+        H, W = pkgs[0]["render"].shape[-2:]
+        sends, recvs = [], []
+        for k, v in enumerate(self.views):
+            if v.peer is None:
+                continue
+            if v.role == 1:
+                sends.append((pkgs[k]["render"].detach(), v.peer))
             else:
-                o, g = zip(*pair_grad_fn(i, pkg, spkg))
-                outs += list(o)
-                grads += list(g)
-        if loss_fn is not None:
+                if k not in self._recv_img:
+                    self._recv_img[k] = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+                recvs.append((self._recv_img[k], v.peer))
+        self._exchange(sends, recvs)
+        leaves, items = {}, []
+        for k, v in enumerate(self.views):
+            if v.role != 0:
+                continue
+            lp = dict(pkgs[k])
+            for name in ("render", "rendered_depth", "rendered_alpha"):
+                lp[name] = leaf(pkgs[k][name])
+            leaves[k] = lp
+            sp = None
+            if v.mate is not None:
+                sp = dict(pkgs[v.mate])
+                sp["render"] = leaf(pkgs[v.mate]["render"])
+                leaves[v.mate] = sp
+            elif v.peer is not None:
+                sp = {"render": leaf(self._recv_img[k])}
+                leaves[("remote", k)] = sp
+            items.append((v.key, v.cam, lp, sp, v.t))
+        if items:
+            total = batch_loss_fn(items) if batch_loss_fn is not None else sum(loss_fn(*it) for it in items)
             total.backward()
-        else:
-            torch.autograd.backward(outs, grads)
-        if self.range_slab is None:
-            self.fused.finish_deferred(overwrite=True)
-        else:   # reduce_and_update() runs the chain rule range by range
-            self._pending_views = self.fused.take_deferred()
-        return len(views)
+        sends, recvs = [], []
+        for k, v in enumerate(self.views):
+            if v.peer is None:
+                continue
+            if v.role == 0:
+                g = leaves[("remote", k)]["render"].grad
+                sends.append((g if g is not None else torch.zeros((3, H, W), dtype=torch.float32, device=dev), v.peer))
+            else:
+                if k not in self._recv_grad:
+                    self._recv_grad[k] = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+                recvs.append((self._recv_grad[k], v.peer))
+        self._exchange(sends, recvs)
+        outs, grads = [], []
+        for k, v in enumerate(self.views):
+            if v.role == 1 and v.peer is not None:
+                outs.append(pkgs[k]["render"])
+                grads.append(self._recv_grad[k])
+                continue
+            lp = leaves.get(k)
+            if lp is None:
+                continue
+            for name in (("render", "rendered_depth", "rendered_alpha") if v.role == 0 else ("render",)):
+                if lp[name].grad is not None:
+                    outs.append(pkgs[k][name])
+                    grads.append(lp[name].grad)
+        return outs, grads

@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE: HIP-vs-oracle metrics at BASELINE.json's full sizes (shared by tests/test_gpu_fullsize_oracle.py
+and tools/fullsize_report.py).  Two legs, both against oracle/tile_ref.c on the same seeded synth scene:
+
+  dropin_metrics   the reference-shaped surface (_C.rasterize_gaussians[_backward], reference binning rule):
+                   integer state bit-exact, images, eight gradient tensors
+  fused_metrics    the BENCHMARKED path (FusedRasterizer: raw parameters, in-kernel activations, batched launches,
+                   shared depth sort, tight binning, multi-view chain rule, densification statistics): images per
+                   view, parameter gradients summed over the views, statistics, and the structure of the tight tile
+                   lists (order-preserving subsequence of the oracle's lists; every dropped entry has
+                   alpha < 1/255 at every pixel of its tile)
+
+The oracle gets torch-activated inputs (sigmoid / exp / normalize / cat on the CPU, float32): the same bits the
+drop-in path receives; the fused path evaluates the activations in-kernel (1-ulp differences).
+"""
+import math
+
+import numpy as np
+import torch
+
+from helpers import rel_l2
+
+GRAD_KEYS = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+
+
+def view_set(W, H, fov, views):
+    """views == 6: BASELINE.md section 3 (3 input + 3 binocular-shifted);  8: config 5 (YAWS_8 input views, the first
+    four with a binocular partner are not needed: 8 input views, no partners)."""
+    from binocular3dgs_amd import synth
+    if views == 8:
+        return [(c, None, 0.0) for c in synth.synth_cameras(W, H, fovx_deg=fov, yaws=synth.YAWS_8, device="cuda")]
+    return synth.synth_view_set(W, H, fovx_deg=fov, device="cuda")
+
+
+def activated(model):
+    """CPU float32 activated inputs (what render() hands the rasterizer)."""
+    with torch.no_grad():
+        return dict(means3D=model.get_xyz.detach().cpu(), opacities=model.get_opacity.detach().cpu(),
+                    scales=model.get_scaling.detach().cpu(), rotations=model.get_rotation.detach().cpu(),
+                    shs=model.get_features.detach().cpu())
+
+
+def oracle_kw(act, cam, bg, W, H, sh_degree):
+    return dict(means3D=act["means3D"].numpy(), opacities=act["opacities"].numpy(), scales=act["scales"].numpy(),
+                rotations=act["rotations"].numpy(), shs=act["shs"].numpy(),
+                viewmatrix=cam.world_view_transform.cpu().numpy(), projmatrix=cam.full_proj_transform.cpu().numpy(),
+                campos=cam.camera_center.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H,
+                tanfovx=math.tan(cam.FoVx / 2), tanfovy=math.tan(cam.FoVy / 2), sh_degree=sh_degree)
+
+
+def image_err(got, ref):
+    """(max, fraction above the 2e-5 band) of |got - ref| / (1 + |ref|)"""
+    err = np.abs(got - ref) / (1 + np.abs(ref))
+    return float(err.max()), float((err > 2e-5).mean())
+
+
+def dropin_metrics(P, W, H, fov=60.0, seed=0, yaw=3.0):
+    from oracle import tile_ref
+    from binocular3dgs_amd import _C, synth
+    from binocular3dgs_amd.debug import state_views
+    model = synth.synth_model(P, seed=seed, device="cpu", width=W, height=H, fovx_deg=fov, requires_grad=False)
+    cam = synth.synth_cameras(W, H, fovx_deg=fov, yaws=(yaw,), device="cpu")[0]
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    act = activated(model)
+    st = tile_ref.forward(**oracle_kw(act, cam, bg, W, H, 1))
+    g = {k: v.cuda() for k, v in act.items()}
+    e = torch.empty(0, device="cuda")
+    vm, pm, cp, bgd = (cam.world_view_transform.cuda(), cam.full_proj_transform.cuda(), cam.camera_center.cuda(),
+                       bg.cuda())
+    tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    n, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
+        bgd, g["means3D"], e, g["opacities"], g["scales"], g["rotations"], 1.0, e, vm, pm, tfx, tfy, H, W, g["shs"], 1,
+        cp, False, False)
+    v = state_views(P, W, H, n, geom, binning, img)
+    m = dict(P=P, W=W, H=H, N=int(st.N), V=int((st.radii > 0).sum()))
+    m["n_equal"] = int(n) == int(st.N)
+    m["radii_equal"] = bool(np.array_equal(radii.cpu().numpy(), st.radii))
+    m["tiles_touched_equal"] = bool(np.array_equal(v["tiles_touched"].cpu().numpy().astype(np.uint32), st.tiles_touched))
+    m["point_list_equal"] = bool(np.array_equal(v["point_list"].cpu().numpy().astype(np.uint32), st.point_list))
+    m["tile_ids_equal"] = bool(np.array_equal(v["tile_ids"].cpu().numpy().astype(np.uint64), st.keys >> np.uint64(32)))
+    m["ranges_equal"] = bool(np.array_equal(v["ranges"].cpu().numpy().astype(np.uint32), st.ranges))
+    vis = st.radii > 0
+    rec = v["records"].cpu().numpy()
+    m["records_equal"] = bool(np.array_equal(rec[vis, 0:2], st.means2D[vis]) and
+                              np.array_equal(rec[vis][:, [2, 3, 4, 5]], st.conic_opacity[vis]) and
+                              np.array_equal(rec[vis][:, [6, 7, 8]], st.rgb[vis]) and
+                              np.array_equal(rec[vis, 9], st.depths[vis]))
+    for name, got, ref in (("color", color, st.color), ("depth", depth, st.depth), ("alpha", alpha, st.alpha)):
+        m[name + "_max"], m[name + "_frac"] = image_err(got.cpu().numpy(), ref)
+    m["n_contrib_frac"] = float((v["n_contrib"].cpu().numpy().astype(np.uint32) != st.n_contrib).mean())
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=seed)
+    ref = tile_ref.backward(st, gc.numpy(), gd.numpy(), ga.numpy())
+    res = _C.rasterize_gaussians_backward(bgd, g["means3D"], radii, e, g["scales"], g["rotations"], 1.0, e, vm, pm, tfx,
+                                          tfy, gc.cuda(), gd.cuda(), ga.cuda(), g["shs"], 1, cp, geom, n, binning, img,
+                                          alpha, False)
+    for k, t in zip(GRAD_KEYS, res):
+        m[k] = rel_l2(t.cpu().numpy(), ref[k])
+    return m
+
+
+def _tight_list_metrics(P, W, H, st, fv, radii_hip):
+    """Structure of the tight tile lists of one view against the oracle's full lists (device tensors, int64)."""
+    dev = "cuda"
+    agree = torch.from_numpy(st.radii).to(dev) == radii_hip          # Gaussians whose integer radius agrees
+    o_pl = torch.from_numpy(st.point_list.astype(np.int64)).to(dev)
+    o_tile = torch.from_numpy((st.keys >> np.uint64(32)).astype(np.int64)).to(dev)
+    t_pl, t_tile = fv["point_list"].to(torch.int64), fv["tile_ids"].to(torch.int64)
+    o_keep, t_keep = agree[o_pl], agree[t_pl]
+    o_pl, o_tile, t_pl, t_tile = o_pl[o_keep], o_tile[o_keep], t_pl[t_keep], t_tile[t_keep]
+    o_key, t_key = o_tile * P + o_pl, t_tile * P + t_pl                # (tile, Gaussian) is unique inside a list
+    so, perm = torch.sort(o_key)
+    idx = torch.searchsorted(so, t_key).clamp(max=so.numel() - 1)
+    member = so[idx] == t_key
+    pos = perm[idx]
+    out = dict(radius_flips=int((~agree).sum()), N_tight=int(fv["point_list"].numel()), N_oracle=int(st.N),
+               subset=bool(member.all()), order_preserved=bool((pos[1:] > pos[:-1]).all()))
+    present = torch.zeros(o_key.numel(), dtype=torch.bool, device=dev)
+    present[pos[member]] = True
+    d_pl, d_tile = o_pl[~present], o_tile[~present]
+    out["dropped"] = int(d_pl.numel())
+    # largest alpha any dropped entry reaches at any pixel of its tile, from the oracle's own per-Gaussian record
+    m2d = torch.from_numpy(st.means2D).to(dev).double()
+    co = torch.from_numpy(st.conic_opacity).to(dev).double()
+    gx = (W + 15) // 16
+    ox = torch.arange(16, device=dev, dtype=torch.float64)
+    worst = 0.0
+    for c0 in range(0, d_pl.numel(), 400_000):
+        g_, t_ = d_pl[c0:c0 + 400_000], d_tile[c0:c0 + 400_000]
+        px = ((t_ % gx) * 16).double()[:, None] + ox[None, :]          # [n,16] pixel x of the tile's columns
+        py = ((t_ // gx) * 16).double()[:, None] + ox[None, :]
+        inx, iny = px < W, py < H
+        dx = (m2d[g_, 0][:, None] - px)[:, None, :]                    # [n,1,16]
+        dy = (m2d[g_, 1][:, None] - py)[:, :, None]                    # [n,16,1]
+        c = co[g_]
+        power = -0.5 * (c[:, 0, None, None] * dx * dx + c[:, 2, None, None] * dy * dy) - c[:, 1, None, None] * dx * dy
+        a = c[:, 3, None, None] * torch.exp(power.clamp(max=0.0))
+        a = torch.where((power > 0) | ~(iny[:, :, None] & inx[:, None, :]), torch.zeros_like(a), a)
+        worst = max(worst, float(a.max()) if a.numel() else 0.0)
+    out["dropped_max_alpha_x255"] = worst * 255.0
+    return out
+
+
+def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
+    """All views of one iteration through FusedRasterizer.render_batch (the bench.py path) against the oracle."""
+    from oracle import tile_ref
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.debug import state_views
+    from binocular3dgs_amd.fused import FusedRasterizer
+    dev = "cuda"
+    model = synth.synth_model(P, seed=seed, device=dev, width=W, height=H, fovx_deg=fov)
+    model.init_densification_stats()
+    pairs = view_set(W, H, fov, views)
+    bg = torch.zeros(3, device=dev)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=seed, device=dev)
+    gc2 = synth.synth_pixel_grads(W, H, seed=100 + seed, device=dev)[0]
+    vlist, slot = [], 0
+    for cam, scam, _t in pairs:
+        vlist.append((cam, slot, True, (gc, gd, ga)))
+        slot += 1
+        if scam is not None:
+            vlist.append((scam, slot, False, (gc2, None, None)))
+            slot += 1
+    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=True)
+    with torch.no_grad():                              # size the persistent binning buffers for this scene
+        fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
+        while fr.overflowed():
+            fr.grow()
+            fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    outs = fr.render_batch([(c, s, st_) for c, s, st_, _ in vlist], bg)
+    o_t, g_t = [], []
+    for o, (_, _, _, (a, b, c)) in zip(outs, vlist):
+        o_t.append(o["render"]); g_t.append(a)
+        if b is not None:
+            o_t += [o["rendered_depth"], o["rendered_alpha"]]
+            g_t += [b, c]
+    torch.autograd.backward(o_t, g_t)
+    torch.cuda.synchronize()
+    nr = fr.num_rendered()
+    assert max(nr) <= fr.capacity, "binning capacity overflow"
+    m = dict(P=P, W=W, H=H, views=len(vlist), N_binned=nr)
+
+    act = activated(model)
+    acc = {k: np.zeros(tuple(act[n].shape), np.float64) for k, n in
+           (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"),
+            ("dL_drotations", "rotations"), ("dL_dsh", "shs"))}
+    st_norm = np.zeros(P, np.float64)
+    st_cnt = np.zeros(P, np.float64)
+    st_rad = np.zeros(P, np.float64)
+    per_view = []
+    for k, ((cam, s, is_primary, (a, b, c)), o) in enumerate(zip(vlist, outs)):
+        st = tile_ref.forward(**oracle_kw(act, cam, bg, W, H, 1))
+        pv = dict(N_oracle=int(st.N))
+        radii = o["radii"]
+        pv["radius_flips"] = int((radii.cpu().numpy() != st.radii).sum())
+        for name, key, ref in (("color", "render", st.color), ("depth", "rendered_depth", st.depth),
+                               ("alpha", "rendered_alpha", st.alpha)):
+            pv[name + "_max"], pv[name + "_frac"] = image_err(o[key].detach().cpu().numpy(), ref)
+        sl = fr.slots[s]
+        # the slot's binning buffer is carved for `capacity` instances (that fixes where the tile-id array of the
+        # two-word layout starts); the first N entries are the lists
+        fv = state_views(P, W, H, sl.capacity, sl.geom, sl.binning, sl.img)
+        fv["point_list"], fv["tile_ids"] = fv["point_list"][:nr[s]], fv["tile_ids"][:nr[s]]
+        if check_lists and (k < 2 or k == len(vlist) - 1):
+            pv["lists"] = _tight_list_metrics(P, W, H, st, fv, radii)
+        ref = tile_ref.backward(st, a.cpu().numpy(), None if b is None else b.cpu().numpy(),
+                                None if c is None else c.cpu().numpy())
+        for kk in acc:
+            acc[kk] += ref[kk].astype(np.float64).reshape(acc[kk].shape)
+        pv["dL_dmeans2D"] = rel_l2(sl.means2D_grad.cpu().numpy(), ref["dL_dmeans2D"])
+        if is_primary:
+            vis = st.radii > 0
+            st_norm[vis] += np.linalg.norm(ref["dL_dmeans2D"][vis, :2].astype(np.float64), axis=1)
+            st_cnt[vis] += 1
+            st_rad[vis] = np.maximum(st_rad[vis], st.radii[vis])
+        per_view.append(pv)
+    m["per_view"] = per_view
+    # chain rule of the activations (fp64 autograd on the CPU) applied to the oracle's summed gradients
+    raw = {n: getattr(model, "_" + n).detach().cpu().double().requires_grad_(True)
+           for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    acts = [raw["xyz"], torch.sigmoid(raw["opacity"]), torch.exp(raw["scaling"]),
+            torch.nn.functional.normalize(raw["rotation"]), torch.cat((raw["features_dc"], raw["features_rest"]), 1)]
+    torch.autograd.backward(acts, [torch.from_numpy(acc[k]) for k in
+                                   ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
+    for n in raw:
+        got = getattr(model, "_" + n).grad
+        if got.numel():
+            m["grad_" + n] = rel_l2(got.cpu().numpy(), raw[n].grad.numpy())
+    m["stat_accum"] = rel_l2(model.xyz_gradient_accum.cpu().numpy().ravel(), st_norm)
+    m["stat_denom_mismatch"] = int((model.denom.cpu().numpy().ravel() != st_cnt).sum())
+    m["stat_max_radii_mismatch"] = int((model.max_radii2D.cpu().numpy().ravel() != st_rad).sum())
+    return m

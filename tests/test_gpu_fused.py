@@ -47,14 +47,17 @@ def test_fused_equals_dropin(K):
     assert not fr.overflowed()
     # activations are evaluated by different code (torch vs in-kernel expf): allow borderline radius flips
     assert float((out["radii"] != ref_radii).float().mean()) < 1e-3
+    # the stated contract (tests/test_gpu_parity.py): images within 2e-5 (1 + |x|), apart from pixels where the 1-ulp
+    # activation difference flips a 1/255-rule decision (at most one minimal contribution, a handful of pixels)
     for a, b in zip((out["render"], out["rendered_depth"], out["rendered_alpha"]), ref_img):
-        assert float((a - b).abs().max()) < 5e-4
+        err = ((a - b).abs() / (1 + b.abs())).detach()
+        assert int((err > 2e-5).sum()) <= 3 and float(err.max()) <= 10.0 / 255, (float(err.max()), int((err > 2e-5).sum()))
     names = ["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"]
     for n, p, r in zip(names, model.parameters(), ref):
         if r.numel() == 0:
             continue
-        assert rel_l2(p.grad.cpu().numpy(), 2.0 * r.cpu().numpy()) < 2e-3, n
-    assert rel_l2(out["viewspace_points_grad"].cpu().numpy(), ref_m2d.cpu().numpy()) < 2e-3
+        assert rel_l2(p.grad.cpu().numpy(), 2.0 * r.cpu().numpy()) < 2e-4, n
+    assert rel_l2(out["viewspace_points_grad"].cpu().numpy(), ref_m2d.cpu().numpy()) < 2e-4
     for sl in fr.slots:
         assert float(sl.scratch.abs().max()) == 0.0, "scratch must be left clean"
 
@@ -78,7 +81,7 @@ def test_step_with_fused_path_matches_dropin_step():
         st.step(pair_grad_fn=grad_fn)      # slab zeroed between steps
         torch.cuda.synchronize()
         flats.append(st.slab.flat.clone())
-    assert rel_l2(flats[1].cpu().numpy(), flats[0].cpu().numpy()) < 2e-3
+    assert rel_l2(flats[1].cpu().numpy(), flats[0].cpu().numpy()) < 2e-4
 
 
 def test_schedules_give_the_same_gradients():
@@ -186,7 +189,7 @@ def test_densification_statistics_match_reference_formula():
     same = got[2].reshape(-1) == ref.denom.reshape(-1)
     assert float(same.float().mean()) > 0.999
     assert float(got[2].max()) == 2.0 * len(pairs)
-    assert rel_l2(got[1].reshape(-1)[same].cpu().numpy(), ref.xyz_gradient_accum.reshape(-1)[same].cpu().numpy()) < 2e-3
+    assert rel_l2(got[1].reshape(-1)[same].cpu().numpy(), ref.xyz_gradient_accum.reshape(-1)[same].cpu().numpy()) < 2e-4
     assert float((got[0][same] != ref.max_radii2D[same]).float().mean()) < 1e-3
 
 
