@@ -140,6 +140,16 @@ int debug_sync(const B3gsScene* sc, hipStream_t s, const char* what) {
 
 }  // namespace
 
+int b3gs_fail(int code, const char* what, const char* detail) {
+  snprintf(g_err, sizeof(g_err), "%s%s%s", what ? what : "", (what && detail) ? ": " : "", detail ? detail : "");
+  return code;
+}
+
+int b3gs_launch_status(const char* what) {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? B3GS_OK : b3gs_fail(B3GS_ERR_HIP, what, hipGetErrorString(e));
+}
+
 extern "C" {
 
 int b3gs_abi_version(void) { return B3GS_ABI_VERSION; }

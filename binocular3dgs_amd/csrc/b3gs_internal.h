@@ -143,6 +143,12 @@ struct SceneX {
 
 #define B3GS_MAX_FUSED_VIEWS 8
 
+// ---- error reporting shared by every translation unit (api.hip owns the thread-local message) -------
+// b3gs_fail: store the message b3gs_last_error() returns and hand back `code`;
+// b3gs_launch_status: B3GS_OK, or B3GS_ERR_HIP with "<what>: <hip error string>" when a launch / runtime call failed
+int b3gs_fail(int code, const char* what, const char* detail);
+int b3gs_launch_status(const char* what);
+
 // ---- launchers implemented in the individual .hip files -----------------------------------
 // (all enqueue on `s`, none synchronise)
 

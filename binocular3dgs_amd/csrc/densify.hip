@@ -109,10 +109,10 @@ __global__ void __launch_bounds__(256)
 }
 
 int check_io(const B3gsDensifyIO* io) {
-  if (!io || io->P < 0 || io->M < 1) return B3GS_ERR_ARG;
+  if (!io || io->P < 0 || io->M < 1) return b3gs_fail(B3GS_ERR_ARG, "densify", "NULL io, negative P or M < 1");
   for (int t = 0; t < 6; t++)
-    if (!io->param[t] && !(t == 2 && io->M == 1) && io->P > 0) return B3GS_ERR_ARG;
-  if (io->P > 0 && (!io->xyz_gradient_accum || !io->denom)) return B3GS_ERR_ARG;
+    if (!io->param[t] && !(t == 2 && io->M == 1) && io->P > 0) return b3gs_fail(B3GS_ERR_ARG, "densify", "NULL parameter tensor");
+  if (io->P > 0 && (!io->xyz_gradient_accum || !io->denom)) return b3gs_fail(B3GS_ERR_ARG, "densify", "NULL statistics array");
   return B3GS_OK;
 }
 
@@ -122,9 +122,9 @@ extern "C" int b3gs_densify_classify(const B3gsDensifyIO* io, int32_t* flags, b3
   int rc = check_io(io);
   if (rc) return rc;
   if (io->P == 0) return B3GS_OK;
-  if (!flags) return B3GS_ERR_ARG;
+  if (!flags) return b3gs_fail(B3GS_ERR_ARG, "b3gs_densify_classify", "flags is NULL");
   hipLaunchKernelGGL(densify_classify_kernel, dim3((io->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *io, flags);
-  return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
+  return b3gs_launch_status("b3gs_densify_classify");
 }
 
 extern "C" int b3gs_densify_scatter(const B3gsDensifyIO* io, const int32_t* flags, const int32_t* off_keep,
@@ -136,16 +136,18 @@ extern "C" int b3gs_densify_scatter(const B3gsDensifyIO* io, const int32_t* flag
   if (io->P == 0) return B3GS_OK;
   if (!flags || !off_keep || !off_clone || !off_split || !out_param || n_keep < 0 || n_clone < 0 || n_split < 0 ||
       (n_split > 0 && !noise))
-    return B3GS_ERR_ARG;
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_densify_scatter", "NULL flags / offsets / outputs, negative count, or split without noise");
   Outs o;
   for (int t = 0; t < 6; t++) {
     o.param[t] = out_param[t];
     o.exp_avg[t] = out_exp_avg ? out_exp_avg[t] : nullptr;
     o.exp_avg_sq[t] = out_exp_avg_sq ? out_exp_avg_sq[t] : nullptr;
-    if (!o.param[t] && !(t == 2 && io->M == 1) && (n_keep + n_clone + n_split) > 0) return B3GS_ERR_ARG;
-    if ((o.exp_avg[t] == nullptr) != (o.exp_avg_sq[t] == nullptr)) return B3GS_ERR_ARG;
+    if (!o.param[t] && !(t == 2 && io->M == 1) && (n_keep + n_clone + n_split) > 0)
+      return b3gs_fail(B3GS_ERR_ARG, "b3gs_densify_scatter", "NULL output parameter tensor");
+    if ((o.exp_avg[t] == nullptr) != (o.exp_avg_sq[t] == nullptr))
+      return b3gs_fail(B3GS_ERR_ARG, "b3gs_densify_scatter", "exp_avg / exp_avg_sq outputs must both be given or both be NULL");
   }
   hipLaunchKernelGGL(densify_scatter_kernel, dim3((io->P + 255) / 256), dim3(256), 0, (hipStream_t)stream, *io, flags,
                      off_keep, off_clone, off_split, n_keep, n_clone, n_split, noise, o);
-  return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
+  return b3gs_launch_status("b3gs_densify_scatter");
 }

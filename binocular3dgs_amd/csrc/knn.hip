@@ -146,7 +146,8 @@ size_t carve_ws(char* base, int32_t P, KnnWs* w) {
 extern "C" size_t b3gs_knn_workspace_bytes(int32_t P) { return carve_ws(nullptr, P, nullptr); }
 
 extern "C" int b3gs_knn_mean_dist2(int32_t P, const float* points, float* mean_dist2, char* workspace, b3gs_stream_t stream) {
-  if (P < 0 || (P > 0 && (!points || !mean_dist2 || !workspace))) return B3GS_ERR_ARG;
+  if (P < 0 || (P > 0 && (!points || !mean_dist2 || !workspace)))
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_knn_mean_dist2", "negative P or NULL points / output / workspace");
   if (P == 0) return B3GS_OK;
   hipStream_t s = (hipStream_t)stream;
   KnnWs w;
@@ -158,5 +159,5 @@ extern "C" int b3gs_knn_mean_dist2(int32_t P, const float* points, float* mean_d
   const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
   hipLaunchKernelGGL(box_kernel, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, w.sval[0], w.sorted, w.boxes);
   hipLaunchKernelGGL(knn3_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, w.sorted, w.sval[0], w.boxes, nboxes, mean_dist2);
-  return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
+  return b3gs_launch_status("b3gs_knn_mean_dist2");
 }

@@ -380,7 +380,8 @@ extern "C" int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream) {
 }
 
 extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, b3gs_stream_t stream) {
-  if (npairs <= 0 || npairs > B3GS_MAX_FUSED_VIEWS || !ios) return B3GS_ERR_ARG;
+  if (npairs <= 0 || npairs > B3GS_MAX_FUSED_VIEWS || !ios)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_binocular_loss", "pair count must be 1..8 and ios non-NULL");
   hipStream_t s = (hipStream_t)stream;
   // window exactly as utils/loss_utils.py:23-26: double exp -> float tensor -> normalised in float
   Win win;
@@ -394,7 +395,7 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
     const B3gsLossIO* io = ios + k;
     if (io->W <= 0 || io->H <= 0 || !io->image || !io->depth || !io->alpha || !io->gt_image || !io->dL_dimage ||
         !io->dL_ddepth || !io->dL_dalpha || !io->parts || !io->workspace || (io->shifted_image && !io->dL_dshifted))
-      return B3GS_ERR_ARG;
+      return b3gs_fail(B3GS_ERR_ARG, "b3gs_binocular_loss", "bad size or NULL image / gradient / workspace pointer");
     const int W = io->W, H = io->H;
     const size_t hw = (size_t)W * H;
     const float scale = io->grad_scale, inner = (float)(H - 2) * (float)(W - 2);
@@ -424,5 +425,5 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
   hipLaunchKernelGGL(ssim_grad_kernel, sgrid, blk, 0, s, lb, win);
   hipLaunchKernelGGL(binocular_kernel, dim3(gx, gy, npairs), blk, 0, s, lb);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(npairs), dim3(SLOTS), 0, s, lb);
-  return hipGetLastError() == hipSuccess ? B3GS_OK : B3GS_ERR_HIP;
+  return b3gs_launch_status("b3gs_binocular_loss");
 }

@@ -25,6 +25,9 @@ def _adam_state(optimizer, params):
     """-> (list of exp_avg, list of exp_avg_sq) per parameter, or (None, None)."""
     if optimizer is None:
         return None, None
+    if hasattr(optimizer, "gather_full_state"):   # step.ShardedAdam: this rank holds 1/N of the moments
+        fm, fv = optimizer.gather_full_state()
+        return [fm[a:b] for a, b in optimizer.bounds], [fv[a:b] for a, b in optimizer.bounds]
     if hasattr(optimizer, "exp_avg") and torch.is_tensor(optimizer.exp_avg):   # step.FusedAdam: flat buffers
         m, v, off = [], [], 0
         for p in optimizer.params:
@@ -122,6 +125,9 @@ def densify_and_prune(model, optimizer, max_grad: float, min_opacity: float, ext
 
 
 def _rebind_optimizer(optimizer, old_params, new_params, flat_m, flat_v, widths, newP):
+    if hasattr(optimizer, "rebuild"):             # step.ShardedAdam: re-flatten the parameters, keep this rank's share
+        optimizer.rebuild(new_params, flat_m, flat_v)
+        return
     if hasattr(optimizer, "exp_avg") and torch.is_tensor(optimizer.exp_avg):   # step.FusedAdam
         order = {id(p): k for k, p in enumerate(old_params)}
         assert [order[id(p)] for p in optimizer.params] == list(range(6)), "FusedAdam must own the six tensors in model order"

@@ -33,7 +33,7 @@ MAX_BATCH = 8   # views per batched launch (B3GS_MAX_FUSED_VIEWS)
 
 
 class _Slot:
-    def __init__(self, P, W, H, capacity, dev, want_means2D, scratch_floats, stream):
+    def __init__(self, P, W, H, capacity, dev, want_means2D, scratch_floats, stream, n_dev):
         L = _lib.lib()
         u8 = dict(dtype=torch.uint8, device=dev)
         self.geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
@@ -45,7 +45,7 @@ class _Slot:
         self.depth = torch.empty((1, H, W), **f)
         self.alpha = torch.empty((1, H, W), **f)
         self.radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-        self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.n_dev = n_dev      # [1] int32 view into the rasterizer's per-slot N array (device-side num_rendered)
         self.means2D_grad = torch.zeros((P, 3), **f) if want_means2D else None
         self.scratch = torch.zeros(max(scratch_floats, 1), **f)   # zero on entry / exit of every backward
         self.stream = stream
@@ -106,15 +106,19 @@ class FusedRasterizer:
         assert self.schedule in ("batched", "streams", "serial")
         self.concurrent = self.schedule == "streams"
         self._want_m2d = want_means2D
-        self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev)) for _ in range(num_slots)]
+        # N of every slot's last forward lives on the device (no read-back per view); `high_water` keeps the largest N
+        # seen since the last check_overflow(), updated by one tiny kernel per forward (graph-capturable)
+        self._n_all = torch.zeros((num_slots,), dtype=torch.int32, device=self.dev)
+        self.high_water = torch.zeros((num_slots,), dtype=torch.int32, device=self.dev)
+        self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev), k) for k in range(num_slots)]
         self._deferred = None   # [(spec, B3gsScene)] while a deferred-accumulate section is open
         self._params = _lib.B3gsRawParams()
         self._grads = _lib.B3gsRawGrads()
 
-    def _new_slot(self, stream):
+    def _new_slot(self, stream, index):
         L = _lib.lib()
         return _Slot(self.P, self.W, self.H, self.capacity, self.dev, self._want_m2d,
-                     L.b3gs_backward_scratch_floats(self.P), stream)
+                     L.b3gs_backward_scratch_floats(self.P), stream, self._n_all[index:index + 1])
 
     # ---- C-ABI plumbing -----------------------------------------------------------------------
     def _scene(self, sp) -> _lib.B3gsScene:
@@ -164,6 +168,10 @@ class FusedRasterizer:
         return arr, keep
 
     def _forward_batch(self, specs):
+        self._forward_batch_launch(specs)
+        torch.maximum(self.high_water, self._n_all, out=self.high_water)
+
+    def _forward_batch_launch(self, specs):
         L = _lib.lib()
         main = torch.cuda.current_stream(self.dev)
         scenes = [self._scene(sp) for sp in specs]
@@ -312,7 +320,8 @@ class FusedRasterizer:
         self.P = self.model.get_xyz.shape[0]
         self.capacity = max(self.capacity, 12 * self.P)
         for i in range(len(self.slots)):
-            self.slots[i] = self._new_slot(self.slots[i].stream)
+            self.slots[i] = self._new_slot(self.slots[i].stream, i)
+        self.high_water.zero_()
 
     def num_rendered(self):
         """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered
@@ -323,8 +332,33 @@ class FusedRasterizer:
     def overflowed(self) -> bool:
         return any(n > self.capacity for n in self.num_rendered())
 
-    def grow(self, factor: float = 1.5):
-        need = max(self.num_rendered() + [self.capacity])
+    def grow(self, factor: float = 1.5, need: Optional[int] = None):
+        need = max(self.num_rendered() + [self.capacity, int(need or 0)])
         self.capacity = int(need * factor)
         for i in range(len(self.slots)):
-            self.slots[i] = self._new_slot(self.slots[i].stream)
+            self.slots[i] = self._new_slot(self.slots[i].stream, i)
+        self.high_water.zero_()
+
+    def check_overflow(self) -> int:
+        """One small read-back: the largest N any view produced since the last check.  Returns 0 when every list
+        fitted; otherwise grows the buffers (1.5 x what was needed) and returns that N -- the views of the
+        overflowing forwards were rendered from truncated lists, so the caller repeats those steps.  (The reference
+        sizes the binning buffer from N on every render: one blocking read-back per view.)"""
+        hw = int(self.high_water.max().item())
+        self.high_water.zero_()
+        if hw <= self.capacity:
+            return 0
+        self.grow(need=hw)
+        return hw
+
+    def fit_capacity(self, views: Sequence, bg_color: torch.Tensor, margin: float = 1.3) -> int:
+        """Size the persistent binning buffers from the actual N of `views` ([(camera, slot), ...]): one forward without
+        gradients, one read-back.  Called at start-up and after every densification (the Gaussian set changed), so the
+        capacity follows the scene the way the reference's per-render allocation does."""
+        with torch.no_grad():
+            self.render_batch([(v[0], v[1]) for v in views], bg_color)
+        need = max(self.num_rendered())
+        self.high_water.zero_()
+        if need * margin > self.capacity:
+            self.grow(factor=margin, need=need)
+        return self.capacity

@@ -363,6 +363,8 @@ class ViewShardedStep:
         self.slab = FlatGradSlab(model.parameters(), getattr(optimizer, "padded_numel", 0))
         if fused is not None:
             assert len(fused.slots) >= len(self.views), "FusedRasterizer needs one slot per view of the step"
+            if self.views:     # size the persistent binning buffers from the actual N of this rank's views
+                fused.fit_capacity([(v.cam, v.slot) for v in self.views], bg)
         self.render = render_fn
         self.last_stats = {}
         self.overflow_check_every = int(overflow_check_every)
@@ -456,6 +458,8 @@ class ViewShardedStep:
             self.range_slab = RangeGradSlab(self.model.parameters(), self.pipeline_ranges)
         if self.fused is not None:
             self.fused.resize()
+            if self.views:     # the Gaussian set changed: size the binning buffers from the new N (one read-back)
+                self.fused.fit_capacity([(v.cam, v.slot) for v in self.views], self.bg)
         return newP
 
     def _reduce_and_update_pipelined(self, group=None):
@@ -543,6 +547,8 @@ class ViewShardedStep:
             outs, grads = self._loss_pixel_grads(pkgs, loss_fn, batch_loss_fn)
         if outs:
             torch.autograd.backward(outs, grads)
+        if self.fused is None:
+            self._update_densify_stats(pkgs)
         if self.fused is not None:
             if self.range_slab is None:
                 self.fused.finish_deferred(overwrite=True)
@@ -550,6 +556,22 @@ class ViewShardedStep:
                 self._pending_views = self.fused.take_deferred()
         self.last_stats = {"views": len(self.views)}
         return len(self.views)
+
+    def _update_densify_stats(self, pkgs):
+        """train.py:178-179 for the reference-shaped render(): statistics from the INPUT views only (the shifted
+        render's radii / screen-space gradients are discarded, train.py:128).  The fused path does this inside
+        its per-Gaussian backward kernel."""
+        m = self.model
+        if getattr(m, "denom", None) is None or m.denom.shape[0] != m.get_xyz.shape[0]:
+            return
+        with torch.no_grad():
+            for v, pkg in zip(self.views, pkgs):
+                g = pkg["viewspace_points"].grad if v.role == 0 else None
+                if g is None:
+                    continue
+                vis = pkg["visibility_filter"]
+                m.update_max_radii(pkg["radii"], vis)
+                m.add_densification_stats(g, vis)
 
     def _loss_pixel_grads(self, pkgs, loss_fn, batch_loss_fn):
         """Loss of every pair whose INPUT view lives here, on detached leaves of the rendered images; returns the

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 2
+#define B3GS_ABI_VERSION 3
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -236,8 +236,11 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
  * eps = 1e-15) and optimizer.step() at train.py:196-198.  `device_step` (int32 on the device, incremented
  * by the call unless bump_step_after == 0: a step issued as several calls over disjoint slices -- the pipelined
  * data-parallel tail -- bumps on the last one) keeps the bias correction replayable from a HIP graph.  opacity_decay > 0 additionally
- * applies  o <- logit(sigmoid(o) * opacity_decay)  to segment `opacity_segment` after its update
- * (gaussian_model.py:307-309, train.py:171-173). */
+ * applies  o <- logit(sigmoid(o) * opacity_decay)  to segment `opacity_segment` (gaussian_model.py:307-309,
+ * train.py:171-173): after its update when opacity_decay_first == 0; when != 0, in the reference's order -- the
+ * decay runs BEFORE optimizer.step() (train.py:171-173 vs :196-198), so the Adam update (computed from the gradient at
+ * the un-decayed value) is subtracted from the decayed logit.  A segment with count == 0 may carry NULL pointers
+ * (features_rest at SH degree 0). */
 typedef struct B3gsAdamSegment {
   float* param;
   const float* grad;
@@ -247,8 +250,8 @@ typedef struct B3gsAdamSegment {
   float lr;
 } B3gsAdamSegment;
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
-                   float eps, float opacity_decay, int32_t opacity_segment, int32_t bump_step_after,
-                   b3gs_stream_t stream);
+                   float eps, float opacity_decay, int32_t opacity_segment, int32_t opacity_decay_first,
+                   int32_t bump_step_after, b3gs_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------------------
  * Value and pixel gradients of the per-pair training loss of train.py:123-148 in 4 launches:
