@@ -3,28 +3,41 @@
 
     train iters/s (fwd+bwd) + Mpix/s, 1M Gaussians @ 800x600, 1/2/4/8 GPU
 
-One *iter* = 6 views = 3 input views + their 3 binocular-shifted partners, each rasterised forward
-and backward through the drop-in `render()` (activations and their autograd included), the
-per-Gaussian gradients of all views accumulated in one flat slab, all-reduced over RCCL when
-N > 1 (weak scaling: every rank renders its own 6 views, distinct yaw offsets), and one Adam step.
-Inputs are the seeded synthetic scene of BASELINE.md section 3, resident in HBM before the timed
-region; upstream pixel gradients are the seeded N(0,1)/(3HW), /HW, /HW tensors of SURVEY 8(d)
-(primary views: colour+depth+alpha; shifted views: colour only, as the loss block of
-train.py:123-149 produces).
+One *iter* = 6 views = 3 input views + their 3 binocular-shifted partners, each rasterised forward and backward, the
+per-Gaussian gradients of all views accumulated in one flat slab, summed over the ranks when N > 1 (reduce-scatter ->
+Adam on 1/N of the parameters -> all-gather; weak scaling: every rank renders its own 6 views, distinct yaw offsets),
+and one Adam step.  Inputs are the seeded synthetic scene of BASELINE.md section 3, resident in HBM before the timed
+region; upstream pixel gradients are the seeded N(0,1)/(3HW), /HW, /HW tensors of SURVEY 8(d) (primary views:
+colour+depth+alpha; shifted views: colour only, as the loss block of train.py:123-149 produces).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (blend backward): algorithmic bytes / HIP-event duration vs 8 TB/s
-  roofline_view whole view fwd+bwd: SURVEY 8(d) byte model (R+W) / per-view kernel time
-  cpu_baseline  oracle/tile_ref.c (kind "port") on the host cores, one full-size view fwd+bwd
+  roofline       dominant kernel (blend backward): SURVEY 8(d) algorithmic bytes (44 B per tile instance the launch
+                 PROCESSES + 28 B per pixel) / average launch duration (HIP events on the launch stream over the same K
+                 steps as the timed region) vs 8 TB/s; `traffic` = HBM bytes per launch from rocprofv3 PMC passes run
+                 by this script on a short copy of the same workload (N=1 only; null when rocprofv3 is unavailable);
+                 `valu` = the kernel's real bound: VALU issue-slot utilisation from the SQ counters
+  hbm_measured   whole-iteration HBM bytes from the same PMC passes
+  reference_algorithm_equivalent   SURVEY 8(d)'s whole-view byte model of the REFERENCE algorithm (6 radix passes over
+                 64-bit keys, reference binning rule) divided by this implementation's kernel time: how fast a
+                 reference-shaped implementation would have to stream to match -- not bytes this code moves
+  extras         dropin_iters_per_s (the reference-shaped render() surface, N=1), strong scaling of the same 6 views
+                 over the ranks (configs[3]), configs[4] (2M Gaussians @ 1600x1600, 8 views, view-granular)
+  cpu_baseline   oracle/tile_ref.c (kind "port") on the host cores, one full-size iteration
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import math
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +46,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+CUS, SIMDS_PER_CU = 256, 4
+LRS = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]   # arguments/__init__.py:75-82; eps 1e-15: scene/gaussian_model.py:163
 
 
 def parse():
@@ -44,44 +59,271 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--fov", type=float, default=60.0)
+    ap.add_argument("--views", type=int, choices=(6, 8), default=6,
+                    help="6: 3 input + 3 binocular-shifted views (BASELINE.md section 3); 8: config 5's eight input views")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank renders its own 6 views; strong: the SAME 6 (or 8) views are spread over the "
+                         "ranks view by view (step.assign_views) -- value = global iters/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (drop-in, strong scaling, config 5)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # a PMC pass of this script over itself
     ap.add_argument("--no-optimizer", action="store_true")
-    ap.add_argument("--optimizer", choices=("b3gs", "torch"), default="b3gs",
-                    help="b3gs: one-launch fused Adam (b3gs_adam_step); torch: torch.optim.Adam(fused=True), 12 launches")
+    ap.add_argument("--optimizer", choices=("sharded", "b3gs", "torch"), default="sharded",
+                    help="sharded: reduce-scatter -> one-launch Adam on 1/N -> all-gather (step.ShardedAdam; = the fused "
+                         "Adam on flat buffers at N=1); b3gs: all-reduce + replicated one-launch Adam; torch: "
+                         "torch.optim.Adam(fused=True), 12 launches")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
-                    help="fused: b3gs_forward_raw/backward_raw (activations in-kernel, persistent scratch, no host sync); "
-                         "dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
-    ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched",
-                    help="batched: every stage one launch for all 6 views, pairs share a depth sort; "
-                         "streams: one stream per view; serial: one stream, per-view launches")
+                    help="fused: b3gs_forward_raw_batch / backward (activations in-kernel, persistent scratch, no host "
+                         "sync); dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
+    ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched")
     ap.add_argument("--pipeline-ranges", type=int, default=0,
-                    help="data parallel: cut the chain-rule / all-reduce / Adam tail into this many Gaussian ranges so the "
-                         "all-reduce of one range overlaps the neighbours' compute (0: one all-reduce of the whole slab). "
-                         "Off by default: on ONE GPU the extra launches cost 0.2 ms per iteration (2.39 -> 2.59 ms), "
-                         "about what the overlap can win back at 8 GPUs")
+                    help="(--optimizer b3gs) cut the chain-rule / all-reduce / Adam tail into this many Gaussian ranges")
     ap.add_argument("--loss", choices=("synthetic", "fused", "torch"), default="synthetic",
                     help="synthetic: fixed pixel gradients (the metric's definition); fused / torch: the loss block of "
                          "train.py:123-148 through b3gs_binocular_loss / through PyTorch ops")
-    ap.add_argument("--viewspace-grads", action="store_true",
-                    help="also write every view's [P,3] screen-space mean gradients (viewspace_points.grad)")
-    ap.add_argument("--serial-views", action="store_true",
-                    help="render the views one after the other on one stream (un-overlapped kernel times, for profiles)")
+    ap.add_argument("--viewspace-grads", action="store_true")
+    ap.add_argument("--serial-views", action="store_true")
     ap.add_argument("--dp-path", action="store_true",
-                    help="single-GPU check of the N>1 code path: 1-rank RCCL group, graph + eager all-reduce")
+                    help="single-GPU check of the N>1 code path: 1-rank RCCL group, graph + eager collectives")
     ap.add_argument("--graph", type=int, default=1, help="capture one whole iteration in a HIP graph (fused path only)")
     return ap.parse_args()
 
 
-def byte_model(P, V, N, HW, Tn, K=4, tiles_bits=None):
-    """SURVEY.md 8(d) algorithmic bytes per view, fwd+bwd, K SH coeffs, p radix byte-passes of the
-    reference's 64-bit sort (the model is the REFERENCE algorithm's traffic: what a perfect
-    implementation of that algorithm must move; our two-level sort moves less)."""
+def byte_model(P, V, N, HW, Tn, K=4):
+    """SURVEY.md 8(d) algorithmic bytes per view, fwd+bwd, of the REFERENCE algorithm (p radix byte-passes of its
+    64-bit sort): what a perfect implementation of that algorithm must move; the two-level sort here moves less."""
     p = math.ceil((32 + max(1, math.ceil(math.log2(max(Tn, 2))))) / 8)
     R = 12 * P + (32 + 12 * K) * V + 4 * P + 20 * V + (12 * p + 8) * N + 8 * N + 44 * N + 8 * Tn + 44 * N + 28 * HW + \
         (44 + 12 * K + 76) * V
     Wt = 8 * P + 68 * V + 4 * P + 12 * N + 12 * p * N + 8 * Tn + 28 * HW + 48 * P + 48 * V + (40 + 12 * K) * P
     return R, Wt
+
+
+class Job:
+    """One workload on this rank: model, view set, step object, optional HIP graph."""
+
+    def __init__(self, args, dev, rank, world, dp, P, W, H, fov, views, scaling, path="fused", graph=True, loss="synthetic"):
+        from binocular3dgs_amd import synth
+        from binocular3dgs_amd.render import PipelineParams
+        from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+        self.args, self.dev, self.rank, self.world, self.dp = args, dev, rank, world, dp
+        self.P, self.W, self.H, self.fov, self.scaling, self.path = P, W, H, fov, scaling, path
+        self.model = model = synth.synth_model(P, seed=args.seed, device=dev, width=W, height=H, fovx_deg=fov)
+        if views == 8:
+            gp = [(c, None, 0.0) for c in synth.synth_cameras(W, H, fovx_deg=fov, yaws=synth.YAWS_8, device=dev)]
+        else:
+            # weak scaling: each rank owns 3 distinct pairs (yaw offsets 0, 1.5, 3.0 ... degrees apart)
+            gp = synth.synth_view_set(W, H, fovx_deg=fov, device=dev, yaw_offset=1.5 * rank if scaling == "weak" else 0.0)
+        self.global_pairs = gp
+        self.global_views = sum(1 + (s is not None) for _, s, _ in gp) * (world if scaling == "weak" else 1)
+        self.bg = torch.zeros(3, device=dev)
+        seeds = range(len(gp))
+        self.pix = [synth.synth_pixel_grads(W, H, seed=(rank if scaling == "weak" else 0) + 7 * i, device=dev) for i in seeds]
+        self.pix2 = [synth.synth_pixel_grads(W, H, seed=100 + (rank if scaling == "weak" else 0) + 7 * i, device=dev)[0]
+                     for i in seeds]
+        opt = None
+        if not args.no_optimizer:
+            if args.optimizer == "sharded":
+                opt = ShardedAdam(model.parameters(), LRS, eps=1e-15)
+            elif args.optimizer == "b3gs":
+                opt = FusedAdam(model.parameters(), LRS, eps=1e-15)
+            else:
+                opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), LRS)], lr=0.0,
+                                       eps=1e-15, fused=True)
+        self.opt = opt
+        nlocal = self.global_views if scaling == "weak" else None
+        fused = None
+        if scaling == "weak":
+            local_views = sum(1 + (s is not None) for _, s, _ in gp)
+        else:
+            from binocular3dgs_amd.step import assign_views
+            local_views = len(assign_views([s is not None for _, s, _ in gp], world)[rank])
+        if path == "fused":
+            from binocular3dgs_amd.fused import FusedRasterizer
+            # the densification statistics (train.py:178-179: the only consumer of the screen-space gradients) are
+            # updated inside the per-Gaussian backward pass, so the per-view [P,3] gradient tensors are not
+            # materialised unless asked for
+            model.init_densification_stats()
+            fused = FusedRasterizer(model, W, H, num_slots=max(local_views, 1), want_means2D=bool(args.viewspace_grads),
+                                    schedule="serial" if args.serial_views else args.schedule)
+        self.fused = fused
+        pipe_ranges = args.pipeline_ranges if dp and fused is not None and args.optimizer == "b3gs" else 0
+        kw = dict(optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges, overflow_check_every=0)
+        if scaling == "weak":
+            self.stepper = ViewShardedStep(model, gp, self.bg, PipelineParams(), **kw)
+        else:
+            self.stepper = ViewShardedStep.from_global(model, gp, self.bg, rank=rank, world=world, pipe=PipelineParams(), **kw)
+        self.stepper.slab.force_collective = bool(args.dp_path)
+        if hasattr(opt, "force_collective"):
+            opt.force_collective = bool(args.dp_path)
+        self.local_views = len(self.stepper.views)
+        self.pipe_ranges = pipe_ranges
+        del nlocal
+
+        def grad_fn(i, pkg, spkg):
+            out = []
+            if pkg is not None:
+                gc, gd, ga = self.pix[i]
+                out += [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga)]
+            if spkg is not None:
+                out.append((spkg["render"], self.pix2[i]))
+            return out
+
+        self.step_kw = dict(pair_grad_fn=grad_fn)
+        if loss != "synthetic":
+            # the real loss block of train.py:123-148 on random ground-truth images instead of fixed pixel gradients
+            # (information only: BASELINE.json's metric is the rasterizer fwd+bwd with given pixel gradients)
+            from binocular3dgs_amd.fused_loss import binocular_loss_fused_batch
+            from binocular3dgs_amd.loss import binocular_loss
+            gts = [torch.rand(3, H, W, device=dev) for _ in gp]
+            bgm = [(g_.max(0, keepdim=True).values < 0.1).float() for g_ in gts]
+            if loss == "fused":
+                def batch_loss_fn(items):
+                    return binocular_loss_fused_batch(
+                        [dict(image=pkg["render"], depth=pkg["rendered_depth"], alpha=pkg["rendered_alpha"], gt_image=gts[i],
+                              shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0],
+                              trans_dist=t, bg_mask=bgm[i]) for i, cam, pkg, spkg, t in items], unit_grad=True)
+                self.step_kw = dict(batch_loss_fn=batch_loss_fn)
+            else:
+                def loss_fn(i, cam, pkg, spkg, t):
+                    return binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i],
+                                          shifted_image=None if spkg is None else spkg["render"],
+                                          focal_x=cam.get_focal()[0], trans_dist=t, bg_mask=bgm[i])[0]
+                self.step_kw = dict(loss_fn=loss_fn)
+        self.loss = loss
+        self.use_graph = bool(graph) and fused is not None
+        self.run = self.eager_step
+        self._snap = None
+
+    def eager_step(self):
+        self.stepper.step(**self.step_kw)
+
+    def barrier(self):
+        torch.cuda.synchronize(self.dev)
+        if self.dp:
+            dist.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    # ---- state snapshot: the timed region and the per-kernel timing pass walk the same K optimiser states ----------
+    def _state_tensors(self):
+        m, o = self.model, self.opt
+        ts = list(m.parameters())
+        if getattr(m, "denom", None) is not None:
+            ts += [m.denom, m.xyz_gradient_accum, m.max_radii2D]
+        if o is not None and hasattr(o, "exp_avg") and torch.is_tensor(o.exp_avg):
+            ts += [o.exp_avg, o.exp_avg_sq, o.step_count]
+        elif o is not None and hasattr(o, "state"):
+            for st_ in o.state.values():
+                ts += [v for v in st_.values() if torch.is_tensor(v)]
+        return ts
+
+    def snapshot(self):
+        self._snap = [t.detach().clone() for t in self._state_tensors()]
+
+    def restore(self):
+        with torch.no_grad():
+            for t, s in zip(self._state_tensors(), self._snap):
+                t.copy_(s)
+
+    def prepare(self, warmup):
+        for _ in range(max(warmup, 1)):
+            self.eager_step()
+        if self.fused is not None:
+            while self.fused.check_overflow():     # persistent binning capacity too small: grown, outside the timed region
+                self.eager_step()
+        self.snapshot()
+        if not self.use_graph:
+            return
+        st, opt, args = self.stepper, self.opt, self.args
+        split_comm = self.loss != "synthetic" and any(v.peer is not None for v in st.views)
+        if split_comm:
+            self.use_graph = False                  # point-to-point messages in the middle of the iteration: eager
+            return
+        try:
+            if opt is not None and args.optimizer == "torch" and not self.dp:
+                for g_ in opt.param_groups:
+                    g_["capturable"] = True
+                for st_ in opt.state.values():
+                    if "step" in st_ and not st_["step"].is_cuda:
+                        st_["step"] = st_["step"].to(self.dev)
+            body = (lambda: st.compute_grads(**self.step_kw)) if self.dp else self.eager_step
+            sg = torch.cuda.Stream()
+            sg.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sg):
+                body()
+            torch.cuda.current_stream().wait_stream(sg)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+            if self.dp:
+                # data parallel: the rendering part of the iteration is one hipGraph; the RCCL collectives of the
+                # gradient slab and the (single-kernel) Adam are issued eagerly after each replay
+                def run():
+                    graph.replay()
+                    st.reduce_and_update()
+                self.run = run
+            else:
+                # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
+                # (all views fwd+bwd, Adam) is one hipGraph launch
+                self.run = graph.replay
+            self._graph = graph
+        except Exception as exc:  # capture unsupported in this environment: stay eager
+            if self.rank == 0:
+                print(f"[bench] graph capture failed ({exc!r}); running eager", file=sys.stderr)
+            self.use_graph = False
+            self.run = self.eager_step
+        self.restore()
+
+    def timed(self, steps):
+        """K steps between barriers; returns max-over-ranks seconds."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.run()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.fused is not None and self.fused.check_overflow():
+            raise SystemExit("binning capacity overflow inside the timed region: result invalid")
+        if self.dp:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def kernel_times(self, steps):
+        """Per-stage HIP-event times of the same `steps` optimiser states as the timed region, eager launches on one
+        stream (the events are recorded by the library on the launch stream, nothing synchronises inside a step), and
+        the tile-instance count each blend launch processed (sum of the views' device-side N, read between steps)."""
+        from binocular3dgs_amd import _lib
+        L = _lib.lib()
+        self.restore()
+        L.b3gs_timing_collect()
+        times = _lib.B3gsKernelTimes()
+        L.b3gs_set_timing(C.byref(times))
+        fused = self.fused
+        was = None
+        if fused is not None and fused.schedule == "streams":
+            was = fused.schedule
+            fused.schedule, fused.concurrent = "serial", False
+        inst = []
+        for _ in range(steps):
+            self.eager_step()
+            if fused is not None:
+                torch.cuda.synchronize(self.dev)
+                inst.append(int(fused._n_all[:self.local_views].to(torch.int64).sum().item()))
+        self.barrier()
+        L.b3gs_timing_collect()
+        L.b3gs_set_timing(None)
+        if was is not None:
+            fused.schedule, fused.concurrent = was, True
+        n_views = max(steps * max(self.local_views, 1), 1)
+        ms = dict(preprocess=times.preprocess_ms / n_views, sort=times.sort_ms / n_views,
+                  render_fwd=times.render_fwd_ms / n_views, render_bwd=times.render_bwd_ms / n_views,
+                  preprocess_bwd=times.preprocess_bwd_ms / n_views)
+        return ms, (sum(inst) / len(inst) if inst else None)
 
 
 def main():
@@ -100,261 +342,146 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
-    from binocular3dgs_amd import _lib, synth
-    from binocular3dgs_amd.render import PipelineParams
-    from binocular3dgs_amd.step import ViewShardedStep
-
     P, W, H = args.gaussians, args.width, args.height
-    model = synth.synth_model(P, seed=args.seed, device=dev, width=W, height=H)
-    # weak scaling: each rank owns 3 distinct pairs (yaw offsets 0, 1.5, 3.0 ... degrees apart)
-    pairs = synth.synth_view_set(W, H, device=dev, yaw_offset=1.5 * rank)
-    bg = torch.zeros(3, device=dev)
-    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=rank, device=dev)
-    gc2 = synth.synth_pixel_grads(W, H, seed=100 + rank, device=dev)[0]
-    opt = None
-    if not args.no_optimizer:
-        # learning rates of arguments/__init__.py:75-82, eps of scene/gaussian_model.py:163
-        lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]
-        if args.optimizer == "b3gs":
-            from binocular3dgs_amd.step import FusedAdam
-            opt = FusedAdam(model.parameters(), lrs, eps=1e-15)
-        else:
-            opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), lrs)], lr=0.0,
-                                   eps=1e-15, fused=True)
-    fused = None
-    if args.path == "fused":
-        from binocular3dgs_amd.fused import FusedRasterizer
-        # the densification statistics (train.py:178-179: the only consumer of the screen-space gradients) are
-        # updated inside the per-Gaussian backward pass, so the per-view [P,3] gradient tensors are not
-        # materialised unless asked for
-        model.init_densification_stats()
-        fused = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=bool(args.viewspace_grads),
-                                schedule="serial" if args.serial_views else args.schedule)
-    # data parallel: the tail of the iteration (chain rule -> all-reduce -> Adam) is pipelined over Gaussian ranges
-    pipe_ranges = args.pipeline_ranges if (dp or args.dp_path) and fused is not None and args.optimizer == "b3gs" else 0
-    stepper = ViewShardedStep(model, pairs, bg, PipelineParams(), optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges)
-    stepper.slab.force_collective = bool(args.dp_path)
+    job = Job(args, dev, rank, world, dp, P, W, H, args.fov, args.views, args.scaling, path=args.path, graph=args.graph,
+              loss=args.loss)
+    job.prepare(args.warmup)
+    elapsed = job.timed(args.steps)
+    views_per_iter = job.global_views
+    iters = args.steps * (world if args.scaling == "weak" else 1)
+    value = iters / elapsed
+    mpix = views_per_iter * W * H * args.steps / elapsed / 1e6
 
-    def grad_fn(i, pkg, spkg):
-        out = [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga)]
-        if spkg is not None:
-            out.append((spkg["render"], gc2))
-        return out
+    ms, inst_per_launch = ({k: 0.0 for k in ("preprocess", "sort", "render_fwd", "render_bwd", "preprocess_bwd")}, None)
+    if job.local_views:
+        ms, inst_per_launch = job.kernel_times(min(args.steps, 20))
 
-    step_kw = dict(pair_grad_fn=grad_fn)
-    if args.loss != "synthetic":
-        # the real loss block of train.py:123-148 on random ground-truth images instead of fixed pixel gradients
-        # (information only: BASELINE.json's metric is the rasterizer fwd+bwd with given pixel gradients)
-        from binocular3dgs_amd.fused_loss import binocular_loss_fused
-        from binocular3dgs_amd.loss import binocular_loss
-        gts = [torch.rand(3, H, W, device=dev) for _ in pairs]
-        bgm = [(g_.max(0, keepdim=True).values < 0.1).float() for g_ in gts]
-
-        def loss_fn(i, cam, pkg, spkg, t):
-            kw = dict(shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t,
-                      bg_mask=bgm[i])
-            if args.loss == "fused":
-                return binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i], slot=i,
-                                            unit_grad=True, **kw)
-            return binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gts[i], **kw)[0]
-        step_kw = dict(loss_fn=loss_fn)
-        if args.loss == "fused":
-            from binocular3dgs_amd.fused_loss import binocular_loss_fused_batch
-
-            def batch_loss_fn(items):
-                return binocular_loss_fused_batch(
-                    [dict(image=pkg["render"], depth=pkg["rendered_depth"], alpha=pkg["rendered_alpha"], gt_image=gts[i],
-                          shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t,
-                          bg_mask=bgm[i]) for i, cam, pkg, spkg, t in items], unit_grad=True)
-            step_kw = dict(batch_loss_fn=batch_loss_fn)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if dp:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(max(args.warmup, 1)):
-        stepper.step(**step_kw)
-    if fused is not None:
-        while fused.overflowed():          # persistent binning capacity too small: grow once, outside the timed region
-            fused.grow()
-            stepper.step(**step_kw)
-    run_step = lambda: stepper.step(**step_kw)  # noqa: E731
-    use_graph = bool(args.graph) and fused is not None
-    if use_graph and dp:
-        # data parallel: the rendering part of the iteration is one hipGraph; the RCCL all-reduce of
-        # the gradient slab and the (single-kernel) fused Adam are issued eagerly after each replay
-        try:
-            sg = torch.cuda.Stream()
-            sg.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(sg):
-                stepper.compute_grads(**step_kw)
-            torch.cuda.current_stream().wait_stream(sg)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                stepper.compute_grads(**step_kw)
-
-            def run_step():
-                graph.replay()
-                stepper.reduce_and_update()
-        except Exception as exc:  # capture unsupported in this environment: stay eager
-            if rank == 0:
-                print(f"[bench] graph capture failed ({exc!r}); running eager", file=sys.stderr)
-            use_graph = False
-            run_step = lambda: stepper.step(**step_kw)  # noqa: E731
-    elif use_graph:
-        # the fused path never allocates, never syncs and keeps N on the device: the whole iteration
-        # (6 views fwd+bwd, slab zero, Adam) is one hipGraph launch
-        if opt is not None and args.optimizer == "torch":
-            for g_ in opt.param_groups:
-                g_["capturable"] = True
-            for st_ in opt.state.values():
-                if "step" in st_ and not st_["step"].is_cuda:
-                    st_["step"] = st_["step"].to(dev)
-        sg = torch.cuda.Stream()
-        sg.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(sg):
-            stepper.step(**step_kw)
-        torch.cuda.current_stream().wait_stream(sg)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            stepper.step(**step_kw)
-        run_step = graph.replay
-
-    # stage timing: HIP events recorded by the library on the launch stream, no sync inside.
-    # When the iteration is replayed from a HIP graph the library is not re-entered, so the events
-    # are taken from eager iterations of the same workload run right after the timed region.
-    L = _lib.lib()
-    times = _lib.B3gsKernelTimes()
-    barrier()
-    if not use_graph:
-        L.b3gs_set_timing(C.byref(times))
-    views = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-        views += 2 * len(pairs)
-    barrier()
-    t1 = time.perf_counter()
-    timed_views = args.steps * 2 * len(pairs)
-    if use_graph or (fused is not None and fused.schedule == "streams"):
-        # per-kernel durations need eager launches on one stream: a few more iterations after the timed
-        # region, same workload and kernels ("batched" keeps its batched launches; "streams" cannot be
-        # timed per kernel while overlapped and is issued view by view here)
-        L.b3gs_timing_collect()            # resolve (and discard) stages parked during the timed region
-        L.b3gs_set_timing(None)
-        times = _lib.B3gsKernelTimes()
-        L.b3gs_set_timing(C.byref(times))
-        was = fused.schedule
-        if was == "streams":
-            fused.schedule, fused.concurrent = "serial", False
-        for _ in range(min(args.steps, 5)):
-            stepper.step(**step_kw)
-        barrier()
-        fused.schedule, fused.concurrent = was, was == "streams"
-        timed_views = min(args.steps, 5) * 2 * len(pairs)
-    L.b3gs_timing_collect()
-    L.b3gs_set_timing(None)
-    elapsed = t1 - t0
-    if fused is not None and fused.overflowed():
-        raise SystemExit("binning capacity overflow inside the timed region: result invalid")
-    if dp:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # workload statistics of this rank's primary view 0 (V, N make the byte model concrete)
-    with torch.no_grad():
-        from binocular3dgs_amd.render import render
-        pkg = render(pairs[0][0], model, PipelineParams(), bg)
-        V = int((pkg["radii"] > 0).sum().item())
-    n_views = max(timed_views, 1)
+    # workload statistics of this rank's primary view 0 through the reference-shaped C ABI surface (V, the reference-rule N)
+    from binocular3dgs_amd import _C
+    model, fused = job.model, job.fused
+    N_ref, V = 0, 0
+    if not args.inner:      # (a counter pass profiles the product path only)
+        with torch.no_grad():
+            cam = job.global_pairs[0][0]
+            e = torch.empty(0, device=dev)
+            o = _C.rasterize_gaussians(job.bg, model.get_xyz, e, model.get_opacity, model.get_scaling, model.get_rotation,
+                                       1.0, e, cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx / 2),
+                                       math.tan(cam.FoVy / 2), H, W, model.get_features, model.active_sh_degree,
+                                       cam.camera_center, False, False)
+            N_ref, V = int(o[0]), int((o[4] > 0).sum().item())
+            del o
     # (pixel, Gaussian) pairs the sequential algorithm visits: sum over pixels of the position of their last
     # contributor (n_contrib) -- the work unit of the blend kernels (they are not HBM bound)
-    pairs_per_view = None
-    if fused is not None:
+    pairs_per_view, n_binned = None, N_ref
+    if fused is not None and job.local_views:
         from binocular3dgs_amd.debug import state_views
         s0 = fused.slots[0]
-        n0 = fused.num_rendered()[0]
-        pairs_per_view = int(state_views(P, W, H, n0, s0.geom, s0.binning, s0.img)["n_contrib"].to(torch.int64).sum().item())
-    # N: read back from one more forward through the C ABI surface
-    from binocular3dgs_amd import _C
-    with torch.no_grad():
-        cam = pairs[0][0]
-        N = _C.rasterize_gaussians(bg, model.get_xyz, torch.empty(0, device=dev), model.get_opacity,
-                                   model.get_scaling, model.get_rotation, 1.0, torch.empty(0, device=dev),
-                                   cam.world_view_transform, cam.full_proj_transform, math.tan(cam.FoVx / 2),
-                                   math.tan(cam.FoVy / 2), H, W, model.get_features, model.active_sh_degree,
-                                   cam.camera_center, False, False)[0]
+        n_binned = fused.num_rendered()[0]
+        pairs_per_view = int(state_views(P, W, H, s0.capacity, s0.geom, s0.binning, s0.img)["n_contrib"].to(torch.int64).sum().item())
 
-    iters = args.steps * world
-    value = iters / elapsed
-    views_per_iter = 2 * len(pairs)
-    mpix = views_per_iter * W * H * iters / elapsed / 1e6
-
+    result_line = None
     if rank == 0:
         HW = W * H
         Tn = ((W + 15) // 16) * ((H + 15) // 16)
-        ms = dict(preprocess=times.preprocess_ms / n_views, sort=times.sort_ms / n_views,
-                  render_fwd=times.render_fwd_ms / n_views, render_bwd=times.render_bwd_ms / n_views,
-                  preprocess_bwd=times.preprocess_bwd_ms / n_views)
-        # dominant kernel = the largest stage that is a single kernel launch
-        single = {"render_fwd": ms["render_fwd"], "render_bwd": ms["render_bwd"]}
-        dom = max(single, key=single.get)
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): the blend kernels read one 44-byte record
-        # + 4-byte index per tile instance; fwd writes 28 B/pixel, bwd reads 28 B/pixel and updates
-        # 10 fp32 accumulators per visible Gaussian (read+write = 80 B)
-        dom_bytes = (48 * N + 28 * HW + 8 * Tn) if dom == "render_fwd" else (48 * N + 28 * HW + 8 * Tn + 80 * V)
-        # views per launch of that kernel: the blend backward always takes all views of the iteration, the
-        # blend forward does unless every view runs on its own stream
-        vpl = views_per_iter if (fused is not None and (dom == "render_bwd" or fused.schedule != "streams")) else 1
-        vpl = min(vpl, 8)
-        dom_s = single[dom] / 1e3
-        achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
-        R, Wt = byte_model(P, V, N, HW, Tn)
+        lv = max(job.local_views, 1)
+        # ---- roofline of the dominant kernel, SURVEY 8(d): render bwd reads 44 B per tile instance it PROCESSES
+        #      (index 4, xy 8, conic + opacity 16, rgb 12, depth 4) + 28 B per pixel; one launch = all local views
+        dom = "render_bwd"
+        n_launch = inst_per_launch if inst_per_launch is not None else N_ref * lv
+        bytes_launch = 44.0 * n_launch + 28.0 * HW * lv
+        dur_ms = ms[dom] * lv
+        achieved = bytes_launch / (dur_ms / 1e3) / 1e9 if dur_ms > 0 else 0.0
+        R, Wt = byte_model(P, V, N_ref, HW, Tn)
         view_ms = sum(ms.values())
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                # per launch of the default schedule (all views of the iteration in one launch)
-                traffic = json.load(open(tpath)).get(dom.replace("_kernel", "")) if (vpl == views_per_iter and (P, W, H) == (1_000_000, 800, 600)) else None
-            except Exception:
-                traffic = None
+        roof = {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": int(bytes_launch), "avg_launch_ms": round(dur_ms, 4), "views_per_launch": lv,
+                "instances_per_launch": None if inst_per_launch is None else int(inst_per_launch),
+                "byte_model": "44 B x tile instances processed (tight-binned N summed over the launch's views) + 28 B x H W "
+                              "per view (SURVEY 8d, render bwd); duration = HIP events on the launch stream, mean over "
+                              "the K optimiser states of the timed region",
+                "note": "the blend kernels are VALU-bound (SURVEY 8d caveat): `valu` is their real roofline; the 64-byte "
+                        "records are served from L2 / Infinity Cache, so `traffic` sits below the algorithmic bytes",
+                "pixgauss_pairs_per_view": pairs_per_view,
+                "pixgauss_pairs_per_s": (None if not pairs_per_view or ms["render_bwd"] <= 0
+                                         else round(pairs_per_view / (ms["render_bwd"] / 1e3), 1))}
         out = {
             "metric": "train iters/s (fwd+bwd), 1M Gaussians @ 800x600, 6 views/iter",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mpix_per_s": round(mpix, 1),
-            "config": {"workload": f"synth(P={P}, seed={args.seed}) {W}x{H}, 3 input + 3 binocular-shifted views "
-                                   f"per rank per iter, fwd+bwd+grad all-reduce+Adam", "gaussians": P, "width": W,
-                       "height": H, "views_per_rank": views_per_iter, "global_views": views_per_iter * world,
-                       "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N,
-                       "instances_N_binned": (fused.num_rendered()[0] if fused is not None else N),
-                       "loss": args.loss, "optimizer_in_step": opt is not None, "densify_stats_in_step": fused is not None,
-                       "optimizer": None if opt is None else args.optimizer, "path": args.path, "hip_graph": bool(use_graph),
-                       "schedule": None if fused is None else fused.schedule,
-                       "dp_tail_ranges": pipe_ranges, "parallelism": f"dp{world} (views sharded, params replicated)"},
+            "config": {"workload": f"synth(P={P}, seed={args.seed}) {W}x{H}, "
+                                   + ("3 input + 3 binocular-shifted views" if args.views == 6 else "8 input views")
+                                   + (" per rank per iter" if args.scaling == "weak" else " per iter, spread over the ranks view by view")
+                                   + ", fwd+bwd+gradient sum+Adam", "gaussians": P, "width": W,
+                       "height": H, "views_per_rank": job.local_views, "global_views": views_per_iter,
+                       "sh_degree": 1, "K": 4, "visible_V": V, "instances_N": N_ref, "instances_N_binned": n_binned,
+                       "loss": args.loss, "optimizer_in_step": job.opt is not None, "densify_stats_in_step": fused is not None,
+                       "optimizer": None if job.opt is None else args.optimizer, "path": args.path,
+                       "hip_graph": bool(job.use_graph), "schedule": None if fused is None else fused.schedule,
+                       "dp_tail_ranges": job.pipe_ranges,
+                       "parallelism": f"dp{world} (views sharded, params replicated"
+                                      + (", Adam state sharded: reduce-scatter + all-gather)" if args.optimizer == "sharded" else ")")},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
-            "roofline": {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_launch": dom_bytes * vpl,
-                         "avg_launch_ms": round(single[dom] * vpl, 4), "views_per_launch": vpl,
-                         "note": "blend kernels are VALU-bound (SURVEY 8d caveat): see pixgauss_pairs_per_s",
-                         "pixgauss_pairs_per_view": pairs_per_view,
-                         "pixgauss_pairs_per_s": (None if not pairs_per_view or ms["render_bwd"] <= 0
-                                                  else round(pairs_per_view / (ms["render_bwd"] / 1e3), 1))},
-            "roofline_view": {"bound": "hbm", "bytes_per_view": R + Wt, "read_bytes_per_view": R,
-                              "kernel_ms_per_view": round(view_ms, 4),
-                              "achieved": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
-                              "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "roofline": roof,
+            "reference_algorithm_equivalent": {
+                "what": "SURVEY 8(d) byte model of the REFERENCE algorithm (64-bit keys, 6 radix passes, reference binning "
+                        "rule N) per view / this implementation's per-view kernel time: the streaming rate a "
+                        "reference-shaped implementation would need to match; NOT bytes this code moves",
+                "bytes_per_view": R + Wt, "read_bytes_per_view": R, "kernel_ms_per_view": round(view_ms, 4),
+                "equivalent_GBps": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
+                "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0},
         }
-        if not args.no_cpu_baseline and world == 1:       # rank 0 at N=1 only: the other ranks would wait ~7 s at the barrier
-            out["cpu_baseline"] = cpu_baseline(P, W, H, args.seed)
-        result_line = json.dumps(out)
+        result = out
+    # ---- extras: other workloads of BASELINE.json's configs, measured in the same process ---------------------------
+    extras = {}
+    if not args.no_extras and not args.inner and args.path == "fused" and args.scaling == "weak" and args.views == 6:
+        del job
+        torch.cuda.empty_cache()
+        k = min(args.steps, 10)
+        if world > 1:
+            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "strong")
+            j.prepare(2)
+            el = j.timed(k)
+            extras["strong_scaling_6_views"] = {"iters_per_s": round(k / el, 2), "ms_per_step": round(el / k * 1e3, 3),
+                                                "views_per_rank": [len(b) for b in j.stepper.blocks], "steps": k,
+                                                "config": "BASELINE configs[3]: the SAME 3 input + 3 shifted views per iter, "
+                                                          "view-granular over the ranks"}
+            del j
+            torch.cuda.empty_cache()
+        j = Job(args, dev, rank, world, dp, 2_000_000, 1600, 1600, 50.0, 8, "strong")
+        j.prepare(2)
+        k5 = min(args.steps, 5)
+        el = j.timed(k5)
+        extras["config5_2M_1600x1600_8_views"] = {
+            "iters_per_s": round(k5 / el, 2), "ms_per_step": round(el / k5 * 1e3, 3), "mpix_per_s": round(8 * 1600 * 1600 * k5 / el / 1e6, 1),
+            "views_per_rank": [len(b) for b in j.stepper.blocks], "steps": k5,
+            "instances_N_binned_view0": (j.fused.num_rendered()[0] if j.local_views else None),
+            "config": "BASELINE configs[4]: 2M Gaussians @ 1600x1600, FoV 50, 8 input views per iter, view-granular"}
+        del j
+        torch.cuda.empty_cache()
+        if world == 1:
+            dargs = argparse.Namespace(**vars(args))
+            dargs.optimizer = "b3gs"
+            j = Job(dargs, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", path="dropin", graph=False)
+            j.prepare(2)
+            el = j.timed(5)
+            extras["dropin_iters_per_s"] = round(5 / el, 2)
+            extras["dropin_what"] = ("the same iteration through the reference-shaped surface: render() -> "
+                                     "GaussianRasterizer -> _C.rasterize_gaussians per view, PyTorch activations, "
+                                     "one host read-back of num_rendered per forward")
+            del j
+            torch.cuda.empty_cache()
+    if rank == 0:
+        if extras:
+            result["extras"] = extras
+        if world == 1 and not args.inner:
+            if not args.no_pmc:
+                pmc_passes(args, result)
+            if not args.no_cpu_baseline:       # rank 0 at N=1 only: the other ranks would wait at the barrier
+                result["cpu_baseline"] = cpu_baseline(P, W, H, args.seed)
+        result_line = json.dumps(result)
     if dp:
         dist.barrier()
         dist.destroy_process_group()
@@ -367,19 +494,109 @@ def main():
         print(result_line, flush=True)
 
 
+# ---- rocprofv3 counter passes over a short copy of the same workload (MI355X_MICROARCH.md, HBM / PMC sections) ------
+FWD_KERNELS = re.compile(r"preprocess_fwd|radix|scan_chunk|emit_instances|tile_ranges|render_fwd")
+
+
+def _pmc_pass(args, counters, tag):
+    """`rocprofv3 --kernel-trace --pmc <counters>` (counters only, own pass: never combined with another trace domain)
+    around `bench.py --inner`; returns {kernel: {counter: [values per dispatch]}} or raises."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    out = tempfile.mkdtemp(prefix=f"b3gs_pmc_{tag}_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", *counters.split(), "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--inner", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--steps", "3",
+           "--warmup", "1", "--gaussians", str(args.gaussians), "--width", str(args.width), "--height", str(args.height),
+           "--seed", str(args.seed), "--optimizer", args.optimizer, "--schedule", args.schedule]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            raise RuntimeError("no counter_collection.csv")
+        acc = {}
+        for r in csv.DictReader(open(files[0])):
+            name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+            name = re.sub(r"^void ", "", name).split("(")[0].split("<")[0]
+            acc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        return acc
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_passes(args, result):
+    """HBM bytes (two passes: FETCH_SIZE and WRITE_SIZE do not fit one) and the VALU picture (SQ + GRBM counters) of
+    every kernel, per launch; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled on gfx950 (the counter
+    tallies 128-byte requests as 64 B, MI355X_MICROARCH.md); the streaming Adam kernel calibrates the method (28 B per
+    parameter float)."""
+    roof = result["roofline"]
+    try:
+        fetch = _pmc_pass(args, "FETCH_SIZE", "f")
+        write = _pmc_pass(args, "WRITE_SIZE", "w")
+        valu = _pmc_pass(args, "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE", "v")
+    except Exception as exc:
+        roof["traffic"] = None
+        roof["pmc_error"] = repr(exc)[:200]
+        return
+    mean = lambda v: sum(v) / len(v)  # noqa: E731
+    per_launch = {k: int((2.0 * mean(c.get("FETCH_SIZE", [0.0])) + mean(write.get(k, {}).get("WRITE_SIZE", [0.0]))) * 1024)
+                  for k, c in fetch.items()}
+    n_fwd = len(fetch.get("render_fwd_kernel", {}).get("FETCH_SIZE", [])) or 1
+    n_bwd = len(fetch.get("render_bwd_kernel", {}).get("FETCH_SIZE", [])) or 1
+    per_iter = 0.0
+    for k, c in fetch.items():
+        n = len(c.get("FETCH_SIZE", []))
+        per_iter += per_launch[k] * n / (n_fwd if FWD_KERNELS.search(k) else n_bwd)
+    roof["traffic"] = per_launch.get(roof["kernel"])
+    if roof["traffic"] and roof["avg_launch_ms"] > 0:
+        roof["traffic_GBps"] = round(roof["traffic"] / (roof["avg_launch_ms"] / 1e3) / 1e9, 1)
+        roof["traffic_frac_of_peak"] = round(roof["traffic_GBps"] / HBM_PEAK_GBS, 4)
+    n_par = sum(p_ for p_ in (3, 3, 9, 3, 4, 1)) * args.gaussians
+    result["hbm_measured"] = {
+        "bytes_per_iter": int(per_iter), "GBps": round(per_iter / (result["ms_per_step"] / 1e3) / 1e9, 1),
+        "frac_of_peak": round(per_iter / (result["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+        "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE / WRITE_SIZE over `bench.py --inner "
+                  "--steps 3 --warmup 1` (same workload); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, summed over one "
+                  "iteration's launches",
+        "calibration_adam_bytes": per_launch.get("adam_kernel"), "calibration_adam_expected": 28 * n_par,
+        "per_launch_bytes": {k.replace("_kernel", ""): v for k, v in sorted(per_launch.items())
+                             if re.search(r"render|preprocess|radix|emit|scan|accumulate|adam", k)}}
+    vd = {}
+    for k in ("render_bwd_kernel", "render_fwd_kernel", "accumulate_views_kernel"):
+        c = valu.get(k)
+        if not c:
+            continue
+        cyc = mean(c["GRBM_GUI_ACTIVE"]) / 8.0                 # the counter is summed over the 8 XCDs
+        iv, tc = mean(c["SQ_INSTS_VALU"]), mean(c["SQ_THREAD_CYCLES_VALU"])
+        vd[k] = {"valu_insts_per_launch": int(iv), "cycles_per_launch": int(cyc),
+                 "issue_frac": round(iv * 2.0 / (cyc * CUS * SIMDS_PER_CU), 4), "active_lanes_per_inst": round(tc / iv, 2)}
+    if vd:
+        roof["valu"] = {"bound": "valu issue slots: 256 CUs x 4 SIMDs, one plain fp32 wave64 instruction per 2 cycles "
+                                 "(tools/ubench/valu_rate.hip); transcendental / DPP / LDS-path instructions occupy 8",
+                        "frac": vd.get(roof["kernel"], {}).get("issue_frac"), "kernels": vd}
+
+
 def cpu_baseline(P, W, H, seed):
-    """The oracle (C port, OpenMP) on the host cores: ONE full-size view, forward + backward, same
-    synthetic inputs (1/6 of an iteration).  Reported baseline only -- never on the product path."""
+    """The oracle (C port, OpenMP) on the host cores: ONE full-size iteration (6 views forward + backward), same
+    synthetic inputs.  Reported baseline only -- never on the product path."""
     from binocular3dgs_amd import synth
     from oracle import tile_ref
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
+    cpu_model, physical = "unknown", None
+    try:
+        txt = open("/proc/cpuinfo").read()
+        m = re.search(r"model name\s*:\s*(.+)", txt)
+        cpu_model = m.group(1).strip() if m else cpu_model
+        cores = {(a, b) for a, b in zip(re.findall(r"physical id\s*:\s*(\d+)", txt), re.findall(r"core id\s*:\s*(\d+)", txt))}
+        physical = len(cores) or None
+    except Exception:
+        pass
     model = synth.synth_model(P, seed=seed, device="cpu", width=W, height=H, requires_grad=False)
     gc, gd, ga = synth.synth_pixel_grads(W, H, seed=0)
     gc2 = synth.synth_pixel_grads(W, H, seed=100)[0]
     with torch.no_grad():
         base = dict(means3D=model.get_xyz.numpy(), opacities=model.get_opacity.numpy(),
                     scales=model.get_scaling.numpy(), rotations=model.get_rotation.numpy(),
-                    shs=model.get_features.numpy(), bg=[0.0, 0.0, 0.0], W=W, H=H, sh_degree=1, threads=cores)
+                    shs=model.get_features.numpy(), bg=[0.0, 0.0, 0.0], W=W, H=H, sh_degree=1, threads=threads)
     fwd_s = bwd_s = 0.0
     nviews = 0
     for cam, scam, _t in synth.synth_view_set(W, H):
@@ -395,9 +612,11 @@ def cpu_baseline(P, W, H, seed):
             bwd_s += t2 - t1
             nviews += 1
     it_s = fwd_s + bwd_s
-    return {"value": round(1.0 / it_s, 5), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H} (no all-reduce, no Adam): "
-                      f"fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; oracle/tile_ref.c, OpenMP {cores} threads",
+    return {"value": round(1.0 / it_s, 5), "unit": "iters/s", "cores": threads, "physical_cores": physical,
+            "cpu_model": cpu_model, "kind": "port",
+            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H} (no gradient sum, no Adam): "
+                      f"fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; oracle/tile_ref.c, OpenMP {threads} threads "
+                      f"({physical} physical cores, {cpu_model})",
             "ms_per_view": round(it_s / nviews * 1e3, 1)}
 
 

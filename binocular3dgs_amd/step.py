@@ -157,6 +157,7 @@ class ShardedAdam:
         self.world = dist.get_world_size(group) if _dist_on() else 1
         self.rank = dist.get_rank(group) if _dist_on() else 0
         self.adam_impl = adam_impl
+        self.force_collective = False   # issue the collectives even in a 1-rank group (path check on one GPU)
         self.step_count = None
         self._flatten(list(params), None, None)
 
@@ -189,7 +190,7 @@ class ShardedAdam:
             n = max(0, min(total, lo + self.chunk) - lo)
             self.exp_avg[:n].copy_(full_m[lo:lo + n])
             self.exp_avg_sq[:n].copy_(full_v[lo:lo + n])
-        self.gshard = torch.zeros(self.chunk, **f) if self.world > 1 else None
+        self.gshard = None              # reduce-scatter output, allocated on first use
         if self.step_count is None:
             self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -207,7 +208,10 @@ class ShardedAdam:
     def step(self, slab: FlatGradSlab, average: bool = False):
         assert slab.flat.numel() == self.padded_numel, "gradient slab must be padded to ShardedAdam.padded_numel"
         lo = self.rank * self.chunk
-        if self.world > 1:
+        collective = _dist_on() and (self.world > 1 or self.force_collective)
+        if collective:
+            if self.gshard is None:
+                self.gshard = torch.zeros(self.chunk, dtype=torch.float32, device=self.pflat.device)
             dist.reduce_scatter_tensor(self.gshard, slab.flat, op=dist.ReduceOp.SUM, group=self.group)
             g = self.gshard
             if average:
@@ -227,7 +231,7 @@ class ShardedAdam:
             _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr)
                           for p, gg, m, v, lr in segs], self.step_count, self.betas, self.eps, decay, opacity_seg,
                          self.decay_first, True, self.pflat.device)
-        if self.world > 1:
+        if collective:
             dist.all_gather_into_tensor(self.pflat, self.pflat[lo:lo + self.chunk], group=self.group)
 
     def zero_grad(self, set_to_none: bool = False):
