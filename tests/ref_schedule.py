@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE: the reference's training schedule (train.py:65-202), statement by statement, on a synthetic
+ground-truth scene -- run once on the HIP path and once on an oracle-backed CPU path so that their PSNR can be
+compared (SURVEY 8d last row: "PSNR within 0.1 dB ... vs a batch-1 run of the same schedule"; LLFF data does not
+exist in this environment, so the comparison target is the build's own oracle-backed run).
+
+Per iteration, in the reference's order:
+  update_learning_rate (xyz: get_expon_lr_func, train.py:83)       oneupSHdegree every `sh_interval` (:86-87)
+  one input view (:92, cycled deterministically instead of random.choice so both runs see the same sequence)
+  render (:100)   binocular-shifted render + warp loss once iteration > shift_cam_start (:124-136)
+  L1 + D-SSIM + disparity + alpha loss (:139-149)   backward
+  opacity_decay once iteration > densify_from_iter (:171-173)   densification statistics (:178-179)
+  densify_and_prune every densification_interval (:181-186, split noise shared between the runs)
+  optimizer.step / zero_grad (:196-198)
+"""
+import math
+
+import numpy as np
+import torch
+
+from binocular3dgs_amd import synth
+from binocular3dgs_amd.gaussian_model import GaussianModel, inverse_sigmoid
+from binocular3dgs_amd.loss import binocular_loss, expon_lr, psnr
+from binocular3dgs_amd.render import PipelineParams, render
+
+LR = dict(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, feature_lr=0.0025,
+          opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)   # arguments/__init__.py:75-82
+NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")   # group order of scene/gaussian_model.py:154-161
+
+
+class DispatchRasterizer:
+    """HIP rasterizer for device tensors, oracle stand-in for CPU tensors (patched over render.GaussianRasterizer)."""
+
+    def __init__(self, raster_settings):
+        self.raster_settings = raster_settings
+
+    def __call__(self, means3D, **kw):
+        if means3D.is_cuda:
+            from binocular3dgs_amd.rasterizer import GaussianRasterizer
+            return GaussianRasterizer(self.raster_settings)(means3D=means3D, **kw)
+        from cpu_render import OracleRasterizer
+        return OracleRasterizer(self.raster_settings)(means3D=means3D, **kw)
+
+
+def make_scene(W=160, H=120, P_gt=4000, seed=31, spatial_lr_scale=4.0):
+    """Ground-truth Gaussians, three input cameras, ground-truth images (oracle render: the same for both runs) and a
+    deterministic initial model: half of the true centres (jittered), grey, opacity 0.1 (scene/gaussian_model.py:
+    124-147 initialises opacity to 0.1 and colours from the point cloud)."""
+    import binocular3dgs_amd.render as R
+    R.GaussianRasterizer = DispatchRasterizer
+    gt = synth.synth_model(P_gt, seed=seed, device="cpu", width=W, height=H, requires_grad=False)
+    with torch.no_grad():
+        gt._scaling += 0.9
+    cams = synth.synth_cameras(W, H, yaws=synth.YAWS_6)
+    bg = torch.zeros(3)
+    with torch.no_grad():
+        gts = [render(c, gt, PipelineParams(), bg)["render"].clamp(0, 1) for c in cams]
+    g = torch.Generator().manual_seed(seed + 1)
+    idx = torch.randperm(P_gt, generator=g)[: P_gt // 2]
+    n = idx.numel()
+    init = dict(xyz=gt._xyz[idx] + 0.01 * torch.randn(n, 3, generator=g),
+                features_dc=torch.zeros(n, 1, 3), features_rest=torch.zeros(n, 3, 3),
+                scaling=gt._scaling[idx] - 0.2, rotation=torch.randn(n, 4, generator=g),
+                opacity=inverse_sigmoid(0.1 * torch.ones(n, 1)))
+    return dict(W=W, H=H, cams=cams, gts=gts, init=init, bg=bg, extent=spatial_lr_scale)
+
+
+def _optimizer(model, extent):
+    groups = [(model._xyz, LR["position_lr_init"] * extent), (model._features_dc, LR["feature_lr"]),
+              (model._features_rest, LR["feature_lr"] / 20.0), (model._opacity, LR["opacity_lr"]),
+              (model._scaling, LR["scaling_lr"]), (model._rotation, LR["rotation_lr"])]
+    return torch.optim.Adam([{"params": [p], "lr": lr, "name": n} for (p, lr), n in zip(groups, NAMES)], lr=0.0, eps=1e-15)
+
+
+def _densify_cpu(model, opt, thr, min_opacity, extent, noise):
+    """CPU counterpart of binocular3dgs_amd.densify.densify_and_prune (tests/densify_ref.py is pinned by G8)."""
+    from densify_ref import densify_and_prune
+    attr = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+                rotation="_rotation")
+    params = {n: getattr(model, a).detach() for n, a in attr.items()}
+    m, v = {}, {}
+    for n, a in attr.items():
+        st = opt.state.get(getattr(model, a), {})
+        m[n] = st.get("exp_avg", torch.zeros_like(params[n]))
+        v[n] = st.get("exp_avg_sq", torch.zeros_like(params[n]))
+    new_p, new_m, new_v = densify_and_prune(params, m, v, model.xyz_gradient_accum.clone(), model.denom.clone(), thr,
+                                            min_opacity, extent, None, 0.01, noise)
+    for group in opt.param_groups:
+        n = group["name"]
+        old = group["params"][0]
+        st = opt.state.pop(old, None)
+        p = torch.nn.Parameter(new_p[n].contiguous(), requires_grad=True)
+        setattr(model, attr[n], p)
+        group["params"][0] = p
+        if st:
+            st["exp_avg"], st["exp_avg_sq"] = new_m[n].contiguous(), new_v[n].contiguous()
+            opt.state[p] = st
+    newP = model._xyz.shape[0]
+    model.xyz_gradient_accum = torch.zeros((newP, 1))
+    model.denom = torch.zeros((newP, 1))
+    model.max_radii2D = torch.zeros((newP,))
+    return newP
+
+
+def train(scene, device, iterations=300, densify_from_iter=60, densification_interval=40, densify_grad_threshold=0.0002,
+          shift_cam_start=100, sh_interval=100, cam_trans_dist=0.4, opacity_decay=0.995, seed=5, eval_every=100):
+    """The reference loop on `device` ("cuda": the HIP rasterizer + HIP densification; "cpu": the oracle + the torch
+    densification).  Returns dict(psnr=[(iteration, mean train-view PSNR)], P=[(iteration, P after densify)])."""
+    import binocular3dgs_amd.render as R
+    R.GaussianRasterizer = DispatchRasterizer
+    i0 = scene["init"]
+    model = GaussianModel.from_tensors(i0["xyz"], i0["features_dc"], i0["features_rest"], i0["scaling"], i0["rotation"],
+                                       i0["opacity"], sh_degree=1, active_sh_degree=0, device=device)
+    model.init_densification_stats()
+    cams = [synth.synth_cameras(scene["W"], scene["H"], yaws=synth.YAWS_6, device=device)[k] for k in range(3)]
+    gts = [g.to(device) for g in scene["gts"]]
+    bg = scene["bg"].to(device)
+    extent = scene["extent"]
+    opt = _optimizer(model, extent)
+    pipe = PipelineParams()
+    rng = np.random.default_rng(seed)                     # trans_dist sequence shared by both runs
+    shifts = (rng.random(iterations + 1) * cam_trans_dist) * rng.choice([-1.0, 1.0], iterations + 1)
+    hist = dict(psnr=[], P=[])
+
+    def mean_psnr():
+        with torch.no_grad():
+            return float(np.mean([float(psnr(render(c, model, pipe, bg)["render"].clamp(0, 1)[None], g[None]).mean())
+                                  for c, g in zip(cams, gts)]))
+
+    for it in range(1, iterations + 1):
+        lr = expon_lr(it, LR["position_lr_init"] * extent, LR["position_lr_final"] * extent,
+                      lr_delay_mult=LR["position_lr_delay_mult"], max_steps=iterations)
+        opt.param_groups[0]["lr"] = lr
+        if it % sh_interval == 0:
+            model.oneupSHdegree()
+        k = (it - 1) % len(cams)
+        cam, gt = cams[k], gts[k]
+        pkg = render(cam, model, pipe, bg)
+        shifted, t = None, None
+        if it > shift_cam_start:
+            t = float(shifts[it])
+            shifted = render(cam.shifted(t), model, pipe, bg)["render"]
+        total, _ = binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gt, shifted_image=shifted,
+                                  focal_x=cam.get_focal()[0], trans_dist=t)
+        total.backward()
+        with torch.no_grad():
+            if opacity_decay and it > densify_from_iter:
+                o = model.get_opacity * opacity_decay
+                model._opacity.data = inverse_sigmoid(o)
+            vis = pkg["visibility_filter"]
+            model.update_max_radii(pkg["radii"], vis)
+            model.add_densification_stats(pkg["viewspace_points"].grad, vis)
+            if it > densify_from_iter and it % densification_interval == 0:
+                P = model.get_xyz.shape[0]
+                noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it))
+                if device == "cpu":
+                    newP = _densify_cpu(model, opt, densify_grad_threshold, 0.005, extent, noise)
+                else:
+                    from binocular3dgs_amd.densify import densify_and_prune
+                    newP = densify_and_prune(model, opt, densify_grad_threshold, 0.005, extent, None, noise=noise.to(device))
+                hist["P"].append((it, int(newP)))
+            if it < iterations:
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+        if it % eval_every == 0 or it == iterations:
+            hist["psnr"].append((it, mean_psnr()))
+    return hist

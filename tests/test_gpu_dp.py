@@ -75,3 +75,63 @@ def test_two_ranks_on_one_gpu_equal_one_process_with_all_pairs(tmp_path, pipelin
     assert rel < 1e-6, rel                                               # sum over ranks == sum over pairs (fp32 order)
     np.testing.assert_array_equal(r0["denom"], ref_denom)
     np.testing.assert_array_equal(r1["denom"], ref_denom)
+
+
+def _run_views(world_rank, steps, sharded):
+    """3 pairs through ViewShardedStep.from_global (view-granular blocks), fused rasterizer, the fused binocular loss
+    (so that a split pair really exchanges the shifted image and its gradient), ShardedAdam or FusedAdam."""
+    sys.path.insert(0, ROOT)
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.fused_loss import binocular_loss_fused_batch
+    from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+    W, H, P = 160, 120, 9000
+    dev = "cuda"
+    rank, world = world_rank
+    model = synth.synth_model(P, seed=13, device=dev, width=W, height=H)
+    with torch.no_grad():
+        model._scaling += 0.5
+    model.init_densification_stats()
+    pairs = synth.synth_view_set(W, H, device=dev)
+    bg = torch.zeros(3, device=dev)
+    gts = [torch.rand(3, H, W, generator=torch.Generator().manual_seed(40 + i)).to(dev) for i in range(3)]
+    opt = (ShardedAdam if sharded else FusedAdam)(model.parameters(), LRS, eps=1e-15)
+    from binocular3dgs_amd.step import assign_views
+    nloc = len(assign_views([True] * 3, world)[rank])
+    fr = FusedRasterizer(model, W, H, num_slots=max(nloc, 1), want_means2D=False)
+    st = ViewShardedStep.from_global(model, pairs, bg, rank=rank, world=world, optimizer=opt, fused=fr)
+
+    def batch_loss(items):
+        return binocular_loss_fused_batch(
+            [dict(image=pkg["render"], depth=pkg["rendered_depth"], alpha=pkg["rendered_alpha"], gt_image=gts[i],
+                  shifted_image=None if spkg is None else spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t)
+             for i, cam, pkg, spkg, t in items], unit_grad=True)
+    for _ in range(steps):
+        st.step(batch_loss_fn=batch_loss)
+    st.sync_densify_stats()
+    torch.cuda.synchronize()
+    return (torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy(), model.denom.cpu().numpy(),
+            sum(v.peer is not None for v in st.views))
+
+
+def _worker_views(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params, denom, split = _run_views((rank, world), steps=2, sharded=True)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), params=params, denom=denom, split=np.array(split))
+    dist.destroy_process_group()
+
+
+def test_view_granular_split_pair_and_sharded_adam_on_one_gpu(tmp_path):
+    """Two ranks, 3+3 views: pair 1 straddles the ranks (its shifted image and the gradient of it travel point to
+    point), reduce-scatter -> Adam on half of the flat parameter buffer -> all-gather.  Equals one process."""
+    import torch.multiprocessing as mp
+    ref_params, ref_denom, _ = _run_views((0, 1), steps=2, sharded=False)
+    mp.spawn(_worker_views, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert int(r0["split"]) == 1 and int(r1["split"]) == 1
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    rel = np.linalg.norm(r0["params"] - ref_params) / np.linalg.norm(ref_params)
+    assert rel < 1e-6, rel
+    np.testing.assert_array_equal(r0["denom"], ref_denom)

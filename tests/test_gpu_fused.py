@@ -402,3 +402,102 @@ def test_single_view_raw_entry_points_match_the_batched_path():
     assert rel_l2(m2d.cpu().numpy(), ref_m2d.cpu().numpy()) < 1e-5
     for g, r in zip(grads, ref):
         assert rel_l2((g / 2).cpu().numpy(), r.cpu().numpy()) < 2e-5
+
+
+def test_adam_reference_decay_order_empty_segment_and_error_text():
+    """(i) decay_first: the reference decays the opacity logits BEFORE optimizer.step() (train.py:171-173 vs :196-198):
+    p <- logit(sigmoid(p) f) - delta(g); (ii) a zero-width tensor (features_rest at SH degree 0: [P,0,3], data_ptr 0)
+    is an empty segment, not an error; (iii) a failing call leaves a message in b3gs_last_error."""
+    import ctypes as C
+    from binocular3dgs_amd import _lib
+    from binocular3dgs_amd.step import FusedAdam
+    torch.manual_seed(1)
+    shapes = [(4000, 3), (4000, 1, 3), (4000, 0, 3), (4000, 3), (4000, 4), (4000, 1)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs) if p.numel()], eps=1e-15)
+    mine = FusedAdam(b, lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True)
+    for it in range(3):
+        for p, q in zip(a, b):
+            g = torch.randn_like(p) * 0.01
+            p.grad, q.grad = g.clone(), g.clone()
+        with torch.no_grad():      # train.py:171-173: opacity_decay() on .data, then optimizer.step()
+            o = torch.sigmoid(a[5]) * 0.995
+            a[5].copy_(torch.log(o / (1 - o)))
+        ref.step()
+        mine.step()
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        if p.numel():
+            assert float((p - q).abs().max()) < 5e-6 * max(1.0, float(p.abs().max()))
+    seg = (_lib.B3gsAdamSegment * 1)()
+    seg[0].count, seg[0].lr = 5, 1e-3          # non-empty segment with NULL pointers
+    rc = _lib.lib().b3gs_adam_step(1, seg, mine.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None)
+    assert rc == -1 and b"b3gs_adam_step" in _lib.lib().b3gs_last_error()
+    io = _lib.B3gsDensifyIO()
+    io.P, io.M = 4, 0
+    assert _lib.lib().b3gs_densify_classify(C.byref(io), None, None) == -1
+    assert b"densify" in _lib.lib().b3gs_last_error()
+
+
+def test_sharded_adam_one_rank_equals_fused_adam_and_survives_densification():
+    """ShardedAdam with one rank = the one-launch Adam on flat buffers: same parameters as FusedAdam step for step;
+    the parameters live in one flat buffer (views), and densify_and_prune re-flattens them with the moments carried."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+    W, H = 160, 120
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    fn = lambda i, pkg, spkg: [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]  # noqa: E731
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+    res = []
+    for cls in (FusedAdam, ShardedAdam):
+        model, pairs, bg = _setup(P=9001, W=W, H=H)
+        model.init_densification_stats()
+        opt = cls(model.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr)
+        for _ in range(3):
+            st.step(pair_grad_fn=fn)
+        noise = torch.randn(2, 9001, 3, generator=torch.Generator().manual_seed(3)).cuda()
+        thr = float((model.xyz_gradient_accum / model.denom.clamp(min=1)).quantile(0.7))
+        newP = st.densify_and_prune(thr, 0.005, 5.0, noise=noise)
+        assert newP == model.get_xyz.shape[0] and newP != 9001
+        for _ in range(2):
+            st.step(pair_grad_fn=fn)
+        torch.cuda.synchronize()
+        if cls is ShardedAdam:
+            lo = opt.pflat.data_ptr()
+            assert all(lo <= p.data_ptr() < lo + 4 * opt.padded_numel for p in model.parameters())
+            assert st.slab.flat.numel() == opt.padded_numel
+        res.append([p.detach().clone() for p in model.parameters()] + [model.denom.clone()])
+    for x, y in zip(*res):
+        assert x.shape == y.shape and rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6
+
+
+def test_step_detects_binning_overflow_and_grows():
+    """The step object never trains on truncated tile lists unknowingly: the largest device-side N since the last
+    check is compared with the capacity at check_capacity() (every overflow_check_every steps / at densification)."""
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import ViewShardedStep
+    W, H = 160, 120
+    model, pairs, bg = _setup(P=6000, W=W, H=H)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    fn = lambda i, pkg, spkg: [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]  # noqa: E731
+    fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), binning_capacity=1000)
+    st = ViewShardedStep(model, pairs, bg, fused=fr, overflow_check_every=2)
+    need = max(fr.num_rendered())
+    assert fr.capacity >= need > 1000            # fit_capacity() at construction sized the buffers from the actual N
+    st.step(pair_grad_fn=fn)
+    st.step(pair_grad_fn=fn)                     # second step runs the periodic check: nothing to report
+    fr.capacity = 1000                           # simulate a scene that outgrew its buffers
+    for i in range(len(fr.slots)):
+        fr.slots[i] = fr._new_slot(fr.slots[i].stream, i)
+    st.step(pair_grad_fn=fn)
+    with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
+        st.step(pair_grad_fn=fn)
+    assert fr.capacity >= need
+    st.step(pair_grad_fn=fn)
+    st.check_capacity()
