@@ -673,99 +673,160 @@ struct MultiViews {
 #ifndef B3GS_ACC_WAVES
 #define B3GS_ACC_WAVES 3   /* 168 VGPRs (40 B spilled) beats 182 VGPRs at 2 waves per SIMD: 0.060 -> 0.053 ms per view */
 #endif
+// Most visible Gaussians of a view lie behind the saturation point of every pixel they cover: only ~8 % of the
+// (Gaussian, view) rows receive anything from the blend backward, ~20 % of the Gaussians have at least one such view.
+// With lane = Gaussian and a wave-uniform view loop the chain rule ran with ~5 of 64 lanes active (PMC:
+// SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = 4.9) while every wave still executed it for every view.  So the pass is
+// split inside one workgroup of 256 threads / ACC_BLOCK = 1024 Gaussians:
+//   phase 1 (streaming, all lanes): read every view's radius + scratch row (coalesced), update the densification
+//           statistics, write the optional screen-space gradients, store zero gradients for untouched Gaussians
+//           (overwrite mode), and append (local index | touched-view mask) of the others to an LDS list -- wave ballot +
+//           one LDS atomic per wave;
+//   phase 2 (compute, compacted): lane = list entry; the view loop runs only over the entry's touched views
+//           (row read + reset, chain rule, 23 gradients in registers), gradients written once.
+constexpr int ACC_PER_THREAD = 4;
+constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
+
 __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
     accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
                             int count, B3gsDensifyStats ds) {
+  __shared__ uint32_t s_list[ACC_BLOCK];
+  __shared__ uint32_t s_count;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
   // Gaussians [first, first + count): every pointer is indexed by the GLOBAL Gaussian index
-  const int i = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= first + count) return;
-  const size_t i3 = 3 * (size_t)i;
+  const int blk_first = first + (int)blockIdx.x * ACC_BLOCK;
+  const int end = first + count;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int nrest = 3 * (base.M - 1);
+
+  // ---- phase 1 ------------------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int j = 0; j < ACC_PER_THREAD; j++) {
+    const int li = j * 256 + (int)threadIdx.x;
+    const int i = blk_first + li;
+    uint32_t mask = 0;
+    if (i < end) {
+      const size_t i3 = 3 * (size_t)i;
+      float st_norm = 0.f, st_cnt = 0.f;
+      int st_rad = 0;
+      for (int v = 0; v < mv.n; v++) {
+        const B3gsViewRef& vr = mv.v[v];
+        float* m2d = vr.dL_dmeans2D;
+        const int rad = vr.radii[i];
+        if (rad <= 0) {
+          if (m2d) { m2d[i3] = 0.f; m2d[i3 + 1] = 0.f; m2d[i3 + 2] = 0.f; }
+          continue;
+        }
+        const float2* row = reinterpret_cast<const float2*>(vr.scratch) + 5 * (size_t)i;
+        const float2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+        // sums are never -0.0 (atomic adds onto +0.0), so the bit pattern tells "nothing arrived"
+        const uint32_t any = ((__float_as_uint(r0.x) | __float_as_uint(r0.y)) | (__float_as_uint(r1.x) | __float_as_uint(r1.y))) |
+                             ((__float_as_uint(r2.x) | __float_as_uint(r2.y)) | (__float_as_uint(r3.x) | __float_as_uint(r3.y))) |
+                             (__float_as_uint(r4.x) | __float_as_uint(r4.y));
+        if (any) mask |= 1u << v;
+        if (m2d) { m2d[i3] = r2.x; m2d[i3 + 1] = r2.y; m2d[i3 + 2] = 0.f; }
+        if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
+          st_norm += sqrtf(r2.x * r2.x + r2.y * r2.y);
+          st_cnt += 1.0f;
+          st_rad = max(st_rad, rad);
+        }
+      }
+      if (ds.denom && st_cnt > 0.f) {
+        ds.xyz_gradient_accum[i] += st_norm;
+        ds.denom[i] += st_cnt;
+        ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
+      }
+      if (mask == 0u && overwrite) {   // no view has a gradient for this Gaussian: its rows of the slab are zero
+        rg.xyz[i3] = 0.f; rg.xyz[i3 + 1] = 0.f; rg.xyz[i3 + 2] = 0.f;
+        rg.scaling[i3] = 0.f; rg.scaling[i3 + 1] = 0.f; rg.scaling[i3 + 2] = 0.f;
+        reinterpret_cast<float4*>(rg.rotation)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rg.opacity[i] = 0.f;
+        rg.features_dc[i3] = 0.f; rg.features_dc[i3 + 1] = 0.f; rg.features_dc[i3 + 2] = 0.f;
+        float* rest = rg.features_rest + (size_t)nrest * i;
+        for (int k = 0; k < nrest; k++) rest[k] = 0.f;
+      }
+    }
+    const unsigned long long b = __ballot(mask != 0u);
+    if (b) {
+      const int leader = __builtin_ctzll(b);
+      uint32_t at = 0;
+      if ((int)lane == leader) at = atomicAdd(&s_count, (uint32_t)__builtin_popcountll(b));
+      at = (uint32_t)__shfl((int)at, leader, 64);
+      if (mask != 0u) s_list[at + (uint32_t)__builtin_popcountll(b & lt)] = (uint32_t)li | (mask << 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2 ------------------------------------------------------------------------------------------
+  const uint32_t n_list = s_count;
   SceneX sx_;
   sx_.sc = base;
   sx_.raw = raw;
   sx_.raw_mode = 1;
   sx_.tight = 0;
-  float dxyz[3] = {0.f, 0.f, 0.f}, dscaling[3] = {0.f, 0.f, 0.f}, dop = 0.f;
-  float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
-  ShAddReg<4> sink;
+#pragma unroll 1
+  for (uint32_t e = threadIdx.x; e < n_list; e += 256) {
+    const uint32_t ent = s_list[e];
+    const int i = blk_first + (int)(ent & 0xFFFFu);
+    const uint32_t mask = ent >> 16;
+    const size_t i3 = 3 * (size_t)i;
+    float dxyz[3] = {0.f, 0.f, 0.f}, dscaling[3] = {0.f, 0.f, 0.f}, dop = 0.f;
+    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+    ShAddReg<4> sink;
 #pragma unroll
-  for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
-  sink.dc = rg.features_dc + i3;
-  sink.rest = rg.features_rest + (size_t)3 * (base.M - 1) * i;
-  if (overwrite && base.M > 4)  // coefficients beyond the register window accumulate in memory
-    for (int k = 9; k < 3 * (base.M - 1); k++) sink.rest[k] = 0.f;
-  bool any = false;
-  float st_norm = 0.f, st_cnt = 0.f;
-  int st_rad = 0;
-  int rad_next = mv.v[0].radii[i];
-  for (int v = 0; v < mv.n; v++) {
-    const B3gsViewRef& vr = mv.v[v];
-    float* m2d = vr.dL_dmeans2D;
-    const int rad = rad_next;
-    if (v + 1 < mv.n) rad_next = mv.v[v + 1].radii[i];   // in flight during this view's chain rule
-    if (rad <= 0) {
-      if (m2d) { m2d[i3] = 0.f; m2d[i3 + 1] = 0.f; m2d[i3 + 2] = 0.f; }
-      continue;
+    for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
+    sink.dc = rg.features_dc + i3;
+    sink.rest = rg.features_rest + (size_t)nrest * i;
+    if (overwrite && base.M > 4)  // coefficients beyond the register window accumulate in memory
+      for (int k = 9; k < nrest; k++) sink.rest[k] = 0.f;
+    for (int v = 0; v < mv.n; v++) {
+      if (!((mask >> v) & 1u)) continue;
+      const B3gsViewRef& vr = mv.v[v];
+      sx_.sc.W = vr.W; sx_.sc.H = vr.H;
+      sx_.sc.tan_fovx = vr.tan_fovx; sx_.sc.tan_fovy = vr.tan_fovy;
+      sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
+      const Mat16 vm = load_mat(vr.viewmatrix);
+      const Mat16 pm = load_mat(vr.projmatrix);
+      const PixSums in = load_scratch_row(vr.scratch, i);   // read the sums, leave the row zero for the next iteration
+      GaussGrad gg;
+      gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
+      dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
+      float dsc[3];
+      float4 dr;
+      raw_chain(gg, dsc, dr);
+      dscaling[0] += dsc[0]; dscaling[1] += dsc[1]; dscaling[2] += dsc[2];
+      drot.x += dr.x; drot.y += dr.y; drot.z += dr.z; drot.w += dr.w;
+      dop += in.gop;
     }
-    any = true;
-    sx_.sc.W = vr.W; sx_.sc.H = vr.H;
-    sx_.sc.tan_fovx = vr.tan_fovx; sx_.sc.tan_fovy = vr.tan_fovy;
-    sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
-    const Mat16 vm = load_mat(vr.viewmatrix);
-    const Mat16 pm = load_mat(vr.projmatrix);
-    // read the row; only a row that received something is reset (and only it has a gradient to push through the
-    // chain rule): most visible Gaussians of a view lie behind the saturation point of every pixel they cover
-    bool touched;
-    const PixSums in = load_scratch_row(vr.scratch, i, &touched);
-    if (m2d) { m2d[i3] = in.g2x; m2d[i3 + 1] = in.g2y; m2d[i3 + 2] = 0.f; }
-    if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
-      st_norm += sqrtf(in.g2x * in.g2x + in.g2y * in.g2y);
-      st_cnt += 1.0f;
-      st_rad = max(st_rad, rad);
+    const float op = load_opacity<true>(sx_, i);
+    dop = dop * op * (1.0f - op);
+    const int nreg = base.M < 4 ? base.M : 4;
+    float4* rot_dst = reinterpret_cast<float4*>(rg.rotation) + i;
+    if (overwrite) {
+      rg.xyz[i3] = dxyz[0]; rg.xyz[i3 + 1] = dxyz[1]; rg.xyz[i3 + 2] = dxyz[2];
+      rg.scaling[i3] = dscaling[0]; rg.scaling[i3 + 1] = dscaling[1]; rg.scaling[i3 + 2] = dscaling[2];
+      *rot_dst = drot;
+      rg.opacity[i] = dop;
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) sink.dc[ch] = sink.acc[ch];
+#pragma unroll
+      for (int k = 1; k < 4; k++)
+        if (k < nreg) { sink.rest[3 * (k - 1)] = sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] = sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] = sink.acc[3 * k + 2]; }
+    } else {
+      rg.xyz[i3] += dxyz[0]; rg.xyz[i3 + 1] += dxyz[1]; rg.xyz[i3 + 2] += dxyz[2];
+      rg.scaling[i3] += dscaling[0]; rg.scaling[i3 + 1] += dscaling[1]; rg.scaling[i3 + 2] += dscaling[2];
+      float4 cur = *rot_dst;
+      cur.x += drot.x; cur.y += drot.y; cur.z += drot.z; cur.w += drot.w;
+      *rot_dst = cur;
+      rg.opacity[i] += dop;
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) sink.dc[ch] += sink.acc[ch];
+#pragma unroll
+      for (int k = 1; k < 4; k++)
+        if (k < nreg) { sink.rest[3 * (k - 1)] += sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] += sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] += sink.acc[3 * k + 2]; }
     }
-    if (!touched) continue;
-    GaussGrad gg;
-    gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
-    dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
-    float dsc[3];
-    float4 dr;
-    raw_chain(gg, dsc, dr);
-    dscaling[0] += dsc[0]; dscaling[1] += dsc[1]; dscaling[2] += dsc[2];
-    drot.x += dr.x; drot.y += dr.y; drot.z += dr.z; drot.w += dr.w;
-    dop += in.gop;
-  }
-  if (ds.denom && st_cnt > 0.f) {
-    ds.xyz_gradient_accum[i] += st_norm;
-    ds.denom[i] += st_cnt;
-    ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
-  }
-  if (!any && !overwrite) return;
-  const float op = load_opacity<true>(sx_, i);
-  dop = dop * op * (1.0f - op);
-  const int nreg = base.M < 4 ? base.M : 4;
-  float4* rot_dst = reinterpret_cast<float4*>(rg.rotation) + i;
-  if (overwrite) {
-    rg.xyz[i3] = dxyz[0]; rg.xyz[i3 + 1] = dxyz[1]; rg.xyz[i3 + 2] = dxyz[2];
-    rg.scaling[i3] = dscaling[0]; rg.scaling[i3 + 1] = dscaling[1]; rg.scaling[i3 + 2] = dscaling[2];
-    *rot_dst = drot;
-    rg.opacity[i] = dop;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) sink.dc[ch] = sink.acc[ch];
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-      if (k < nreg) { sink.rest[3 * (k - 1)] = sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] = sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] = sink.acc[3 * k + 2]; }
-  } else {
-    rg.xyz[i3] += dxyz[0]; rg.xyz[i3 + 1] += dxyz[1]; rg.xyz[i3 + 2] += dxyz[2];
-    rg.scaling[i3] += dscaling[0]; rg.scaling[i3 + 1] += dscaling[1]; rg.scaling[i3 + 2] += dscaling[2];
-    float4 cur = *rot_dst;
-    cur.x += drot.x; cur.y += drot.y; cur.z += drot.z; cur.w += drot.w;
-    *rot_dst = cur;
-    rg.opacity[i] += dop;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) sink.dc[ch] += sink.acc[ch];
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-      if (k < nreg) { sink.rest[3 * (k - 1)] += sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] += sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] += sink.acc[3 * k + 2]; }
   }
 }
 
@@ -827,8 +888,8 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   mv.n = nviews;
   for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
   const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(accumulate_views_kernel, dim3((count + 255) / 256), dim3(256), 0, s, base, raw, mv, rg, overwrite,
-                     first, count, ds);
+  hipLaunchKernelGGL(accumulate_views_kernel, dim3((count + ACC_BLOCK - 1) / ACC_BLOCK), dim3(256), 0, s, base, raw, mv, rg,
+                     overwrite, first, count, ds);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

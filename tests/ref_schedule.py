@@ -101,66 +101,110 @@ def _densify_cpu(model, opt, thr, min_opacity, extent, noise):
     return newP
 
 
-def train(scene, device, iterations=300, densify_from_iter=60, densification_interval=40, densify_grad_threshold=0.0002,
-          shift_cam_start=100, sh_interval=100, cam_trans_dist=0.4, opacity_decay=0.995, seed=5, eval_every=100):
+class Trainer:
     """The reference loop on `device` ("cuda": the HIP rasterizer + HIP densification; "cpu": the oracle + the torch
-    densification).  Returns dict(psnr=[(iteration, mean train-view PSNR)], P=[(iteration, P after densify)])."""
-    import binocular3dgs_amd.render as R
-    R.GaussianRasterizer = DispatchRasterizer
-    i0 = scene["init"]
-    model = GaussianModel.from_tensors(i0["xyz"], i0["features_dc"], i0["features_rest"], i0["scaling"], i0["rotation"],
-                                       i0["opacity"], sh_degree=1, active_sh_degree=0, device=device)
-    model.init_densification_stats()
-    cams = [synth.synth_cameras(scene["W"], scene["H"], yaws=synth.YAWS_6, device=device)[k] for k in range(3)]
-    gts = [g.to(device) for g in scene["gts"]]
-    bg = scene["bg"].to(device)
-    extent = scene["extent"]
-    opt = _optimizer(model, extent)
-    pipe = PipelineParams()
-    rng = np.random.default_rng(seed)                     # trans_dist sequence shared by both runs
-    shifts = (rng.random(iterations + 1) * cam_trans_dist) * rng.choice([-1.0, 1.0], iterations + 1)
-    hist = dict(psnr=[], P=[])
+    densification), one iteration per step() so that two trainers can also be run in lockstep from a shared state."""
 
-    def mean_psnr():
+    def __init__(self, scene, device, iterations=300, densify_from_iter=60, densification_interval=40,
+                 densify_grad_threshold=0.0002, shift_cam_start=100, sh_interval=100, cam_trans_dist=0.4,
+                 opacity_decay=0.995, seed=5):
+        import binocular3dgs_amd.render as R
+        R.GaussianRasterizer = DispatchRasterizer
+        self.__dict__.update(device=device, iterations=iterations, densify_from_iter=densify_from_iter,
+                             densification_interval=densification_interval, thr=densify_grad_threshold,
+                             shift_cam_start=shift_cam_start, sh_interval=sh_interval, opacity_decay=opacity_decay)
+        i0 = scene["init"]
+        self.model = GaussianModel.from_tensors(i0["xyz"], i0["features_dc"], i0["features_rest"], i0["scaling"],
+                                                i0["rotation"], i0["opacity"], sh_degree=1, active_sh_degree=0, device=device)
+        self.model.init_densification_stats()
+        self.cams = synth.synth_cameras(scene["W"], scene["H"], yaws=synth.YAWS_6, device=device)[:3]
+        self.gts = [g.to(device) for g in scene["gts"]]
+        self.bg = scene["bg"].to(device)
+        self.extent = scene["extent"]
+        self.opt = _optimizer(self.model, self.extent)
+        self.pipe = PipelineParams()
+        rng = np.random.default_rng(seed)                     # trans_dist sequence shared by all runs
+        self.shifts = (rng.random(iterations + 1) * cam_trans_dist) * rng.choice([-1.0, 1.0], iterations + 1)
+        self.last_newP = None
+
+    def mean_psnr(self):
         with torch.no_grad():
-            return float(np.mean([float(psnr(render(c, model, pipe, bg)["render"].clamp(0, 1)[None], g[None]).mean())
-                                  for c, g in zip(cams, gts)]))
+            return float(np.mean([float(psnr(render(c, self.model, self.pipe, self.bg)["render"].clamp(0, 1)[None],
+                                             g[None]).mean()) for c, g in zip(self.cams, self.gts)]))
 
-    for it in range(1, iterations + 1):
-        lr = expon_lr(it, LR["position_lr_init"] * extent, LR["position_lr_final"] * extent,
-                      lr_delay_mult=LR["position_lr_delay_mult"], max_steps=iterations)
-        opt.param_groups[0]["lr"] = lr
-        if it % sh_interval == 0:
+    def step(self, it):
+        model, opt, extent = self.model, self.opt, self.extent
+        opt.param_groups[0]["lr"] = expon_lr(it, LR["position_lr_init"] * extent, LR["position_lr_final"] * extent,
+                                             lr_delay_mult=LR["position_lr_delay_mult"], max_steps=self.iterations)
+        if it % self.sh_interval == 0:
             model.oneupSHdegree()
-        k = (it - 1) % len(cams)
-        cam, gt = cams[k], gts[k]
-        pkg = render(cam, model, pipe, bg)
+        k = (it - 1) % len(self.cams)
+        cam, gt = self.cams[k], self.gts[k]
+        pkg = render(cam, model, self.pipe, self.bg)
         shifted, t = None, None
-        if it > shift_cam_start:
-            t = float(shifts[it])
-            shifted = render(cam.shifted(t), model, pipe, bg)["render"]
+        if it > self.shift_cam_start:
+            t = float(self.shifts[it])
+            shifted = render(cam.shifted(t), model, self.pipe, self.bg)["render"]
         total, _ = binocular_loss(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gt, shifted_image=shifted,
                                   focal_x=cam.get_focal()[0], trans_dist=t)
         total.backward()
+        self.last_newP = None
         with torch.no_grad():
-            if opacity_decay and it > densify_from_iter:
-                o = model.get_opacity * opacity_decay
-                model._opacity.data = inverse_sigmoid(o)
+            if self.opacity_decay and it > self.densify_from_iter:
+                model._opacity.data = inverse_sigmoid(model.get_opacity * self.opacity_decay)
             vis = pkg["visibility_filter"]
             model.update_max_radii(pkg["radii"], vis)
             model.add_densification_stats(pkg["viewspace_points"].grad, vis)
-            if it > densify_from_iter and it % densification_interval == 0:
+            if it > self.densify_from_iter and it % self.densification_interval == 0:
                 P = model.get_xyz.shape[0]
                 noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it))
-                if device == "cpu":
-                    newP = _densify_cpu(model, opt, densify_grad_threshold, 0.005, extent, noise)
+                if self.device == "cpu":
+                    self.last_newP = _densify_cpu(model, opt, self.thr, 0.005, extent, noise)
                 else:
                     from binocular3dgs_amd.densify import densify_and_prune
-                    newP = densify_and_prune(model, opt, densify_grad_threshold, 0.005, extent, None, noise=noise.to(device))
-                hist["P"].append((it, int(newP)))
-            if it < iterations:
+                    self.last_newP = densify_and_prune(model, opt, self.thr, 0.005, extent, None, noise=noise.to(self.device))
+            if it < self.iterations:
                 opt.step()
                 opt.zero_grad(set_to_none=True)
+        return float(total.detach())
+
+    # ---- state transfer (lockstep runs): parameters, Adam moments + step, densification statistics, SH degree -----
+    def get_state(self):
+        m, st = self.model, []
+        for g in self.opt.param_groups:
+            p = g["params"][0]
+            s = self.opt.state.get(p, {})
+            st.append(dict(p=p.detach().cpu().clone(), m=None if not s else s["exp_avg"].cpu().clone(),
+                           v=None if not s else s["exp_avg_sq"].cpu().clone(),
+                           step=None if not s else float(s["step"])))
+        return dict(groups=st, accum=m.xyz_gradient_accum.cpu().clone(), denom=m.denom.cpu().clone(),
+                    radii=m.max_radii2D.cpu().clone(), sh=m.active_sh_degree)
+
+    def set_state(self, state):
+        m, dev = self.model, self.device
+        attr = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+                    rotation="_rotation")
+        for g, s in zip(self.opt.param_groups, state["groups"]):
+            old = g["params"][0]
+            self.opt.state.pop(old, None)
+            p = torch.nn.Parameter(s["p"].to(dev).contiguous(), requires_grad=True)
+            setattr(m, attr[g["name"]], p)
+            g["params"][0] = p
+            if s["m"] is not None:
+                self.opt.state[p] = dict(step=torch.tensor(s["step"]), exp_avg=s["m"].to(dev).contiguous(),
+                                         exp_avg_sq=s["v"].to(dev).contiguous())
+        m.xyz_gradient_accum, m.denom = state["accum"].to(dev), state["denom"].to(dev)
+        m.max_radii2D, m.active_sh_degree = state["radii"].to(dev), state["sh"]
+
+
+def train(scene, device, iterations=300, eval_every=100, **kw):
+    """Free run.  Returns dict(psnr=[(iteration, mean train-view PSNR)], P=[(iteration, P after densify)])."""
+    tr = Trainer(scene, device, iterations=iterations, **kw)
+    hist = dict(psnr=[], P=[])
+    for it in range(1, iterations + 1):
+        tr.step(it)
+        if tr.last_newP is not None:
+            hist["P"].append((it, int(tr.last_newP)))
         if it % eval_every == 0 or it == iterations:
-            hist["psnr"].append((it, mean_psnr()))
+            hist["psnr"].append((it, tr.mean_psnr()))
     return hist
