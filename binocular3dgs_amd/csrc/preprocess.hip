@@ -684,7 +684,10 @@ struct MultiViews {
 //           one LDS atomic per wave;
 //   phase 2 (compute, compacted): lane = list entry; the view loop runs only over the entry's touched views
 //           (row read + reset, chain rule, 23 gradients in registers), gradients written once.
-constexpr int ACC_PER_THREAD = 4;
+#ifndef B3GS_ACC_PER_THREAD
+#define B3GS_ACC_PER_THREAD 4
+#endif
+constexpr int ACC_PER_THREAD = B3GS_ACC_PER_THREAD;
 constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
 
 __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)

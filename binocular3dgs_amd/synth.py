@@ -20,8 +20,10 @@ def fovy_from(fovx: float, width: int, height: int) -> float:
     return 2.0 * math.atan(math.tan(fovx * 0.5) * height / width)
 
 
-def synth_gaussians(P: int, seed: int = 0, width: int = 800, height: int = 600, fovx_deg: float = 60.0, K: int = 4):
-    """Raw (pre-activation) parameters, float32 CPU tensors, keyed like the model attributes."""
+def synth_gaussians(P: int, seed: int = 0, width: int = 800, height: int = 600, fovx_deg: float = 60.0, K: int = 4,
+                    scale_mult: float = 1.0):
+    """Raw (pre-activation) parameters, float32 CPU tensors, keyed like the model attributes.  scale_mult multiplies the
+    median splat size (1.0 = BASELINE.md section 3; 3.0 = the instance-heavy variant: ~9x the screen area per splat)."""
     g = torch.Generator().manual_seed(seed)
     fovx = math.radians(fovx_deg)
     fovy = fovy_from(fovx, width, height)
@@ -29,7 +31,7 @@ def synth_gaussians(P: int, seed: int = 0, width: int = 800, height: int = 600, 
     x = z * math.tan(fovx / 2) * (2.3 * torch.rand(P, generator=g) - 1.15)
     y = z * math.tan(fovy / 2) * (2.3 * torch.rand(P, generator=g) - 1.15)
     xyz = torch.stack([x, y, z], dim=1)
-    scaling = math.log(0.02) + 0.6 * torch.randn(P, 3, generator=g)          # log of LogNormal(ln .02, .6)
+    scaling = math.log(0.02 * scale_mult) + 0.6 * torch.randn(P, 3, generator=g)   # log of LogNormal(ln .02, .6)
     rotation = torch.randn(P, 4, generator=g)
     opacity = inverse_sigmoid(0.05 + 0.9 * torch.rand(P, 1, generator=g))
     features_dc = torch.randn(P, 1, 3, generator=g) * (0.25 / C0)
@@ -38,10 +40,11 @@ def synth_gaussians(P: int, seed: int = 0, width: int = 800, height: int = 600, 
                 scaling=scaling.float(), rotation=rotation.float(), opacity=opacity.float())
 
 
-def synth_model(P: int, seed: int = 0, device="cpu", width=800, height=600, fovx_deg=60.0, K=4, requires_grad=True):
+def synth_model(P: int, seed: int = 0, device="cpu", width=800, height=600, fovx_deg=60.0, K=4, requires_grad=True,
+                scale_mult: float = 1.0):
     import math as _m
     sh_degree = int(round(_m.sqrt(K))) - 1
-    p = synth_gaussians(P, seed, width, height, fovx_deg, K)
+    p = synth_gaussians(P, seed, width, height, fovx_deg, K, scale_mult)
     return GaussianModel.from_tensors(p["xyz"], p["features_dc"], p["features_rest"], p["scaling"], p["rotation"],
                                       p["opacity"], sh_degree=sh_degree, active_sh_degree=min(1, sh_degree),
                                       device=device, requires_grad=requires_grad)

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Per-wave trace of the BATCHED blend kernels (all 6 views of an iteration in one launch; B3GS_BWD_TRACE / B3GS_FWD_TRACE):
+how many waves are resident over the kernel's span -- i.e. how much of the launch is tail."""
+import ctypes as C
+import os
+import sys
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "bwd"
+os.environ["B3GS_BWD_TRACE" if WHICH == "bwd" else "B3GS_FWD_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from binocular3dgs_amd import _lib, synth
+from binocular3dgs_amd.fused import FusedRasterizer
+P, W, H = 1_000_000, 800, 600
+model = synth.synth_model(P, seed=0, device="cuda", width=W, height=H)
+pairs = synth.synth_view_set(W, H, device="cuda")
+bg = torch.zeros(3, device="cuda")
+gc, gd, ga = synth.synth_pixel_grads(W, H, seed=0, device="cuda")
+fr = FusedRasterizer(model, W, H, num_slots=6, want_means2D=False)
+views = []
+for i, (c, s, t) in enumerate(pairs):
+    views += [(c, 2 * i, True), (s, 2 * i + 1, False)]
+fr.fit_capacity(views, bg)
+for p in model.parameters():
+    p.grad = torch.zeros_like(p)
+for _ in range(3):
+    outs = fr.render_batch(views, bg)
+    if WHICH == "bwd":
+        o, g = [], []
+        for k, x in enumerate(outs):
+            o.append(x["render"]); g.append(gc)
+            if k % 2 == 0:
+                o += [x["rendered_depth"], x["rendered_alpha"]]; g += [gd, ga]
+        torch.autograd.backward(o, g)
+torch.cuda.synchronize()
+L = _lib.lib()
+L.b3gs_debug_bwd_trace.restype = C.c_size_t
+L.b3gs_debug_bwd_trace.argtypes = [C.c_void_p, C.c_size_t]
+buf = np.zeros(1 << 22, np.uint64)
+n = L.b3gs_debug_bwd_trace(buf.ctypes.data, buf.size)
+t = buf[:n].reshape(-1, 4)
+t = t[t[:, 0] > 0]
+rs = (t[:, 1] >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF
+re = (t[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+it = t[:, 2].astype(np.int64)
+t0 = rs.min()
+s_us, e_us = (rs - t0) / 100.0, (re - t0) / 100.0
+span = e_us.max()
+print(WHICH, "waves", len(t), "kernel span %.1f us" % span, "last wave start %.1f us" % s_us.max())
+grid = np.linspace(0, span, 21)
+res = [int(((s_us <= x) & (e_us > x)).sum()) for x in grid]
+print("resident waves at 0,5,...,100 %% of the span:", res)
+print("mean resident waves %.0f (slots: 1024 SIMDs x occupancy)" % ((e_us - s_us).sum() / span))
+print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % ((e_us - s_us).mean(), *np.percentile(e_us - s_us, [50, 90, 99]), (e_us - s_us).max()))
+print("iterations per wave: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (it.mean(), *np.percentile(it, [50, 90, 99]), it.max()))
+print("corr(iters, duration) %.3f" % np.corrcoef(it, e_us - s_us)[0, 1])
+late = s_us > 0.5 * span
+print("waves started in the second half: %d, their mean duration %.1f us" % (late.sum(), (e_us - s_us)[late].mean() if late.any() else 0))
