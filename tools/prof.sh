@@ -7,7 +7,7 @@ ROOTDIR=$(pwd)
 mkdir -p $ROOTDIR/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -- python $ROOTDIR/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $ROOTDIR/gpurun_out/${tag}_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -- python $ROOTDIR/bench.py --steps ${PROF_STEPS:-20} --warmup ${PROF_WARMUP:-5} --no-cpu-baseline "$@" > $ROOTDIR/gpurun_out/${tag}_bench.log 2>&1
 db=$(find /tmp/prof_$tag -name "*_results.db" | head -1)
 cd $ROOTDIR
 python tools/rocpd_summary.py $db gpurun_out/${tag}_kernel_stats.csv | head -${PROF_LINES:-24}
