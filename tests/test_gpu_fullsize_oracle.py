@@ -60,3 +60,95 @@ def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views):
         assert m["grad_" + n] <= 2e-4, f"{n}: rel L2 {m['grad_' + n]:.3e}"
     assert m["stat_accum"] <= 2e-4
     assert m["stat_denom_mismatch"] <= flips and m["stat_max_radii_mismatch"] <= 2 * flips + 4
+
+
+def test_config2_500k_three_pairs_full_loop_with_the_stereo_loss():
+    """BASELINE configs[2]: ~500k Gaussians, 3 input views + their 3 binocular-shifted partners at 800x600, the full
+    loop on one MI355X with the depth / alpha outputs feeding the stereo-consistency loss.
+    (i) ONE iteration end to end against the oracle: the six images -> loss block (train.py:123-148: L1 + D-SSIM, warp
+        L1 through the un-detached depth, edge-aware smoothness, alpha term) -> pixel gradients -> rasterizer backward ->
+        parameter gradients.  HIP: FusedRasterizer + b3gs_binocular_loss_batch + multi-view chain rule; oracle side:
+        tile_ref forward, the PyTorch loss block on the CPU, tile_ref backward, fp64 activation chain.  Loss values to
+        1e-5 relative; parameter gradients to 1e-3 relative L2 -- the loss block is not smooth (the sign of image - gt in
+        the L1 terms, the floor of the disparity in the warp): a pixel where the two 1e-7-apart images fall on different
+        sides flips a whole pixel gradient, so this chained check is looser than the fixed-pixel-gradient parity above
+        (2e-4), which is the rasterizer's own bar.
+    (ii) then the loop itself: 10 iterations with the fused loss, ShardedAdam (reference decay order) and one
+        densification; the loss falls, nothing overflows, everything stays finite."""
+    import math
+    import numpy as np
+    import torch
+    import fullsize
+    from helpers import rel_l2
+    from oracle import tile_ref
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.fused_loss import binocular_loss_fused_batch
+    from binocular3dgs_amd.loss import binocular_loss
+    from binocular3dgs_amd.step import ShardedAdam, ViewShardedStep
+    P, W, H, dev = 500_000, 800, 600, "cuda"
+    model = synth.synth_model(P, seed=2, device=dev, width=W, height=H)
+    model.init_densification_stats()
+    pairs = synth.synth_view_set(W, H, device=dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(77)
+    gts = [torch.rand(3, H, W, generator=g) for _ in pairs]
+    masks = [(torch.rand(1, H, W, generator=g) < 0.2).float() for _ in pairs]
+    lrs = [1.6e-4, 2.5e-3, 2.5e-3 / 20, 5e-3, 1e-3, 0.05]
+    opt = ShardedAdam(model.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True)
+    fr = FusedRasterizer(model, W, H, num_slots=6, want_means2D=False)
+    st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr)
+    gts_d, masks_d = [t.to(dev) for t in gts], [t.to(dev) for t in masks]
+    parts_seen = []
+
+    def batch_loss(items):
+        total, parts = binocular_loss_fused_batch(
+            [dict(image=pkg["render"], depth=pkg["rendered_depth"], alpha=pkg["rendered_alpha"], gt_image=gts_d[i],
+                  shifted_image=spkg["render"], focal_x=cam.get_focal()[0], trans_dist=t, bg_mask=masks_d[i])
+             for i, cam, pkg, spkg, t in items], unit_grad=True, return_parts=True)
+        parts_seen.append(parts[:, 0].detach().clone())
+        return total
+
+    # ---- (i) one iteration against the oracle ---------------------------------------------------------------
+    act = fullsize.activated(model)
+    st.compute_grads(batch_loss_fn=batch_loss)
+    torch.cuda.synchronize()
+    hip_losses = parts_seen[-1].cpu().numpy()
+    acc = {k: np.zeros(tuple(act[n].shape), np.float64) for k, n in
+           (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"),
+            ("dL_drotations", "rotations"), ("dL_dsh", "shs"))}
+    for i, (cam, scam, t) in enumerate(pairs):
+        sp = tile_ref.forward(**fullsize.oracle_kw(act, cam, bg, W, H, 1))
+        ss = tile_ref.forward(**fullsize.oracle_kw(act, scam, bg, W, H, 1))
+        img, dep, alp, shf = (torch.from_numpy(a.copy()).requires_grad_(True) for a in (sp.color, sp.depth, sp.alpha, ss.color))
+        total, _ = binocular_loss(img, dep, alp, gts[i], shifted_image=shf, focal_x=cam.get_focal()[0], trans_dist=t,
+                                  bg_mask=masks[i])
+        total.backward()
+        assert abs(float(total) - float(hip_losses[i])) <= 1e-5 * abs(float(total)) + 1e-7, (i, float(total), hip_losses[i])
+        for stt, grads in ((sp, (img.grad.numpy(), dep.grad.numpy(), alp.grad.numpy())), (ss, (shf.grad.numpy(), None, None))):
+            ref = tile_ref.backward(stt, *grads)
+            for kk in acc:
+                acc[kk] += ref[kk].astype(np.float64).reshape(acc[kk].shape)
+    raw = {n: getattr(model, "_" + n).detach().cpu().double().requires_grad_(True)
+           for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    acts = [raw["xyz"], torch.sigmoid(raw["opacity"]), torch.exp(raw["scaling"]),
+            torch.nn.functional.normalize(raw["rotation"]), torch.cat((raw["features_dc"], raw["features_rest"]), 1)]
+    torch.autograd.backward(acts, [torch.from_numpy(acc[k]) for k in
+                                   ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
+    for n in raw:
+        e = rel_l2(getattr(model, "_" + n).grad.cpu().numpy(), raw[n].grad.numpy())
+        assert e <= 1e-3, f"{n}: rel L2 {e:.3e}"
+    # ---- (ii) the loop ----------------------------------------------------------------------------------------------
+    st.reduce_and_update()
+    losses = []
+    for it in range(2, 12):
+        st.step(batch_loss_fn=batch_loss)
+        losses.append(float(parts_seen[-1].sum()))
+        if it == 6:
+            thr = float((model.xyz_gradient_accum / model.denom.clamp(min=1)).quantile(0.9))
+            newP = st.densify_and_prune(thr, 0.005, 5.0, generator=torch.Generator(device=dev).manual_seed(it))
+            assert newP > P
+    torch.cuda.synchronize()
+    st.check_capacity()
+    assert losses[-1] < losses[0], losses
+    assert all(torch.isfinite(p).all() for p in model.parameters()) and math.isfinite(losses[-1])
