@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("B3GS_LIB") or os.path.join(_HERE, "libb3gs_raster.so")   # B3GS_LIB: A/B builds of the kernels
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -48,14 +48,14 @@ class B3gsBlendView(C.Structure):
     _fields_ = [("view", C.POINTER(B3gsScene)), ("geometry", C.c_void_p), ("binning", C.c_void_p),
                 ("image", C.c_void_p), ("out_color", C.c_void_p), ("out_depth", C.c_void_p),
                 ("out_alpha", C.c_void_p), ("dL_dcolor", C.c_void_p), ("dL_ddepth", C.c_void_p),
-                ("dL_dalpha", C.c_void_p), ("scratch", C.c_void_p)]
+                ("dL_dalpha", C.c_void_p), ("scratch", C.c_void_p), ("binning_capacity", C.c_int64)]
 
 
 class B3gsForwardView(C.Structure):
     _fields_ = [("view", C.POINTER(B3gsScene)), ("geometry", C.c_void_p), ("binning", C.c_void_p),
                 ("binning_capacity", C.c_int64), ("image", C.c_void_p), ("out_color", C.c_void_p),
                 ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
-                ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32)]
+                ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32), ("seg1_fraction", C.c_float)]
 
 
 class B3gsLossIO(C.Structure):
@@ -86,7 +86,8 @@ class B3gsDensifyStats(C.Structure):
 class B3gsDebugViews(C.Structure):
     _fields_ = [("tiles_touched", C.c_void_p), ("depths", C.c_void_p), ("records", C.c_void_p),
                 ("point_list", C.c_void_p), ("tile_ids", C.c_void_p), ("ranges", C.c_void_p),
-                ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("packed_idx_bits", C.c_int32)]
+                ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("packed_idx_bits", C.c_int32),
+                ("counts", C.c_void_p), ("point_list2", C.c_void_p), ("ranges2", C.c_void_p)]
 
 
 class B3gsKernelTimes(C.Structure):

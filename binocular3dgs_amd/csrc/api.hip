@@ -339,8 +339,9 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     pb.sc[k] = sc;
     pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
     jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr,
-                     nullptr, 1};
+                     nullptr, 1, 0};
     bb.v[k] = b3gs_blend_view(sc, g, b, im);
+    bb.v[k].open_rows = im.open_rows;
     bb.v[k].out_color = fv.out_color;
     bb.v[k].out_depth = fv.out_depth;
     bb.v[k].out_alpha = fv.out_alpha;
@@ -365,17 +366,42 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     jobs[k].rect_stride = pb.out[k].rect_stride;
   }
   pb.raw = *params;
+  // two-round binning: the same K1 for every view of the batch; needs packed instance words and one tile-sort depth
+  const int32_t P = views[0].view->P;
+  int32_t K1 = 0;
+  {
+    float frac = views[0].seg1_fraction;
+    if (const char* e = getenv("B3GS_SEG1_FRAC")) frac = (float)atof(e);
+    if (frac > 0.0f && frac < 1.0f && P > 1) {
+      K1 = (int32_t)((double)frac * (double)P + 0.999999);
+      K1 = K1 < 1 ? 1 : K1;
+      for (int k = 0; k < nviews && K1; k++) {
+        const B3gsScene& sc = *views[k].view;
+        if (b3gs_packed_idx_bits(P, sc.W, sc.H) < 0 || b3gs_tile_bits(sc.W, sc.H) != b3gs_tile_bits(views[0].view->W, views[0].view->H))
+          K1 = 0;
+      }
+      if (K1 >= P) K1 = 0;
+    }
+  }
+  for (int k = 0; k < nviews; k++) jobs[k].K1 = K1;
   StageTimer tm(s);
   tm.mark(-1);
   if (phases & 1) {
     b3gs_launch_preprocess(pb, s);
     tm.mark(0);
-    b3gs_launch_binning_batch(views[0].view->P, nviews, jobs, s);
+    b3gs_launch_binning_batch(P, nviews, jobs, s);
     tm.mark(1);
   }
   if (phases & 2) {
     b3gs_launch_blend_forward(bb, s);
     tm.mark(2);
+    if (K1) {   // second round: the rest of the depth order, into the tiles segment 1 did not finish
+      b3gs_launch_round2_batch(P, nviews, jobs, s);
+      tm.mark(1);
+      for (int k = 0; k < nviews; k++) bb.v[k].round = 1;
+      b3gs_launch_blend_forward(bb, s);
+      tm.mark(2);
+    }
   }
   HIP_TRY(hipGetLastError());
   return B3GS_OK;
@@ -505,7 +531,7 @@ int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_st
     BinView b;
     b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
     b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
-    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, 1, &b);
+    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, bv.binning_capacity > 0 ? bv.binning_capacity : 1, &b);
     batch.v[k] = b3gs_blend_view(*bv.view, g, b, im);
     batch.v[k].out_color = bv.out_color;
     batch.v[k].out_depth = bv.out_depth;
@@ -533,7 +559,7 @@ int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_s
     BinView b;
     b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
     b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
-    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, 1, &b);
+    b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, bv.binning_capacity > 0 ? bv.binning_capacity : 1, &b);
     batch.v[k] = blend_backward_view(*bv.view, g, b, im, bv.dL_dcolor, bv.dL_ddepth, bv.dL_dalpha, bv.scratch + 4,
                                      bv.scratch + 6, bv.scratch + 9, bv.scratch, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW,
                                      B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW);
@@ -617,6 +643,9 @@ int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, cons
     out->tile_ids = out->packed_idx_bits >= 0 ? nullptr : b.key[0];
   }
   out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
+  out->ranges2 = reinterpret_cast<const uint32_t*>(im.ranges2);
+  out->counts = g.header;
+  if (binning) out->point_list2 = b.key[0];
   out->final_T = im.final_T;
   out->n_contrib = im.n_contrib;
   return B3GS_OK;

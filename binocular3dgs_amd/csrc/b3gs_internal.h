@@ -28,8 +28,9 @@ struct GeomView {       // sized by P
   uint32_t* clamped;    // [P]   bit c set: SH colour channel c clamped at 0
   uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
   uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
-  uint32_t* soffs;      // [P]   inclusive scan of tiles_touched in depth order
+  uint32_t* soffs;      // [P]   inclusive scan of tiles_touched in depth order (segment 1: [0,K1), segment 2: [K1,P))
   uint2* srect;         // [P]   rect in depth order
+  uint32_t* scount;     // [P]   segment 2: tiles of the rect that were not finished after segment 1, in depth order
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
   uint32_t* scan_tmp;   // [4096] block sums for scans
   float* bwd_rows;      // [P * B3GS_SCRATCH_ROW] drop-in backward: per-Gaussian sums of the blend backward (one row each)
@@ -45,7 +46,10 @@ struct ImgView {        // sized by W*H
   uint32_t* header;     // [64]  header[0] = N used by the forward that filled this buffer
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
-  uint2* ranges;        // [tiles]
+  uint2* ranges;        // [tiles]  segment 1 of every tile list
+  uint2* ranges2;       // [tiles]  segment 2 (two-round binning, see BinJob::K1); empty = (0xFFFFFFFF, 0)
+  unsigned long long* open_rows;  // [grid_y * ceil(grid_x / 64)] bit x % 64 of word (y, x / 64) set: tile (x, y) still has
+                        //          an unterminated pixel after segment 1 (header[3] = their number); zeroed per forward
 };
 
 #define B3GS_SORT_ITEMS 16                       /* keys per thread in a radix tile */
@@ -97,6 +101,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
   t.soffs = b3gs_carve<uint32_t>(cur, p);
   t.srect = b3gs_carve<uint2>(cur, p);
+  t.scount = b3gs_carve<uint32_t>(cur, p);
   t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
   t.bwd_rows = b3gs_carve<float>(cur, p * B3GS_SCRATCH_ROW);
@@ -129,6 +134,8 @@ static inline size_t b3gs_img_view(char* base, int32_t W, int32_t H, ImgView* v)
   t.final_T = b3gs_carve<float>(cur, hw ? hw : 1);
   t.n_contrib = b3gs_carve<uint32_t>(cur, hw ? hw : 1);
   t.ranges = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
+  t.ranges2 = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
+  t.open_rows = b3gs_carve<unsigned long long>(cur, (size_t)((H + B3GS_TILE - 1) / B3GS_TILE + 1) * (size_t)(((W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64));
   if (v) *v = t;
   return (size_t)(cur - base);
 }
@@ -167,7 +174,9 @@ struct PreOut {
   uint32_t* clamped;
   int32_t* radii;
   uint2* ranges;
-  int32_t ntiles;
+  uint2* ranges2;
+  unsigned long long* open_rows;
+  int32_t ntiles, nrowwords;
 };
 struct PreBatch {
   int32_t n, raw_mode, tight;
@@ -203,6 +212,10 @@ struct BinJob {
   const uint32_t* order;  // internal (order_from == -2): explicit depth order
   const uint2* rect;      // tile rects as written by the projection (PreOut::rect / rect_stride); null: g.rect, stride 1
   int32_t rect_stride;
+  // Two-round ("termination-aware") binning, fused path: K1 in (0, P) bins only the nearest K1 Gaussians of the depth
+  // order first (segment 1); after the blend forward has marked the tiles whose pixels all terminated, the remaining
+  // Gaussians are binned into the OTHER tiles only (segment 2, b3gs_launch_round2_batch).  0 or >= P: one round.
+  int32_t K1;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,
@@ -210,12 +223,23 @@ void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], u
 // the two halves, for callers that size the binning buffer from N in between (b3gs_forward)
 void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);  // sort + scan
 void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);   // emit + split + ranges
+// segment 2 of every view's tile lists (jobs with 0 < K1 < P; packed instance words only): count / scan / emit the
+// Gaussians [K1, P) of the depth order into the tiles still open in im.open_rows, stable split by tile id into
+// b.key[0] (the idle half of the packed-word binning buffer), ranges -> im.ranges2, N2 -> header[2], *n_out += N2
+void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
+static inline int32_t b3gs_seg1_count(const BinJob& j, int32_t P) { return (j.K1 > 0 && j.K1 < P) ? j.K1 : P; }
 
 // ---- blend (per-tile alpha compositing) launches: one or several views per launch ---------------
 struct BlendView {
   int32_t W, H, grid_x, ntiles, block_base;   // block_base is filled by the launcher
   const uint2* ranges;
   const uint32_t* point_list;
+  const uint2* ranges2;    // segment 2 of the tile lists (two-round binning): list position q >= len(segment 1) reads
+  const uint32_t* point_list2;   //   point_list2[ranges2[tile].x + q - len1]
+  unsigned long long* open_rows;  // forward, round 0: bitmap of the tiles with an unterminated pixel (null: not wanted)
+  uint32_t* open_count;    //   ... and their number (image header word 3)
+  int32_t row_words;       //   64-bit words per tile row of the bitmap
+  int32_t round;           // forward: 0 = first pass over all tiles; 1 = second pass, only tiles with a segment 2
   uint32_t idx_mask;       // Gaussian index = point_list[j] & idx_mask (packed tile|index words, see b3gs_packed_idx_bits)
   const float4* rec;
   const float* bg;

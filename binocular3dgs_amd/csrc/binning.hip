@@ -100,6 +100,11 @@ struct ScanBatch {
   ScanJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
+// The tiles still open after segment 1 as a bitmap: word (y, x / 64), bit x % 64 (ImgView::open_rows).
+struct OpenMap {
+  const unsigned long long* rows;
+  uint32_t row_words, grid_x;
+};
 struct EmitJob {
   const uint32_t* order;
   const uint32_t* soffs;
@@ -109,9 +114,12 @@ struct EmitJob {
   uint32_t n_cap;
   int32_t grid_x;
   int32_t idx_bits;
+  const uint32_t* scount;   // round 2: tiles of the rect still open (null in round 1: all tiles of the rect)
+  OpenMap open;             // round 2: the bitmap of the open tiles
+  const uint32_t* open_count;   // round 2: their number (0: nothing to emit)
 };
 struct EmitBatch {
-  int32_t n, P;
+  int32_t n, P, first;      // Gaussians [first, P) of the depth order
   EmitJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -216,9 +224,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
     base += loc[k];
   }
   if (threadIdx.x == 0) {
-    job.header[0] = tot;   // N
+    job.header[0] = tot;   // N (segment 1)
     job.header[1] = totv;  // V
-    if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; }
+    job.header[2] = 0u;    // N2: set by the second binning round, if one runs
+    if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; job.img_header[2] = 0u; job.img_header[3] = 0u; }
     if (job.n_out) *job.n_out = (int32_t)tot;
   }
 }
@@ -447,6 +456,42 @@ void radix_pass(SortBatch& sb, int shift, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // instance emission in depth order (wave-cooperative expansion)
 // ---------------------------------------------------------------------------------------------
+// bits of row y inside columns [x0, x1) of 64-column block wb, shifted so that bit 0 is column max(x0, 64 wb)
+__device__ __forceinline__ unsigned long long open_bits(const OpenMap& om, uint32_t y, uint32_t wb, uint32_t x0, uint32_t x1,
+                                                        uint32_t* col0) {
+  const uint32_t lo = max(x0, wb * 64u), hi = min(x1, wb * 64u + 64u);
+  const unsigned long long m = om.rows[(size_t)y * om.row_words + wb] >> (lo & 63u);
+  *col0 = lo;
+  const uint32_t w = hi - lo;
+  return w >= 64u ? m : (m & ((1ull << w) - 1ull));
+}
+// number of open tiles inside the rect
+__device__ __forceinline__ uint32_t open_tiles(uint2 rc, const OpenMap& om) {
+  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+  if (x1 <= x0) return 0u;
+  uint32_t n = 0, c0;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) n += (uint32_t)__builtin_popcountll(open_bits(om, y, wb, x0, x1, &c0));
+  return n;
+}
+// k-th open tile of the rect in row-major order (k < open_tiles(rc))
+__device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const OpenMap& om) {
+  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
+      uint32_t c0;
+      unsigned long long m = open_bits(om, y, wb, x0, x1, &c0);
+      const uint32_t c = (uint32_t)__builtin_popcountll(m);
+      if (k < c) {
+        for (uint32_t j = 0; j < k; j++) m &= m - 1ull;
+        return y * om.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
+      }
+      k -= c;
+    }
+  return y0 * om.grid_x + x0;   // not reached
+}
+
+template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ uint32_t s_end[4][64];
   const EmitJob& job = eb.j[blockIdx.y];
@@ -455,13 +500,19 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   uint32_t* __restrict__ tile_out = job.tile_out;
   uint32_t* __restrict__ idx_out = job.idx_out;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int s = eb.first + (int)(blockIdx.x * 256 + threadIdx.x);
   uint32_t gid = 0, cnt = 0, end = 0;
   uint2 rc = make_uint2(0, 0);
+  if (ROUND2) {
+    // almost every Gaussian of the second round lies in finished tiles only: look at the counts first (4 bytes each)
+    if (*job.open_count == 0u) return;
+    if (s < P) cnt = job.scount[s];
+    if (__ballot(cnt != 0) == 0) return;
+  }
   if (s < P) {
     gid = job.order[s];
     rc = job.srect[s];
-    cnt = rect_area(rc);
+    if (!ROUND2) cnt = rect_area(rc);
     end = job.soffs[s];
   }
   // lanes past P inherit the last valid end so the search array stays monotone
@@ -487,10 +538,20 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     const uint32_t src_cnt = __shfl(cnt, (int)lo, 64);
     const uint32_t src_gid = __shfl(gid, (int)lo, 64);
     const uint32_t src_x0 = __shfl(x0, (int)lo, 64), src_y0 = __shfl(y0, (int)lo, 64), src_rw = __shfl(rw, (int)lo, 64);
+    uint2 src_rc = make_uint2(0u, 0u);
+    if (ROUND2) {
+      src_rc.x = __shfl(rc.x, (int)lo, 64);
+      src_rc.y = __shfl(rc.y, (int)lo, 64);
+    }
     if (j < wave_end && j < n_cap) {
       const uint32_t k = j - (src_end - src_cnt);
-      const uint32_t ry = k / src_rw, rx = k - ry * src_rw;
-      const uint32_t tile = (src_y0 + ry) * (uint32_t)job.grid_x + (src_x0 + rx);
+      uint32_t tile;
+      if (ROUND2) {
+        tile = kth_open_tile(src_rc, k, job.open);
+      } else {
+        const uint32_t ry = k / src_rw, rx = k - ry * src_rw;
+        tile = (src_y0 + ry) * (uint32_t)job.grid_x + (src_x0 + rx);
+      }
       if (idx_out) {
         tile_out[j] = tile;
         idx_out[j] = src_gid;
@@ -498,6 +559,145 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
         tile_out[j] = (tile << job.idx_bits) | src_gid;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// round 2 of the two-round binning: count / scan of the Gaussians [K1, P) of the depth order, restricted to the
+// tiles that segment 1 did not finish
+// ---------------------------------------------------------------------------------------------
+struct Scan2Job {
+  const uint32_t* order;
+  const uint2* rect;
+  int32_t rect_stride;
+  int32_t partner;          // as ScanJob::partner: >= 0 gathers both views of a binocular pair with one 16-byte load
+  uint2* srect;
+  uint32_t* scount;
+  uint32_t* soffs;
+  uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
+  uint32_t* header;         // header[0] = N1 (read), header[2] = N2 (written)
+  uint32_t* img_header;
+  int32_t* n_out;           // *n_out = N1 + N2
+  OpenMap open;
+};
+struct Scan2Batch {
+  int32_t n, P, K1, tiles_per_chunk, nchunks;
+  Scan2Job j[B3GS_MAX_FUSED_VIEWS];
+};
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_sums(Scan2Batch sb) {
+  __shared__ uint32_t tmp[8];
+  const Scan2Job& job = sb.j[blockIdx.y];
+  if (job.partner == -2) return;
+  {   // no tile left open (in either view of a pair): segment 2 is empty, the chunk sum is all that is needed
+    const bool none = job.img_header[3] == 0u && (job.partner < 0 || sb.j[job.partner].img_header[3] == 0u);
+    if (none) {
+      if (threadIdx.x == 0) {
+        job.chunk_sums[blockIdx.x] = 0u;
+        if (job.partner >= 0) sb.j[job.partner].chunk_sums[blockIdx.x] = 0u;
+      }
+      return;
+    }
+  }
+  const uint32_t* __restrict__ order = job.order;
+  const int64_t begin = (int64_t)sb.K1 + (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
+  uint32_t sum = 0, sum2 = 0;
+  if (job.partner >= 0) {
+    const Scan2Job& pj = sb.j[job.partner];
+    const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
+    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
+      const uint4 rr = rect2[order[i]];
+      const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
+      const uint32_t ta = open_tiles(ra, job.open), tb = open_tiles(rb, pj.open);
+      job.srect[i] = ra; job.scount[i] = ta;
+      pj.srect[i] = rb; pj.scount[i] = tb;
+      sum += ta;
+      sum2 += tb;
+    }
+  } else {
+    const uint2* __restrict__ rect = job.rect;
+    const size_t stride = (size_t)job.rect_stride;
+    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
+      const uint2 rc = rect[order[i] * stride];
+      const uint32_t t = open_tiles(rc, job.open);
+      job.srect[i] = rc; job.scount[i] = t;
+      sum += t;
+    }
+  }
+  uint32_t tot;
+  block_excl_scan_256(sum, tmp, &tot);
+  if (threadIdx.x == 0) job.chunk_sums[blockIdx.x] = tot;
+  if (job.partner >= 0) {
+    block_excl_scan_256(sum2, tmp, &tot);
+    if (threadIdx.x == 0) sb.j[job.partner].chunk_sums[blockIdx.x] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_offsets(Scan2Batch sb) {
+  __shared__ uint32_t tmp[8];
+  const Scan2Job& job = sb.j[blockIdx.x];
+  const int nchunks = sb.nchunks;
+  uint32_t loc[8], s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int idx = threadIdx.x * 8 + k;
+    loc[k] = idx < nchunks ? job.chunk_sums[idx] : 0u;
+    s += loc[k];
+  }
+  uint32_t tot;
+  uint32_t base = block_excl_scan_256(s, tmp, &tot);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int idx = threadIdx.x * 8 + k;
+    if (idx < nchunks) job.chunk_sums[idx] = base;
+    base += loc[k];
+  }
+  if (threadIdx.x == 0) {
+    job.header[2] = tot;   // N2
+    if (job.img_header) job.img_header[2] = tot;
+    if (job.n_out) *job.n_out = (int32_t)(job.header[0] + tot);
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_apply(Scan2Batch sb) {
+  __shared__ uint32_t wave_tot[4];
+  const Scan2Job& job = sb.j[blockIdx.y];
+  if (job.img_header[3] == 0u) return;   // no open tile: no segment 2, nobody reads the offsets
+  const uint32_t* __restrict__ scount = job.scount;
+  uint32_t* __restrict__ soffs = job.soffs;
+  const int P = sb.P;
+  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+  uint32_t carry = job.chunk_sums[blockIdx.x];
+  const int64_t begin = (int64_t)sb.K1 + (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  for (int t = 0; t < sb.tiles_per_chunk; t++) {
+    const int64_t tb = begin + (int64_t)t * SCAN_TILE;
+    if (tb >= P) break;
+    const int64_t wb = tb + (int64_t)w * (SCAN_ITEMS * 64);
+    uint32_t inc[SCAN_ITEMS], run = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; r++) {
+      const int64_t i = wb + r * 64 + lane;
+      const uint32_t v = i < P ? scount[i] : 0u;
+      inc[r] = run + wave_incl_scan(v);
+      run = __shfl(inc[r], 63, 64);
+    }
+    if (lane == 0) wave_tot[w] = run;
+    __syncthreads();
+    uint32_t base = carry, tot = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+      const uint32_t x = wave_tot[k];
+      if (k < w) base += x;
+      tot += x;
+    }
+#pragma unroll
+    for (int r = 0; r < SCAN_ITEMS; r++) {
+      const int64_t i = wb + r * 64 + lane;
+      if (i < P) soffs[i] = base + inc[r];
+    }
+    carry += tot;
+    __syncthreads();
   }
 }
 
@@ -580,11 +780,12 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     }
   }
 
-  // ---- 2. scan of tiles_touched in depth order -> soffs, N, V
-  const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
+  // ---- 2. scan of tiles_touched in depth order -> soffs, N, V (segment 1 = the first K1 Gaussians of the order)
+  const int K1 = b3gs_seg1_count(jobs[0], P);
+  const int total_tiles = (K1 + SCAN_TILE - 1) / SCAN_TILE;
   ScanBatch sc;
   sc.n = nviews;
-  sc.P = P;
+  sc.P = K1;
   sc.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
@@ -629,9 +830,11 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   // ---- 3. emit (tile, index) instances in depth order into the buffer from which `passes` ping-pongs end in [0];
   //         every kernel clamps to min(N, capacity)
   const int first = passes & 1;
+  const int K1 = b3gs_seg1_count(jobs[0], P);
   EmitBatch eb;
   eb.n = nviews;
-  eb.P = P;
+  eb.P = K1;
+  eb.first = 0;
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -647,19 +850,19 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
       // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
       // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
       // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits};
     } else {
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0};
     }
   }
   if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
-  hipLaunchKernelGGL(emit_instances, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
+  hipLaunchKernelGGL(emit_instances<false>, dim3((K1 + 255) / 256, nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
   for (int p = 0; p < passes; p++) {
@@ -674,5 +877,79 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
     }
   }
   // ---- 5. per-tile [begin, end): produced by the last pass above; a single-tile image has no pass
+  if (passes == 0) hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
+}
+
+void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
+  if (nviews <= 0 || P <= 0) return;
+  const int K1 = b3gs_seg1_count(jobs[0], P);
+  if (K1 >= P) return;
+  const int passes = tile_sort_passes(jobs[0].W, jobs[0].H);
+  for (int v = 0; v < nviews; v++)   // (the caller only enables K1 for batches of equal tile-sort depth and packed words)
+    if (tile_sort_passes(jobs[v].W, jobs[v].H) != passes || b3gs_packed_idx_bits(P, jobs[v].W, jobs[v].H) < 0) return;
+  const int rest = P - K1;
+  const int total_tiles = (rest + SCAN_TILE - 1) / SCAN_TILE;
+  Scan2Batch sc;
+  sc.n = nviews;
+  sc.P = P;
+  sc.K1 = K1;
+  sc.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
+  sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
+  for (int v = 0; v < nviews; v++) {
+    const BinJob& jb = jobs[v];
+    const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
+    const int32_t rstride = jb.rect ? jb.rect_stride : 1;
+    const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
+    sc.j[v] = Scan2Job{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp,
+                       jb.g.header, jb.im.header, jb.n_out, OpenMap{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx}};
+  }
+  for (int v = 0; v < nviews; v++) {
+    const int d = jobs[v].order_from;
+    if (d < 0 || sc.j[d].partner != -1 || sc.j[v].rect_stride != 2 || sc.j[d].rect_stride != 2 ||
+        sc.j[v].rect != sc.j[d].rect + 1)
+      continue;
+    sc.j[d].partner = v;
+    sc.j[v].partner = -2;
+  }
+  hipLaunchKernelGGL(scan2_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
+  hipLaunchKernelGGL(scan2_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+
+  // emission + stable split by tile id, in the idle half of the packed-word binning buffer: key[first] -> ... -> key[0]
+  const int first = passes & 1;
+  EmitBatch eb;
+  eb.n = nviews;
+  eb.P = P;
+  eb.first = K1;
+  SortBatch tb;
+  tb.n = nviews;
+  RangeBatch rb;
+  rb.n = nviews;
+  uint32_t max_cap = 0;
+  for (int v = 0; v < nviews; v++) {
+    const BinJob& jb = jobs[v];
+    const uint32_t n_cap = (uint32_t)(jb.n_bound > 0 ? jb.n_bound : 0);
+    max_cap = n_cap > max_cap ? n_cap : max_cap;
+    const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
+    const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
+    eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], nullptr, n_cap, gx, idx_bits,
+                      jb.g.scount, OpenMap{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx}, jb.im.header + 3};
+    tb.j[v] = SortJob{jb.b.key[first], nullptr, jb.b.key[first ^ 1], nullptr, jb.g.header + 2, n_cap,
+                      b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr};
+    rb.j[v] = RangeJob{jb.b.key[0], jb.g.header + 2, jb.im.ranges2, n_cap, idx_bits};
+  }
+  if (max_cap == 0) return;
+  hipLaunchKernelGGL(emit_instances<true>, dim3((rest + 255) / 256, nviews), dim3(256), 0, s, eb);
+  for (int p = 0; p < passes; p++) {
+    if (p == passes - 1)
+      for (int v = 0; v < nviews; v++) tb.j[v].ranges = jobs[v].im.ranges2;
+    radix_pass(tb, 8 * p, s);
+    for (int v = 0; v < nviews; v++) {
+      SortJob& j = tb.j[v];
+      const uint32_t* k = j.kin;
+      j.kin = j.kout;
+      j.kout = const_cast<uint32_t*>(k);
+    }
+  }
   if (passes == 0) hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
 }

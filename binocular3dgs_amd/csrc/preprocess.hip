@@ -191,7 +191,12 @@ template <bool RAW>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (int v = 0; v < pb.n; v++)
-    if (i < pb.out[v].ntiles) pb.out[v].ranges[i] = make_uint2(0xFFFFFFFFu, 0u);  // empty = (max, 0): the tile sort's last pass min/maxes into it
+    if (i < pb.out[v].ntiles) {   // empty = (max, 0): the tile sort's last pass min/maxes into it
+      pb.out[v].ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
+      pb.out[v].ranges2[i] = make_uint2(0xFFFFFFFFu, 0u);
+    }
+  for (int v = 0; v < pb.n; v++)
+    if (i < pb.out[v].nrowwords) pb.out[v].open_rows[i] = 0ull;
   if (i >= pb.sc[0].P) return;
   // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
   // scale modifier), activated opacity
@@ -855,6 +860,9 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.clamped = g.clamped;
   o.radii = radii;
   o.ranges = im.ranges;
+  o.ranges2 = im.ranges2;
+  o.open_rows = im.open_rows;
+  o.nrowwords = ((sc.H + B3GS_TILE - 1) / B3GS_TILE) * (((sc.W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64);
   o.ntiles = ((sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   return o;
 }

@@ -71,18 +71,40 @@ struct TileShared {
   u64 mask[4][CHUNK / 64];   // [quadrant][producer wave]
 };
 
-// Stage one chunk: lane `tid` fetches list entry (first + tid); returns the Gaussian id (or -1).
+// A tile's list is the concatenation of up to two segments (two-round binning, b3gs_internal.h BinJob::K1): positions
+// [0, len1) live in point_list at r1.x, positions [len1, len1 + len2) in point_list2 at r2.x.
+struct TileList {
+  const uint32_t* list1;
+  const uint32_t* list2;
+  uint32_t first1, first2, len1, total;
+};
+__device__ __forceinline__ TileList tile_list(const BlendView& bv, int tile, bool with_segment2) {
+  uint2 r1 = bv.ranges[tile];
+  if (r1.y <= r1.x) r1 = make_uint2(0u, 0u);   // empty tiles hold (0xFFFFFFFF, 0)
+  uint2 r2 = with_segment2 ? bv.ranges2[tile] : make_uint2(0u, 0u);
+  if (r2.y <= r2.x) r2 = make_uint2(0u, 0u);
+  TileList t;
+  t.list1 = bv.point_list;
+  t.list2 = bv.point_list2;
+  t.first1 = r1.x;
+  t.first2 = r2.x;
+  t.len1 = r1.y - r1.x;
+  t.total = t.len1 + (r2.y - r2.x);
+  return t;
+}
+
+// Stage one chunk: lane `tid` fetches list position (q0 + tid); returns the Gaussian id (or -1).
 template <int CHUNK>
-__device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const uint32_t* __restrict__ point_list,
-                                           uint32_t idx_mask, const float4* __restrict__ rec, uint32_t first, uint32_t last,
-                                           float tile_px, float tile_py) {
+__device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const TileList& tl, uint32_t idx_mask,
+                                           const float4* __restrict__ rec, uint32_t q0, float tile_px, float tile_py) {
   const unsigned tid = threadIdx.x;
-  const uint32_t idx = first + tid;
+  const uint32_t q = q0 + tid;
   int id = -1;
   bool hit[4] = {false, false, false, false};
   if (CHUNK < 256 && tid >= (unsigned)CHUNK) return id;  // whole waves: wave-uniform exit
-  if (idx < last) {
-    id = (int)(point_list[idx] & idx_mask);
+  if (q < tl.total) {
+    const uint32_t word = q < tl.len1 ? tl.list1[tl.first1 + q] : tl.list2[tl.first2 + (q - tl.len1)];
+    id = (int)(word & idx_mask);
     const float4* r = rec + 4 * (size_t)id;
     const float4 r0 = r[0], r1 = r[1], r2 = r[2];
     sh.A[tid] = r0;
@@ -153,8 +175,6 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   unsigned n_iter = 0, n_chunks = 0;
   const BlendView bv = select_view(batch, (int)blockIdx.x);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
-  const uint2* __restrict__ ranges = bv.ranges;
-  const uint32_t* __restrict__ point_list = bv.point_list;
   const float4* __restrict__ rec = bv.rec;
   const float* __restrict__ bg = bv.bg;
   float* __restrict__ final_T = bv.final_T;
@@ -170,9 +190,12 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   const int py = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
   const bool inside = px < W && py < H;
   const float fpx = (float)px, fpy = (float)py;
-  uint2 range = ranges[tile];
-  if (range.y <= range.x) range = make_uint2(0u, 0u);  // empty tiles hold (0xFFFFFFFF, 0)
-  const int nchunks = (int)((range.y - range.x + CHUNK - 1) / CHUNK);
+  // round 0: every tile, segment 1 only, and the per-tile "all pixels terminated" flag; round 1 (after the second
+  // binning round): only the tiles that received a segment 2, recomputed over segment 1 + segment 2
+  if (bv.round != 0 && *bv.open_count == 0u) return;   // no tile of this view was left open: nothing to redo
+  const TileList tl = tile_list(bv, tile, bv.round != 0);
+  if (bv.round != 0 && tl.total == tl.len1) return;
+  const int nchunks = (int)((tl.total + CHUNK - 1) / CHUNK);
 
   // A finished pixel is encoded as Tw == 0 (working transmittance): every later weight is then exactly zero, the
   // saturation test fires again harmlessly, and "is anyone still active" is one compare -- no lane-mask
@@ -184,7 +207,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
 
   for (int c = 0; c < nchunks; c++) {
     if (__syncthreads_and(Tw == 0.0f)) break;
-    stage_chunk(sh, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
+    stage_chunk(sh, tl, bv.idx_mask, rec, (uint32_t)(c * CHUNK), (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
     if (TRACE) n_chunks++;
     if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) continue;  // this quadrant is finished; keep pace with the barriers
@@ -220,6 +243,13 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
         if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
       }
       if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
+    }
+  }
+  if (bv.round == 0 && bv.open_rows != nullptr) {   // (all threads of the workgroup are still here: no early return above)
+    const int all_done = __syncthreads_and(Tw == 0.0f);
+    if (tid == 0 && !all_done) {   // an unterminated pixel: the tile stays open for the second binning round
+      atomicOr(&bv.open_rows[(size_t)tile_y * bv.row_words + (tile_x >> 6)], 1ull << (tile_x & 63));
+      atomicAdd(bv.open_count, 1u);
     }
   }
   if (inside) {
@@ -326,8 +356,6 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   unsigned n_iter = 0, n_live = 0, n_lanes = 0;
   const BlendView bv = select_view(batch, (int)blockIdx.x);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
-  const uint2* __restrict__ ranges = bv.ranges;
-  const uint32_t* __restrict__ point_list = bv.point_list;
   const float4* __restrict__ rec = bv.rec;
   const float* __restrict__ bg = bv.bg;
   const float* __restrict__ final_T = bv.final_T;
@@ -347,8 +375,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   const int ipx = tile_x * B3GS_TILE + (int)((w & 1) * 8 + (lane & 7));
   const int ipy = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
   const bool inside = ipx < W && ipy < H;
-  uint2 range = ranges[tile];
-  if (range.y <= range.x) range = make_uint2(0u, 0u);  // empty tiles hold (0xFFFFFFFF, 0)
+  const TileList tl = tile_list(bv, tile, true);   // n_contrib counts positions of segment 1 + segment 2
 
   BwdPixel px;
   px.fpx = (float)ipx;
@@ -474,8 +501,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       : "memory")
 
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
-    stage_chunk(sh.f, point_list, bv.idx_mask, rec, range.x + c * CHUNK, range.y, (float)(tile_x * B3GS_TILE),
-                (float)(tile_y * B3GS_TILE));
+    stage_chunk(sh.f, tl, bv.idx_mask, rec, (uint32_t)(c * CHUNK), (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
 #pragma unroll 1
     for (int pw = CHUNK / 64 - 1; pw >= 0; pw--) {
@@ -590,6 +616,12 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.ntiles = v.grid_x * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   v.ranges = im.ranges;
   v.point_list = b.val[0];
+  v.ranges2 = im.ranges2;      // empty unless a second binning round ran (b3gs_launch_round2_batch)
+  v.point_list2 = b.key[0];
+  v.open_rows = nullptr;
+  v.open_count = im.header + 3;
+  v.row_words = (v.grid_x + 63) / 64;
+  v.round = 0;
   const int idx_bits = b3gs_packed_idx_bits(sc.P, sc.W, sc.H);
   v.idx_mask = (idx_bits < 0 || idx_bits >= 32) ? 0xFFFFFFFFu : ((1u << idx_bits) - 1u);
   v.rec = g.rec;

@@ -31,8 +31,11 @@ def state_views(P: int, W: int, H: int, num_rendered: int, geom: torch.Tensor, b
                final_T=_slice(img, v.final_T, W * H, torch.float32).view(H, W),
                n_contrib=_slice(img, v.n_contrib, W * H, torch.int32).view(H, W))
     # empty tiles are stored as (0xFFFFFFFF, 0) (min / max identity of the tile sort's last pass): show [0, 0)
-    empty = out["ranges"][:, 1].to(torch.int64) <= (out["ranges"][:, 0].to(torch.int64) & 0xFFFFFFFF)
-    out["ranges"] = torch.where(empty[:, None], torch.zeros_like(out["ranges"]), out["ranges"])
+    out["ranges2"] = _slice(img, v.ranges2, tiles * 2, torch.int32).view(tiles, 2)
+    for key in ("ranges", "ranges2"):
+        empty = out[key][:, 1].to(torch.int64) <= (out[key][:, 0].to(torch.int64) & 0xFFFFFFFF)
+        out[key] = torch.where(empty[:, None], torch.zeros_like(out[key]), out[key])
+    out["counts"] = _slice(geom, v.counts, 3, torch.int32)      # N1, V, N2 (device side)
     if has_bin:
         words = _slice(binning, v.point_list, num_rendered, torch.int32)
         if v.packed_idx_bits >= 0:
@@ -40,6 +43,10 @@ def state_views(P: int, W: int, H: int, num_rendered: int, geom: torch.Tensor, b
             w64 = words.to(torch.int64) & 0xFFFFFFFF
             out["point_list"] = (w64 & ((1 << v.packed_idx_bits) - 1)).to(torch.int32)
             out["tile_ids"] = (w64 >> v.packed_idx_bits).to(torch.int32)
+            # segment 2 of a two-round forward (num_rendered must be the capacity the buffer was carved with)
+            w2 = _slice(binning, v.point_list2, num_rendered, torch.int32).to(torch.int64) & 0xFFFFFFFF
+            out["point_list2"] = (w2 & ((1 << v.packed_idx_bits) - 1)).to(torch.int32)
+            out["tile_ids2"] = (w2 >> v.packed_idx_bits).to(torch.int32)
         else:
             out["point_list"] = words
             out["tile_ids"] = _slice(binning, v.tile_ids, num_rendered, torch.int32)

@@ -88,7 +88,8 @@ class _RasterizeBatch(torch.autograd.Function):
 
 class FusedRasterizer:
     def __init__(self, model, width: int, height: int, num_slots: int = 2, binning_capacity: Optional[int] = None,
-                 want_means2D: bool = True, concurrent: bool = True, schedule: Optional[str] = None):
+                 want_means2D: bool = True, concurrent: bool = True, schedule: Optional[str] = None,
+                 seg1_fraction="auto"):
         self.model = model
         self.W, self.H = int(width), int(height)
         p = model.get_xyz
@@ -106,6 +107,14 @@ class FusedRasterizer:
         assert self.schedule in ("batched", "streams", "serial")
         self.concurrent = self.schedule == "streams"
         self._want_m2d = want_means2D
+        # Two-round binning (schedule "batched"): bin the nearest seg1_fraction of the depth order, blend, bin the rest
+        # only into the tiles that are not finished (B3gsForwardView.seg1_fraction; 0 or >= 1: one round).  It removes
+        # the emission and the tile split of every instance behind a tile's saturation point at the price of ~12 more
+        # (mostly idle) launches and a second, short blend pass: measured on MI355X it breaks even at 4.8M instances
+        # per view (1M Gaussians, 800x600: 504 vs 500-503 iters/s), loses 5 % at 2.4M and wins 32-45 % at 25M (3x larger
+        # splats: 291 -> 382-422 iters/s).  "auto": decided from the measured N whenever fit_capacity() runs.
+        self._seg1_auto = seg1_fraction == "auto"
+        self.seg1_fraction = 0.0 if self._seg1_auto else float(seg1_fraction)
         # N of every slot's last forward lives on the device (no read-back per view); `high_water` keeps the largest N
         # seen since the last check_overflow(), updated by one tiny kernel per forward (graph-capturable)
         self._n_all = torch.zeros((num_slots,), dtype=torch.int32, device=self.dev)
@@ -153,6 +162,7 @@ class FusedRasterizer:
             arr[k].view = C.pointer(sc)
             arr[k].geometry, arr[k].binning, arr[k].image = s.geom.data_ptr(), s.binning.data_ptr(), s.img.data_ptr()
             arr[k].out_color, arr[k].out_depth, arr[k].out_alpha = s.color.data_ptr(), s.depth.data_ptr(), s.alpha.data_ptr()
+            arr[k].binning_capacity = s.capacity
             if grads is not None:
                 gc, gd, ga = grads[k]
                 if gc is None:
@@ -191,6 +201,7 @@ class FusedRasterizer:
                     # a camera made by Camera.shifted() has the z row of its parent's view matrix: same depth order
                     donor = getattr(sp["cam"], "same_depth_as", None)
                     arr[k].depth_order_from = -1
+                    arr[k].seg1_fraction = self.seg1_fraction
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
@@ -355,10 +366,13 @@ class FusedRasterizer:
         """Size the persistent binning buffers from the actual N of `views` ([(camera, slot), ...]): one forward without
         gradients, one read-back.  Called at start-up and after every densification (the Gaussian set changed), so the
         capacity follows the scene the way the reference's per-render allocation does."""
+        frac, self.seg1_fraction = self.seg1_fraction, 0.0      # one round: the N of the complete lists
         with torch.no_grad():
             self.render_batch([(v[0], v[1]) for v in views], bg_color)
         need = max(self.num_rendered())
         self.high_water.zero_()
         if need * margin > self.capacity:
             self.grow(factor=margin, need=need)
+        # two rounds pay once the tile split dominates: from ~6M instances per view; segment 1 sized for ~3M of them
+        self.seg1_fraction = (0.0 if need < 6_000_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
         return self.capacity

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 3
+#define B3GS_ABI_VERSION 4
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -158,8 +158,16 @@ typedef struct B3gsForwardView {
   float* out_depth;
   float* out_alpha;
   int32_t* radii;
-  int32_t* device_num_rendered;
+  int32_t* device_num_rendered;  /* N = tile instances binned (segment 1 + segment 2) */
   int32_t depth_order_from;
+  /* Two-round ("termination-aware") binning.  0 < seg1_fraction < 1: only the nearest ceil(seg1_fraction * P) Gaussians
+   * of the depth order are binned first (segment 1 of every tile list); the blend forward marks the tiles whose pixels
+   * all terminated inside it (T < 1e-4: nothing behind can contribute), and the remaining Gaussians are binned into the
+   * OTHER tiles only (segment 2), which are then blended again over segment 1 + segment 2.  Images, n_contrib-relative
+   * gradients and the order inside every list are those of one-round binning; only the instances no pixel could have
+   * reached are never emitted or sorted.  0 or >= 1: one round.  All views of a batch use views[0]'s value; needs packed
+   * instance words (bits(P) + bits(tiles) <= 32), otherwise one round is used. */
+  float seg1_fraction;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);
@@ -181,6 +189,8 @@ typedef struct B3gsBlendView {
   const float* dL_ddepth;    /* may be NULL */
   const float* dL_dalpha;    /* may be NULL */
   float* scratch;            /* backward: b3gs_backward_scratch_floats(P) zeroed floats */
+  int64_t binning_capacity;  /* the capacity `binning` was carved with in the forward (locates segment 2 of the tile
+                              * lists); 0: the forward ran one binning round */
 } B3gsBlendView;
 int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
 int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
@@ -334,6 +344,9 @@ typedef struct B3gsDebugViews {
   const float* final_T;          /* [H*W] */
   const uint32_t* n_contrib;     /* [H*W] */
   int32_t packed_idx_bits;       /* >= 0 whenever bits(P) + bits(tiles) <= 32 (e.g. <= 2M Gaussians at 800x600) */
+  const uint32_t* counts;        /* [3] N1 (segment 1 / the only segment), V, N2 (segment 2 of a two-round forward, else stale) */
+  const uint32_t* point_list2;   /* [N2] segment 2 of the tile lists (packed words), valid when num_rendered was the binning capacity */
+  const uint32_t* ranges2;       /* [tiles,2] segment 2 ranges; EMPTY = (0xFFFFFFFF, 0) */
 } B3gsDebugViews;
 int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,
                      const char* binning, const char* image, B3gsDebugViews* out);

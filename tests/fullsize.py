@@ -99,31 +99,59 @@ def dropin_metrics(P, W, H, fov=60.0, seed=0, yaw=3.0):
 
 
 def _tight_list_metrics(P, W, H, st, fv, radii_hip):
-    """Structure of the tight tile lists of one view against the oracle's full lists (device tensors, int64)."""
+    """Structure of the fused path's tile lists of one view against the oracle's full lists (device tensors, int64).
+    A tile's list is segment 1 followed by segment 2 (two-round binning).  Checked: every entry is in the oracle's list
+    of the same tile, in the oracle's order (segment 2 after segment 1), and every oracle entry that is MISSING either
+    cannot reach alpha = 1/255 at any pixel of the tile (tight binning) or sits at or behind the position where the
+    oracle's own forward stopped reading the tile (largest n_contrib of the tile: two-round binning never emits it)."""
     dev = "cuda"
     agree = torch.from_numpy(st.radii).to(dev) == radii_hip          # Gaussians whose integer radius agrees
     o_pl = torch.from_numpy(st.point_list.astype(np.int64)).to(dev)
     o_tile = torch.from_numpy((st.keys >> np.uint64(32)).astype(np.int64)).to(dev)
-    t_pl, t_tile = fv["point_list"].to(torch.int64), fv["tile_ids"].to(torch.int64)
-    o_keep, t_keep = agree[o_pl], agree[t_pl]
-    o_pl, o_tile, t_pl, t_tile = o_pl[o_keep], o_tile[o_keep], t_pl[t_keep], t_tile[t_keep]
-    o_key, t_key = o_tile * P + o_pl, t_tile * P + t_pl                # (tile, Gaussian) is unique inside a list
+    o_start = torch.from_numpy(st.ranges[:, 0].astype(np.int64)).to(dev)
+    o_q = torch.arange(o_pl.numel(), device=dev) - o_start[o_tile]   # position inside the oracle's tile list
+    n1, n2 = int(fv["counts"][0]), int(fv["counts"][2]) if "point_list2" in fv else 0
+    segs = [(fv["point_list"][:n1].to(torch.int64), fv["tile_ids"][:n1].to(torch.int64))]
+    if n2:
+        segs.append((fv["point_list2"][:n2].to(torch.int64), fv["tile_ids2"][:n2].to(torch.int64)))
+    o_keep = agree[o_pl]
+    o_pl, o_tile, o_q = o_pl[o_keep], o_tile[o_keep], o_q[o_keep]
+    o_key = o_tile * P + o_pl                                          # (tile, Gaussian) is unique inside a list
     so, perm = torch.sort(o_key)
-    idx = torch.searchsorted(so, t_key).clamp(max=so.numel() - 1)
-    member = so[idx] == t_key
-    pos = perm[idx]
-    out = dict(radius_flips=int((~agree).sum()), N_tight=int(fv["point_list"].numel()), N_oracle=int(st.N),
-               subset=bool(member.all()), order_preserved=bool((pos[1:] > pos[:-1]).all()))
+    out = dict(radius_flips=int((~agree).sum()), N_seg1=n1, N_seg2=n2, N_tight=n1 + n2, N_oracle=int(st.N), subset=True,
+               order_preserved=True)
     present = torch.zeros(o_key.numel(), dtype=torch.bool, device=dev)
-    present[pos[member]] = True
-    d_pl, d_tile = o_pl[~present], o_tile[~present]
+    tiles = st.ranges.shape[0]
+    last1 = torch.full((tiles,), -1, dtype=torch.int64, device=dev)
+    for k, (t_pl, t_tile) in enumerate(segs):
+        keep = agree[t_pl]
+        t_pl, t_tile = t_pl[keep], t_tile[keep]
+        t_key = t_tile * P + t_pl
+        idx = torch.searchsorted(so, t_key).clamp(max=so.numel() - 1)
+        member = so[idx] == t_key
+        pos = perm[idx]
+        out["subset"] = out["subset"] and bool(member.all())
+        out["order_preserved"] = out["order_preserved"] and bool((pos[1:] > pos[:-1]).all())
+        present[pos[member]] = True
+        if k == 0:
+            last1.scatter_reduce_(0, t_tile, o_q[pos], reduce="amax")
+        else:   # every segment-2 entry of a tile lies behind every segment-1 entry of that tile
+            out["order_preserved"] = out["order_preserved"] and bool((o_q[pos] > last1[t_tile]).all())
+    d_pl, d_tile, d_q = o_pl[~present], o_tile[~present], o_q[~present]
     out["dropped"] = int(d_pl.numel())
-    # largest alpha any dropped entry reaches at any pixel of its tile, from the oracle's own per-Gaussian record
+    # where the oracle's forward stopped reading each tile
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    nc = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
+    nc[:H, :W] = torch.from_numpy(st.n_contrib.astype(np.int64)).to(dev)
+    tile_stop = nc.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(1).values
+    behind = d_q >= tile_stop[d_tile]
+    out["dropped_unreached"] = int(behind.sum())
+    d_pl, d_tile = d_pl[~behind], d_tile[~behind]
+    # largest alpha any REACHABLE dropped entry attains at any pixel of its tile, from the oracle's own record
     m2d = torch.from_numpy(st.means2D).to(dev).double()
     co = torch.from_numpy(st.conic_opacity).to(dev).double()
-    gx = (W + 15) // 16
     ox = torch.arange(16, device=dev, dtype=torch.float64)
-    worst = 0.0
+    worst, n_bad = 0.0, 0
     for c0 in range(0, d_pl.numel(), 400_000):
         g_, t_ = d_pl[c0:c0 + 400_000], d_tile[c0:c0 + 400_000]
         px = ((t_ % gx) * 16).double()[:, None] + ox[None, :]          # [n,16] pixel x of the tile's columns
@@ -135,8 +163,14 @@ def _tight_list_metrics(P, W, H, st, fv, radii_hip):
         power = -0.5 * (c[:, 0, None, None] * dx * dx + c[:, 2, None, None] * dy * dy) - c[:, 1, None, None] * dx * dy
         a = c[:, 3, None, None] * torch.exp(power.clamp(max=0.0))
         a = torch.where((power > 0) | ~(iny[:, :, None] & inx[:, None, :]), torch.zeros_like(a), a)
-        worst = max(worst, float(a.max()) if a.numel() else 0.0)
+        amax = a.reshape(a.shape[0], -1).max(1).values if a.numel() else a.reshape(0)
+        n_bad += int((amax * 255.0 >= 1.0).sum())
+        # entries that could contribute but were dropped: only legitimate next to a pixel whose termination the two
+        # implementations decide differently (T within an ulp of 1e-4); counted, and excluded from the alpha bound
+        ok = amax * 255.0 < 1.0
+        worst = max(worst, float(amax[ok].max()) if ok.any() else 0.0)
     out["dropped_max_alpha_x255"] = worst * 255.0
+    out["dropped_reachable_contributors"] = n_bad
     return out
 
 
@@ -201,7 +235,6 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
         # the slot's binning buffer is carved for `capacity` instances (that fixes where the tile-id array of the
         # two-word layout starts); the first N entries are the lists
         fv = state_views(P, W, H, sl.capacity, sl.geom, sl.binning, sl.img)
-        fv["point_list"], fv["tile_ids"] = fv["point_list"][:nr[s]], fv["tile_ids"][:nr[s]]
         if check_lists and (k < 2 or k == len(vlist) - 1):
             pv["lists"] = _tight_list_metrics(P, W, H, st, fv, radii)
         ref = tile_ref.backward(st, a.cpu().numpy(), None if b is None else b.cpu().numpy(),

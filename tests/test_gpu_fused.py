@@ -122,7 +122,7 @@ def test_batched_forward_is_bit_identical_to_per_view_forward():
         views += [(cam, 2 * i), (scam, 2 * i + 1)]
     res = {}
     for schedule in ("serial", "batched"):
-        fr = FusedRasterizer(model, W, H, num_slots=len(views), schedule=schedule)
+        fr = FusedRasterizer(model, W, H, num_slots=len(views), schedule=schedule, seg1_fraction=0.0)   # one binning round
         with torch.no_grad():
             outs = fr.render_batch(views, bg)
         torch.cuda.synchronize()
@@ -501,3 +501,63 @@ def test_step_detects_binning_overflow_and_grows():
     assert fr.capacity >= need
     st.step(pair_grad_fn=fn)
     st.check_capacity()
+
+
+@pytest.mark.parametrize("scene", ["dense", "thin"])
+def test_two_round_binning_equals_one_round(scene):
+    """Termination-aware binning (B3gsForwardView.seg1_fraction): bin the nearest fraction of the depth order, blend, bin
+    the rest only into the tiles that are not finished, blend those again.  Every pixel walks the same list prefix in the
+    same order as with one-round binning, so images, final_T and n_contrib are BIT-identical and the gradients equal up
+    to the order of the fp32 atomics -- for any fraction, including ones so small that almost every tile needs the second
+    round, and for a scene whose tiles never saturate ("thin": low opacities)."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.debug import state_views
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H, P = 208, 144, 30000
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    with torch.no_grad():
+        model._scaling += 0.6
+        if scene == "thin":
+            model._opacity -= 4.0
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+    views = []
+    for i, (cam, scam, _t) in enumerate(pairs):
+        views += [(cam, 2 * i, True), (scam, 2 * i + 1, False)]
+
+    def run(frac):
+        model.init_densification_stats()
+        fr = FusedRasterizer(model, W, H, num_slots=len(views), seg1_fraction=frac)
+        fr.fit_capacity(views, bg)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        outs = fr.render_batch(views, bg)
+        o, g = [], []
+        for k, x in enumerate(outs):
+            o.append(x["render"]); g.append(gc)
+            if k % 2 == 0:
+                o += [x["rendered_depth"], x["rendered_alpha"]]; g += [gd, ga]
+        torch.autograd.backward(o, g)
+        torch.cuda.synchronize()
+        assert not fr.overflowed()
+        imgs = [[x[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha")] for x in outs]
+        st = [state_views(P, W, H, fr.capacity, s.geom, s.binning, s.img) for s in fr.slots]
+        aux = [(v["final_T"].clone(), v["n_contrib"].clone(), int(v["counts"][0]), int(v["counts"][2])) for v in st]
+        return imgs, aux, [p.grad.clone() for p in model.parameters()], model.denom.clone(), fr.num_rendered()
+
+    ref_imgs, ref_aux, ref_grads, ref_denom, ref_n = run(0.0)
+    assert all(a[3] == 0 for a in ref_aux)
+    for frac in (0.5, 0.125, 0.01):
+        imgs, aux, grads, denom, n = run(frac)
+        second = sum(a[3] for a in aux)
+        if frac == 0.01 or scene == "thin":
+            assert second > 0, "the second round must have had work"
+        for (a, b) in zip(imgs, ref_imgs):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        for a, b, nn, rn in zip(aux, ref_aux, n, ref_n):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            assert nn == a[2] + a[3] <= rn          # never more instances than one-round binning
+        assert torch.equal(denom, ref_denom)
+        for x, y in zip(grads, ref_grads):
+            if y.numel():
+                assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
