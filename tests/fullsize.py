@@ -194,7 +194,8 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
         if scam is not None:
             vlist.append((scam, slot, False, (gc2, None, None)))
             slot += 1
-    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=True)
+    # two-round binning forced on (the automatic rule enables it from 6M instances per view): it must not change a result
+    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=True, seg1_fraction=0.125)
     with torch.no_grad():                              # size the persistent binning buffers for this scene
         fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
         while fr.overflowed():
