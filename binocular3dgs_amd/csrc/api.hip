@@ -377,8 +377,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
       K1 = K1 < 1 ? 1 : K1;
       for (int k = 0; k < nviews && K1; k++) {
         const B3gsScene& sc = *views[k].view;
-        if (b3gs_packed_idx_bits(P, sc.W, sc.H) < 0 || b3gs_tile_bits(sc.W, sc.H) != b3gs_tile_bits(views[0].view->W, views[0].view->H))
-          K1 = 0;
+        if ((b3gs_tile_bits(sc.W, sc.H) + 7) / 8 != (b3gs_tile_bits(views[0].view->W, views[0].view->H) + 7) / 8) K1 = 0;
       }
       if (K1 >= P) K1 = 0;
     }
@@ -645,7 +644,7 @@ int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, cons
   out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
   out->ranges2 = reinterpret_cast<const uint32_t*>(im.ranges2);
   out->counts = g.header;
-  if (binning) out->point_list2 = b.key[0];
+  if (binning) out->point_list2 = b.val[0];   // + N1 elements (counts[0])
   out->final_T = im.final_T;
   out->n_contrib = im.n_contrib;
   return B3GS_OK;

@@ -75,6 +75,8 @@ struct SortJob {
   int32_t shift_base;    // added to the pass shift (position of the tile id inside a packed key)
   uint32_t* hist;        // [256 * nblk] digit-major + 256 totals
   uint2* ranges;         // non-null on the LAST pass of the tile sort: per-tile [begin, end) by atomic min / max
+  const uint32_t* off_ptr;   // null, or a device word: the n elements start at that offset of kin / vin / kout / vout
+                             // (segment 2 of the tile lists sits behind segment 1 in the same arrays; ranges are absolute)
 };
 struct SortBatch {
   int32_t n;
@@ -117,6 +119,7 @@ struct EmitJob {
   const uint32_t* scount;   // round 2: tiles of the rect still open (null in round 1: all tiles of the rect)
   OpenMap open;             // round 2: the bitmap of the open tiles
   const uint32_t* open_count;   // round 2: their number (0: nothing to emit)
+  const uint32_t* off_ptr;      // round 2: device word N1: the instances go behind segment 1 in the same arrays
 };
 struct EmitBatch {
   int32_t n, P, first;      // Gaussians [first, P) of the depth order
@@ -129,6 +132,7 @@ struct RangeJob {
   uint2* ranges;
   uint32_t n_cap;
   int32_t shift;        // tile id = key >> shift
+  const uint32_t* off_ptr;   // as SortJob::off_ptr
 };
 
 __device__ __forceinline__ uint32_t rect_area(uint2 rc) {
@@ -289,8 +293,9 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_hist(SortBatch sb, in
   const SortJob& job = sb.j[blockIdx.y];
   if (blockIdx.x >= job.nblk) return;
   const int shift = pass_shift + job.shift_base;
-  const uint32_t* __restrict__ keys = job.kin;
-  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
+  const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t* __restrict__ keys = job.kin + off;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
   const uint32_t base = blockIdx.x * B3GS_SORT_TILE;
   // The grid is sized by the CAPACITY (n lives on the device); workgroups past n write nothing -- the digit-major
   // store below is 256 scattered 4-byte writes per workgroup, and row scan / scatter only look at the first
@@ -311,7 +316,8 @@ __global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
   __shared__ uint32_t tmp[8];
   const SortJob& job = sb.j[blockIdx.y];
   const uint32_t nblk = job.nblk;
-  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
+  const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
   const uint32_t used = min(nblk, (n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);   // columns the histogram pass wrote
   uint32_t* row = job.hist + (size_t)blockIdx.x * nblk;
   uint32_t carry = 0;
@@ -340,14 +346,15 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
   const SortJob& job = sb.j[blockIdx.y];
   if (blockIdx.x >= job.nblk) return;
   const int shift = pass_shift + job.shift_base;
-  const uint32_t* __restrict__ keys_in = job.kin;
-  const uint32_t* __restrict__ vals_in = job.vin;
-  uint32_t* __restrict__ keys_out = job.kout;
-  uint32_t* __restrict__ vals_out = job.vout;
+  const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t* __restrict__ keys_in = job.kin + off;
+  const uint32_t* __restrict__ vals_in = job.vin ? job.vin + off : nullptr;
+  uint32_t* __restrict__ keys_out = job.kout + off;
+  uint32_t* __restrict__ vals_out = job.vout ? job.vout + off : nullptr;
   const uint32_t nblk = job.nblk;
   const uint32_t* __restrict__ hist = job.hist;
   const uint32_t* __restrict__ totals = job.hist + (size_t)256 * nblk;
-  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap) : job.n_cap;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
   const uint32_t tile_base = blockIdx.x * B3GS_SORT_TILE;
   if (tile_base >= n) return;  // uniform per workgroup
   const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
@@ -433,8 +440,8 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
         // so run boundaries give the tile's range inside this workgroup; min / max merge the workgroups
         // (a few atomics per workgroup).  Ranges start at (0xFFFFFFFF, 0) = empty (preprocess).
         const uint32_t tile = kk >> job.shift_base;
-        if (p == 0 || (s_key[p - 1] >> job.shift_base) != tile) atomicMin(&job.ranges[tile].x, dst);
-        if (p == tile_n - 1 || (s_key[p + 1] >> job.shift_base) != tile) atomicMax(&job.ranges[tile].y, dst + 1u);
+        if (p == 0 || (s_key[p - 1] >> job.shift_base) != tile) atomicMin(&job.ranges[tile].x, off + dst);
+        if (p == tile_n - 1 || (s_key[p + 1] >> job.shift_base) != tile) atomicMax(&job.ranges[tile].y, off + dst + 1u);
       }
     }
   }
@@ -496,9 +503,10 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ uint32_t s_end[4][64];
   const EmitJob& job = eb.j[blockIdx.y];
   const int P = eb.P;
-  const uint32_t n_cap = job.n_cap;
-  uint32_t* __restrict__ tile_out = job.tile_out;
-  uint32_t* __restrict__ idx_out = job.idx_out;
+  const uint32_t off = (ROUND2 && job.off_ptr) ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t n_cap = job.n_cap - off;
+  uint32_t* __restrict__ tile_out = job.tile_out + off;
+  uint32_t* __restrict__ idx_out = job.idx_out ? job.idx_out + off : nullptr;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   const int s = eb.first + (int)(blockIdx.x * 256 + threadIdx.x);
   uint32_t gid = 0, cnt = 0, end = 0;
@@ -703,14 +711,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_apply(Scan2Batch sb)
 
 __global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
   const RangeJob& job = rb.j[blockIdx.y];
-  const uint32_t* __restrict__ tile_sorted = job.tile_sorted;
-  const uint32_t n = min(*job.n_ptr, job.n_cap);
+  const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t* __restrict__ tile_sorted = job.tile_sorted + off;
+  const uint32_t n = min(*job.n_ptr, job.n_cap - off);
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int sh = job.shift;
   const uint32_t t = tile_sorted[j] >> sh;
-  if (j == 0 || (tile_sorted[j - 1] >> sh) != t) job.ranges[t].x = j;
-  if (j == n - 1 || (tile_sorted[j + 1] >> sh) != t) job.ranges[t].y = j + 1;
+  if (j == 0 || (tile_sorted[j - 1] >> sh) != t) job.ranges[t].x = off + j;
+  if (j == n - 1 || (tile_sorted[j + 1] >> sh) != t) job.ranges[t].y = off + j + 1;
 }
 
 int tile_sort_passes(int W, int H) {
@@ -731,7 +740,7 @@ void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], u
                                 uint32_t* hist, hipStream_t s) {
   SortBatch db;
   db.n = 1;
-  db.j[0] = SortJob{keys, nullptr, skey[1], sval[1], nullptr, n, b3gs_sort_blocks((int64_t)n), 0, hist, nullptr};
+  db.j[0] = SortJob{keys, nullptr, skey[1], sval[1], nullptr, n, b3gs_sort_blocks((int64_t)n), 0, hist, nullptr, nullptr};
   for (int pass = 0; pass < 4; pass++) {
     radix_pass(db, 8 * pass, s);
     const int dst = pass & 1;  // destination of the NEXT pass
@@ -763,7 +772,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   for (int v = 0; v < nviews; v++) {
     if (jobs[v].order_from != -1) continue;
     const GeomView& g = jobs[v].g;
-    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, 0, g.hist, nullptr};
+    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, 0, g.hist, nullptr, nullptr};
   }
   for (int pass = 0; pass < 4; pass++) {
     radix_pass(db, 8 * pass, s);
@@ -850,15 +859,15 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
       // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
       // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
       // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
-                        b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr};
-      rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits};
+                        b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, nullptr};
+      rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits, nullptr};
     } else {
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
-                        b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr};
-      rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0};
+                        b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, nullptr};
+      rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0, nullptr};
     }
   }
   if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
@@ -885,8 +894,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   const int K1 = b3gs_seg1_count(jobs[0], P);
   if (K1 >= P) return;
   const int passes = tile_sort_passes(jobs[0].W, jobs[0].H);
-  for (int v = 0; v < nviews; v++)   // (the caller only enables K1 for batches of equal tile-sort depth and packed words)
-    if (tile_sort_passes(jobs[v].W, jobs[v].H) != passes || b3gs_packed_idx_bits(P, jobs[v].W, jobs[v].H) < 0) return;
+  for (int v = 0; v < nviews; v++)   // (the caller only enables K1 for batches of equal tile-sort depth)
+    if (tile_sort_passes(jobs[v].W, jobs[v].H) != passes) return;
   const int rest = P - K1;
   const int total_tiles = (rest + SCAN_TILE - 1) / SCAN_TILE;
   Scan2Batch sc;
@@ -915,7 +924,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
   hipLaunchKernelGGL(scan2_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
 
-  // emission + stable split by tile id, in the idle half of the packed-word binning buffer: key[first] -> ... -> key[0]
+  // emission + stable split by tile id BEHIND segment 1 in the same ping-pong arrays (element offset N1 = header[0],
+  // read on the device): the lists end in val[0] / key[0] like segment 1's, the ranges hold absolute positions
   const int first = passes & 1;
   EmitBatch eb;
   eb.n = nviews;
@@ -932,11 +942,20 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     max_cap = n_cap > max_cap ? n_cap : max_cap;
     const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
     const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
-    eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], nullptr, n_cap, gx, idx_bits,
-                      jb.g.scount, OpenMap{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx}, jb.im.header + 3};
-    tb.j[v] = SortJob{jb.b.key[first], nullptr, jb.b.key[first ^ 1], nullptr, jb.g.header + 2, n_cap,
-                      b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr};
-    rb.j[v] = RangeJob{jb.b.key[0], jb.g.header + 2, jb.im.ranges2, n_cap, idx_bits};
+    const OpenMap om{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx};
+    if (idx_bits >= 0) {
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits,
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header};
+      tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header + 2, n_cap,
+                        b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, jb.g.header};
+      rb.j[v] = RangeJob{jb.b.val[0], jb.g.header + 2, jb.im.ranges2, n_cap, idx_bits, jb.g.header};
+    } else {
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0,
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header};
+      tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header + 2, n_cap,
+                        b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, jb.g.header};
+      rb.j[v] = RangeJob{jb.b.key[0], jb.g.header + 2, jb.im.ranges2, n_cap, 0, jb.g.header};
+    }
   }
   if (max_cap == 0) return;
   hipLaunchKernelGGL(emit_instances<true>, dim3((rest + 255) / 256, nviews), dim3(256), 0, s, eb);
@@ -946,9 +965,9 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     radix_pass(tb, 8 * p, s);
     for (int v = 0; v < nviews; v++) {
       SortJob& j = tb.j[v];
-      const uint32_t* k = j.kin;
-      j.kin = j.kout;
-      j.kout = const_cast<uint32_t*>(k);
+      const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
+      j.kin = j.kout; j.vin = j.vout;
+      j.kout = const_cast<uint32_t*>(k); j.vout = const_cast<uint32_t*>(vv);
     }
   }
   if (passes == 0) hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);

@@ -616,8 +616,8 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.ntiles = v.grid_x * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   v.ranges = im.ranges;
   v.point_list = b.val[0];
-  v.ranges2 = im.ranges2;      // empty unless a second binning round ran (b3gs_launch_round2_batch)
-  v.point_list2 = b.key[0];
+  v.ranges2 = im.ranges2;      // empty unless a second binning round ran (b3gs_launch_round2_batch); segment 2 sits
+  v.point_list2 = b.val[0];    // behind segment 1 in the same array, its ranges are absolute positions
   v.open_rows = nullptr;
   v.open_count = im.header + 3;
   v.row_words = (v.grid_x + 63) / 64;

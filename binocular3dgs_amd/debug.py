@@ -43,11 +43,10 @@ def state_views(P: int, W: int, H: int, num_rendered: int, geom: torch.Tensor, b
             w64 = words.to(torch.int64) & 0xFFFFFFFF
             out["point_list"] = (w64 & ((1 << v.packed_idx_bits) - 1)).to(torch.int32)
             out["tile_ids"] = (w64 >> v.packed_idx_bits).to(torch.int32)
-            # segment 2 of a two-round forward (num_rendered must be the capacity the buffer was carved with)
-            w2 = _slice(binning, v.point_list2, num_rendered, torch.int32).to(torch.int64) & 0xFFFFFFFF
-            out["point_list2"] = (w2 & ((1 << v.packed_idx_bits) - 1)).to(torch.int32)
-            out["tile_ids2"] = (w2 >> v.packed_idx_bits).to(torch.int32)
+            # segment 2 of a two-round forward sits behind segment 1 in the same array (N1 = counts[0], N2 = counts[2])
+            out["point_list2"], out["tile_ids2"] = out["point_list"], out["tile_ids"]
         else:
             out["point_list"] = words
             out["tile_ids"] = _slice(binning, v.tile_ids, num_rendered, torch.int32)
+            out["point_list2"], out["tile_ids2"] = out["point_list"], out["tile_ids"]
     return out

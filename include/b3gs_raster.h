@@ -165,8 +165,7 @@ typedef struct B3gsForwardView {
    * all terminated inside it (T < 1e-4: nothing behind can contribute), and the remaining Gaussians are binned into the
    * OTHER tiles only (segment 2), which are then blended again over segment 1 + segment 2.  Images, n_contrib-relative
    * gradients and the order inside every list are those of one-round binning; only the instances no pixel could have
-   * reached are never emitted or sorted.  0 or >= 1: one round.  All views of a batch use views[0]'s value; needs packed
-   * instance words (bits(P) + bits(tiles) <= 32), otherwise one round is used. */
+   * reached are never emitted or sorted.  0 or >= 1: one round.  All views of a batch use views[0]'s value. */
   float seg1_fraction;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
@@ -189,8 +188,8 @@ typedef struct B3gsBlendView {
   const float* dL_ddepth;    /* may be NULL */
   const float* dL_dalpha;    /* may be NULL */
   float* scratch;            /* backward: b3gs_backward_scratch_floats(P) zeroed floats */
-  int64_t binning_capacity;  /* the capacity `binning` was carved with in the forward (locates segment 2 of the tile
-                              * lists); 0: the forward ran one binning round */
+  int64_t binning_capacity;  /* the capacity `binning` was carved with in the forward (two-word instance layout: locates
+                              * nothing the blend reads; kept for symmetry with B3gsForwardView) */
 } B3gsBlendView;
 int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
 int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_stream_t stream);
@@ -345,7 +344,8 @@ typedef struct B3gsDebugViews {
   const uint32_t* n_contrib;     /* [H*W] */
   int32_t packed_idx_bits;       /* >= 0 whenever bits(P) + bits(tiles) <= 32 (e.g. <= 2M Gaussians at 800x600) */
   const uint32_t* counts;        /* [3] N1 (segment 1 / the only segment), V, N2 (segment 2 of a two-round forward, else stale) */
-  const uint32_t* point_list2;   /* [N2] segment 2 of the tile lists (packed words), valid when num_rendered was the binning capacity */
+  const uint32_t* point_list2;   /* segment 2 of the tile lists: N2 entries starting at element counts[0] (= N1) of this array (it is
+                                  * point_list: segment 2 sits behind segment 1); tile ids likewise at tile_ids + N1 */
   const uint32_t* ranges2;       /* [tiles,2] segment 2 ranges; EMPTY = (0xFFFFFFFF, 0) */
 } B3gsDebugViews;
 int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,

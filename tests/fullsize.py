@@ -112,8 +112,8 @@ def _tight_list_metrics(P, W, H, st, fv, radii_hip):
     o_q = torch.arange(o_pl.numel(), device=dev) - o_start[o_tile]   # position inside the oracle's tile list
     n1, n2 = int(fv["counts"][0]), int(fv["counts"][2]) if "point_list2" in fv else 0
     segs = [(fv["point_list"][:n1].to(torch.int64), fv["tile_ids"][:n1].to(torch.int64))]
-    if n2:
-        segs.append((fv["point_list2"][:n2].to(torch.int64), fv["tile_ids2"][:n2].to(torch.int64)))
+    if n2:   # segment 2 sits behind segment 1 in the same arrays
+        segs.append((fv["point_list2"][n1:n1 + n2].to(torch.int64), fv["tile_ids2"][n1:n1 + n2].to(torch.int64)))
     o_keep = agree[o_pl]
     o_pl, o_tile, o_q = o_pl[o_keep], o_tile[o_keep], o_q[o_keep]
     o_key = o_tile * P + o_pl                                          # (tile, Gaussian) is unique inside a list
