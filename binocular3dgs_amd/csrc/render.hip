@@ -289,8 +289,15 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
 // arrays; on one row the atomic is free.  PMC: VALU busy 66 % of all SIMD cycles (incl. the tail), i.e. the
 // kernel is VALU/issue bound; trimming 15 % of the VALU instructions bought 1-2 %.
 constexpr int RED_STRIDE = 68;
+// B3GS_BWD_PIPELINE 1 consumes the reduction reads of Gaussian n only after evaluating Gaussian n+1 (the write -> read
+// round trip overlaps the next evaluation) and was round 1's choice at 6 waves per SIMD (80 VGPRs).  Reducing at once
+// frees the 16 registers the pending reads occupy: 69 VGPRs, 7 waves per SIMD, no spill -- measured 3 % faster
+// (0.107-0.112 -> 0.102-0.105 ms per view, A/B on the same box, tools/ab.sh); 8 waves (64 VGPRs, 5 spilled) is no better.
+#ifndef B3GS_BWD_PIPELINE
+#define B3GS_BWD_PIPELINE 0
+#endif
 #ifndef B3GS_BWD_WAVES
-#define B3GS_BWD_WAVES 6  /* waves per SIMD the register allocator must leave room for (80 VGPRs) */
+#define B3GS_BWD_WAVES 7  /* waves per SIMD the register allocator must leave room for */
 #endif
 
 template <int CHUNK>
@@ -469,13 +476,14 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       float p[10];                                                                               \
       bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
       B3GS_ROW_WRITES(p);                                                                        \
-      if (pending) B3GS_RETIRE_PENDING();                                                        \
+      if (B3GS_BWD_PIPELINE && pending) B3GS_RETIRE_PENDING();                                   \
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
       __builtin_amdgcn_wave_barrier();                                                           \
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
       q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];                            \
       pend_g = (uint32_t)__float_as_int(Cc.z);                                                   \
-      pending = true;                                                                            \
+      if (B3GS_BWD_PIPELINE) pending = true;                                                     \
+      else B3GS_RETIRE_PENDING();   /* experiment: reduce at once (16 fewer live VGPRs) */        \
     }                                                                                            \
   } while (0)
   // row k of the per-wave scratch <- component k of every lane.  ds_write_addtid_b32 (address = M0 + offset

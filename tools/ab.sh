@@ -6,3 +6,4 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$1', d['value'], d['stage_ms_per_view'])"; }
 run "" "$@"
 for f in tools/ab/*.so; do run $PWD/$f "$@"; done
+run "" "$@"
