@@ -296,6 +296,9 @@ constexpr int RED_STRIDE = 68;
 #ifndef B3GS_BWD_PIPELINE
 #define B3GS_BWD_PIPELINE 0
 #endif
+#ifndef B3GS_BWD_PREFETCH
+#define B3GS_BWD_PREFETCH 1   /* fetch the next candidate's record (3 broadcast ds_read_b128) before evaluating the current one */
+#endif
 #ifndef B3GS_BWD_WAVES
 #define B3GS_BWD_WAVES 7  /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -522,11 +525,12 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       // Walk the set bits from the back.  The record of the NEXT candidate (three broadcast ds_read_b128:
       // A, B, C incl. the Gaussian index) is fetched before the current one is evaluated; the loop is
       // unrolled by two so the two register sets swap roles instead of being copied.
-      int j = 63 - __builtin_clzll(m);
-      m &= ~(1ull << j);
       const float4* const sA = sh.f.A + pw * 64;
       const float4* const sB = sh.f.B + pw * 64;
       const float4* const sC = sh.f.C + pw * 64;
+#if B3GS_BWD_PREFETCH
+      int j = 63 - __builtin_clzll(m);
+      m &= ~(1ull << j);
       float4 A0 = sA[j], B0 = sB[j], C0 = sC[j], A1, B1, C1;
       while (true) {
         bool more = m != 0;
@@ -544,6 +548,14 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
         if (!more) break;
         j = jn;
       }
+#else
+      while (m) {
+        const int j = 63 - __builtin_clzll(m);
+        m &= ~(1ull << j);
+        const float4 A0 = sA[j], B0 = sB[j], C0 = sC[j];
+        B3GS_BWD_CANDIDATE(A0, B0, C0, j);
+      }
+#endif
     }
     __syncthreads();
   }
