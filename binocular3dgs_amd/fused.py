@@ -375,4 +375,16 @@ class FusedRasterizer:
             self.grow(factor=margin, need=need)
         # two rounds pay once the tile split dominates: from ~6M instances per view; segment 1 sized for ~3M of them
         self.seg1_fraction = (0.0 if need < 6_000_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
+        if self._seg1_auto and self.seg1_fraction > 0.0:
+            # ... unless the scene does not saturate: every tile left open after segment 1 is blended twice and gets
+            # its whole list anyway.  One trial forward: more than a quarter of the tiles open -> one round.
+            with torch.no_grad():
+                self.render_batch([(v[0], v[1]) for v in views], bg_color)
+            torch.cuda.synchronize(self.dev)
+            tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+            opened = sum(int(self.slots[int(v[1])].img[:16].view(torch.int32)[3]) for v in views)
+            self.open_tile_fraction = opened / max(tiles * len(views), 1)
+            if self.open_tile_fraction > 0.25:
+                self.seg1_fraction = 0.0
+            self.high_water.zero_()
         return self.capacity
