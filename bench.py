@@ -498,6 +498,7 @@ def main():
         if extras:
             result["extras"] = extras
         if world == 1 and not args.inner:
+            result["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
             if not args.no_pmc:
                 pmc_passes(args, result)
             if not args.no_cpu_baseline:       # rank 0 at N=1 only: the other ranks would wait at the barrier
@@ -594,6 +595,23 @@ def pmc_passes(args, result):
         roof["valu"] = {"bound": "valu issue slots: 256 CUs x 4 SIMDs, one plain fp32 wave64 instruction per 2 cycles "
                                  "(tools/ubench/valu_rate.hip); transcendental / DPP / LDS-path instructions occupy 8",
                         "frac": vd.get(roof["kernel"], {}).get("issue_frac"), "kernels": vd}
+
+
+def measured_copy_bandwidth(dev):
+    """Streaming ceiling of this very box: device-to-device copy of 1 GiB (read + write bytes / time), best of 5 --
+    SURVEY 8(d) asks for the measured peak next to the 8 TB/s datasheet figure (MI355X_MICROARCH.md quotes 6.29 TB/s)."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    best = 0.0
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        best = max(best, 2.0 * 4.0 * n / (e0.elapsed_time(e1) / 1e3) / 1e9)
+    return round(best, 1)
 
 
 def cpu_baseline(P, W, H, seed):
