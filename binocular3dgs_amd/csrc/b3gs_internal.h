@@ -52,7 +52,9 @@ struct ImgView {        // sized by W*H
                         //          an unterminated pixel after segment 1 (header[3] = their number); zeroed per forward
 };
 
+#ifndef B3GS_SORT_ITEMS
 #define B3GS_SORT_ITEMS 16                       /* keys per thread in a radix tile */
+#endif
 #define B3GS_SORT_THREADS 256
 #define B3GS_SORT_TILE (B3GS_SORT_ITEMS * B3GS_SORT_THREADS) /* 4096 keys per workgroup */
 
