@@ -592,6 +592,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
       !grads->rotation || !grads->opacity)
     return fail(B3GS_ERR_ARG, "%s", "NULL gradient buffer");
   B3gsViewRef refs[B3GS_MAX_FUSED_VIEWS];
+  uint32_t *list = nullptr, *counts = nullptr;
   for (int k = 0; k < nviews; k++) {
     const B3gsFusedView& fv = views[k];
     if (!fv.view || !fv.radii || !fv.geometry || !fv.scratch) return fail(B3GS_ERR_ARG, "%s", "NULL view state");
@@ -599,6 +600,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
       return fail(B3GS_ERR_ARG, "%s", "views of one call must share P, M, D and scale_modifier");
     GeomView g;
     b3gs_geom_view(const_cast<char*>(fv.geometry), v0->P, &g);
+    if (k == 0) { list = g.skey[1]; counts = g.skey[0]; }   // idle after the forward's depth sort
     refs[k] = B3gsViewRef{fv.view->W, fv.view->H, fv.view->tan_fovx, fv.view->tan_fovy, fv.view->viewmatrix,
                           fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D,
                           fv.densify_stats};
@@ -608,7 +610,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
   hipStream_t s = (hipStream_t)stream;
   StageTimer tm(s);
   tm.mark(-1);
-  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, stats, first, count, s);
+  b3gs_launch_accumulate_views(*v0, *params, nviews, refs, *grads, overwrite, stats, first, count, list, counts, s);
   tm.mark(4);
   HIP_TRY(hipGetLastError());
   return B3GS_OK;

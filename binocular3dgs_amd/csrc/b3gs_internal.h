@@ -283,4 +283,4 @@ struct B3gsViewRef {
 };
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
                                   const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, int first, int count,
-                                  hipStream_t s);
+                                  uint32_t* list, uint32_t* counts, hipStream_t s);   // list, counts: P words of scratch each

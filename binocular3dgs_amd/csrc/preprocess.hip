@@ -695,9 +695,9 @@ struct MultiViews {
 constexpr int ACC_PER_THREAD = B3GS_ACC_PER_THREAD;
 constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
 
-__global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
-    accumulate_views_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
-                            int count, B3gsDensifyStats ds) {
+__global__ void __launch_bounds__(256, 8)
+    accumulate_scan_kernel(B3gsScene base, MultiViews mv, B3gsRawGrads rg, int overwrite, int first, int count,
+                           B3gsDensifyStats ds, uint32_t* __restrict__ g_list, uint32_t* __restrict__ g_count) {
   __shared__ uint32_t s_list[ACC_BLOCK];
   __shared__ uint32_t s_count;
   if (threadIdx.x == 0) s_count = 0;
@@ -766,9 +766,21 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
     }
   }
   __syncthreads();
-
-  // ---- phase 2 ------------------------------------------------------------------------------------------
+  // the list of this block's touched Gaussians travels through global memory to the chain-rule kernel (which needs 168
+  // VGPRs: 3 waves per SIMD; this streaming pass runs at 8)
   const uint32_t n_list = s_count;
+  for (uint32_t e = threadIdx.x; e < n_list; e += 256) g_list[(size_t)blockIdx.x * ACC_BLOCK + e] = s_list[e];
+  if (threadIdx.x == 0) g_count[blockIdx.x] = n_list;
+}
+
+__global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
+    accumulate_chain_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
+                            const uint32_t* __restrict__ g_list, const uint32_t* __restrict__ g_count) {
+  const int blk_first = first + (int)blockIdx.x * ACC_BLOCK;
+  const int nrest = 3 * (base.M - 1);
+  const uint32_t* __restrict__ s_list = g_list + (size_t)blockIdx.x * ACC_BLOCK;
+  // ---- phase 2 ------------------------------------------------------------------------------------------
+  const uint32_t n_list = g_count[blockIdx.x];
   SceneX sx_;
   sx_.sc = base;
   sx_.raw = raw;
@@ -893,14 +905,17 @@ void b3gs_launch_preprocess_backward(const SceneX& sx, const GeomView& g, const 
 
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
                                   const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, int first, int count,
-                                  hipStream_t s) {
+                                  uint32_t* list, uint32_t* counts, hipStream_t s) {
   if (base.P <= 0 || nviews <= 0 || count <= 0) return;
   MultiViews mv;
   mv.n = nviews;
   for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
   const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(accumulate_views_kernel, dim3((count + ACC_BLOCK - 1) / ACC_BLOCK), dim3(256), 0, s, base, raw, mv, rg,
-                     overwrite, first, count, ds);
+  // scratch of the two-kernel pass: the depth-sort ping-pong arrays of view 0's geometry buffer (P words each) are idle
+  // once the forward has built its tile lists
+  const dim3 grid((count + ACC_BLOCK - 1) / ACC_BLOCK);
+  hipLaunchKernelGGL(accumulate_scan_kernel, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
+  hipLaunchKernelGGL(accumulate_chain_kernel, grid, dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,
