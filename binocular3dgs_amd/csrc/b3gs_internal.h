@@ -28,7 +28,8 @@ struct GeomView {       // sized by P
   uint32_t* clamped;    // [P]   bit c set: SH colour channel c clamped at 0
   uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
   uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
-  uint32_t* soffs;      // [P]   inclusive scan of tiles_touched in depth order (segment 1: [0,K1), segment 2: [K1,P))
+  uint32_t* soffs;      // [P]   segment 1: sums of the 256-Gaussian sub-blocks of the depth order ([ceil(K1/256)] words);
+                        //       segment 2: inclusive scan of scount over [K1,P) (written after segment 1 was emitted)
   uint2* srect;         // [P]   rect in depth order
   uint32_t* scount;     // [P]   segment 2: tiles of the rect that were not finished after segment 1, in depth order
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)

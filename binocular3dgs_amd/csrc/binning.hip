@@ -90,7 +90,7 @@ struct ScanJob {
   int32_t partner;          // >= 0: job whose rects are interleaved with this one's ([P][2]) and which shares the depth
                             //       order: this job's workgroups gather both with ONE 16-byte load; -2: done by its partner
   uint2* srect;             // the same in depth order (written by the first scan launch: ONE gather per view)
-  uint32_t* soffs;
+  uint32_t* soffs;          // segment 1: [ceil(K1 / 256)] sums of the 256-Gaussian sub-blocks (the emission scans inside them)
   uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
   uint32_t* chunk_vis;      // [SCAN_MAX_CHUNKS]
   uint32_t* header;
@@ -120,9 +120,10 @@ struct EmitJob {
   OpenMap open;             // round 2: the bitmap of the open tiles
   const uint32_t* open_count;   // round 2: their number (0: nothing to emit)
   const uint32_t* off_ptr;      // round 2: device word N1: the instances go behind segment 1 in the same arrays
+  const uint32_t* chunk_base;   // round 1: exclusive instance offset of every scan chunk (soffs holds the sub-block sums)
 };
 struct EmitBatch {
-  int32_t n, P, first;      // Gaussians [first, P) of the depth order
+  int32_t n, P, first, subs;    // Gaussians [first, P) of the depth order; round 1: 256-Gaussian sub-blocks per scan chunk
   EmitJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -145,20 +146,34 @@ struct RangeBatch {
 
 // ---------------------------------------------------------------------------------------------
 // scan of tiles_touched in depth order: soffs[s] = sum_{s' <= s} tiles_touched[order[s']]
-// three launches: per-chunk sums, scan of chunk sums (+ N, V to the headers), per-chunk rescan
+// two launches: per-chunk sums + per-256-Gaussian sub-block sums, scan of chunk sums (+ N, V to the headers); the
+// emission kernel finishes the scan inside its own sub-block
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 4096
 constexpr int SCAN_MAX_CHUNKS = 2048;
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+  return v;
+}
+
+// One pass gathers the rects in depth order (the random access of the binning), stores them sorted, and produces the
+// chunk sums AND the sums of every 256-Gaussian sub-block (iteration r of the strided loop = sub-block r): the emission
+// kernel scans inside its own sub-block, so no per-Gaussian offset array is written or read.
+constexpr int SCAN_MAX_SUBS = 64;   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
+  __shared__ uint32_t ssub[2][4][SCAN_MAX_SUBS];
   const ScanJob& job = sb.j[blockIdx.y];
   if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
   const uint32_t* __restrict__ order = job.order;
+  const int subs = sb.tiles_per_chunk * SCAN_ITEMS;
   const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
+  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   uint32_t sum = 0, vis = 0, sum2 = 0, vis2 = 0;
   // tiles_touched == area of the rectangle (preprocess keeps them consistent)
   if (job.partner >= 0) {
@@ -166,34 +181,50 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
     const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
     uint2* __restrict__ sa = job.srect;
     uint2* __restrict__ sb2 = pj.srect;
-    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-      const uint4 rr = rect2[order[i]];   // the random access of the binning: one line for both views of the pair
-      const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
-      sa[i] = ra;
-      sb2[i] = rb;
-      const uint32_t ta = rect_area(ra), tb = rect_area(rb);
+    for (int r = 0; r < subs; r++) {
+      const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
+      uint32_t ta = 0, tb = 0;
+      if (i < end) {
+        const uint4 rr = rect2[order[i]];   // the random access of the binning: one line for both views of the pair
+        const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
+        sa[i] = ra;
+        sb2[i] = rb;
+        ta = rect_area(ra);
+        tb = rect_area(rb);
+      }
       sum += ta; vis += (ta != 0);
       sum2 += tb; vis2 += (tb != 0);
+      const uint32_t wa = wave_sum(ta), wb = wave_sum(tb);
+      if (lane == 0) { ssub[0][w][r] = wa; ssub[1][w][r] = wb; }
     }
   } else {
     const uint2* __restrict__ rect = job.rect;
     const size_t stride = (size_t)job.rect_stride;
     uint2* __restrict__ srect = job.srect;
-    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-      const uint2 rc = rect[order[i] * stride];
-      srect[i] = rc;
-      const uint32_t t = rect_area(rc);
+    for (int r = 0; r < subs; r++) {
+      const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
+      uint32_t t = 0;
+      if (i < end) {
+        const uint2 rc = rect[order[i] * stride];
+        srect[i] = rc;
+        t = rect_area(rc);
+      }
       sum += t;
       vis += (t != 0);
+      const uint32_t wa = wave_sum(t);
+      if (lane == 0) ssub[0][w][r] = wa;
     }
   }
   uint32_t tot, tot2;
-  block_excl_scan_256(sum, tmp, &tot);
+  block_excl_scan_256(sum, tmp, &tot);      // (its barriers also publish ssub)
   block_excl_scan_256(vis, tmp, &tot2);
   if (threadIdx.x == 0) {
     job.chunk_sums[blockIdx.x] = tot;
     job.chunk_vis[blockIdx.x] = tot2;
   }
+  if ((int)threadIdx.x < subs)
+    job.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
+        (ssub[0][0][threadIdx.x] + ssub[0][1][threadIdx.x]) + (ssub[0][2][threadIdx.x] + ssub[0][3][threadIdx.x]);
   if (job.partner >= 0) {
     const ScanJob& pj = sb.j[job.partner];
     block_excl_scan_256(sum2, tmp, &tot);
@@ -202,6 +233,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
       pj.chunk_sums[blockIdx.x] = tot;
       pj.chunk_vis[blockIdx.x] = tot2;
     }
+    if ((int)threadIdx.x < subs)
+      pj.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
+          (ssub[1][0][threadIdx.x] + ssub[1][1][threadIdx.x]) + (ssub[1][2][threadIdx.x] + ssub[1][3][threadIdx.x]);
   }
 }
 
@@ -233,48 +267,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
     job.header[2] = 0u;    // N2: set by the second binning round, if one runs
     if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; job.img_header[2] = 0u; job.img_header[3] = 0u; }
     if (job.n_out) *job.n_out = (int32_t)tot;
-  }
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_apply(ScanBatch sb) {
-  __shared__ uint32_t wave_tot[4];
-  const ScanJob& job = sb.j[blockIdx.y];
-  const uint2* __restrict__ srect = job.srect;
-  uint32_t* __restrict__ soffs = job.soffs;
-  const int P = sb.P;
-  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  uint32_t carry = job.chunk_sums[blockIdx.x];
-  const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
-  for (int t = 0; t < sb.tiles_per_chunk; t++) {
-    const int64_t tb = begin + (int64_t)t * SCAN_TILE;
-    if (tb >= P) break;
-    // wave w owns the contiguous slab [w*1024, (w+1)*1024) of the tile, 16 rounds of 64 consecutive
-    // elements (coalesced loads and stores); running inclusive scan in registers
-    const int64_t wb = tb + (int64_t)w * (SCAN_ITEMS * 64);
-    uint32_t inc[SCAN_ITEMS], run = 0;
-#pragma unroll
-    for (int r = 0; r < SCAN_ITEMS; r++) {
-      const int64_t i = wb + r * 64 + lane;
-      const uint32_t v = i < P ? rect_area(srect[i]) : 0u;
-      inc[r] = run + wave_incl_scan(v);
-      run = __shfl(inc[r], 63, 64);
-    }
-    if (lane == 0) wave_tot[w] = run;
-    __syncthreads();
-    uint32_t base = carry, tot = 0;
-#pragma unroll
-    for (unsigned k = 0; k < 4; k++) {
-      const uint32_t x = wave_tot[k];
-      if (k < w) base += x;
-      tot += x;
-    }
-#pragma unroll
-    for (int r = 0; r < SCAN_ITEMS; r++) {
-      const int64_t i = wb + r * 64 + lane;
-      if (i < P) soffs[i] = base + inc[r];
-    }
-    carry += tot;
-    __syncthreads();
   }
 }
 
@@ -501,6 +493,7 @@ __device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const Op
 template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ uint32_t s_end[4][64];
+  __shared__ uint32_t s_tmp[8];
   const EmitJob& job = eb.j[blockIdx.y];
   const int P = eb.P;
   const uint32_t off = (ROUND2 && job.off_ptr) ? min(*job.off_ptr, job.n_cap) : 0u;
@@ -521,7 +514,16 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     gid = job.order[s];
     rc = job.srect[s];
     if (!ROUND2) cnt = rect_area(rc);
-    end = job.soffs[s];
+    else end = job.soffs[s];
+  }
+  if (!ROUND2) {
+    // inclusive end of every Gaussian's instance run: offset of this 256-Gaussian sub-block (chunk base + the sums of
+    // the sub-blocks before it: uniform scalar loads) + the scan inside the sub-block
+    const uint32_t chunk = blockIdx.x / (uint32_t)eb.subs, sub = blockIdx.x % (uint32_t)eb.subs;
+    uint32_t base = job.chunk_base[chunk];
+    for (uint32_t k = 0; k < sub; k++) base += job.soffs[(size_t)chunk * eb.subs + k];
+    uint32_t tot;
+    end = base + block_excl_scan_256(cnt, s_tmp, &tot) + cnt;
   }
   // lanes past P inherit the last valid end so the search array stays monotone
   const uint32_t wave_end = __shfl(end, 63 - (int)__builtin_clzll(__ballot(s < P) | 1ull), 64);
@@ -816,7 +818,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   }
   hipLaunchKernelGGL(scan_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
-  hipLaunchKernelGGL(scan_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  // (no per-Gaussian offsets: the emission scans inside its 256-Gaussian sub-block, see scan_chunk_sums)
 }
 
 void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
@@ -844,6 +846,10 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   eb.n = nviews;
   eb.P = K1;
   eb.first = 0;
+  {   // the chunking of b3gs_launch_depth_order_batch's scan
+    const int total_tiles = (K1 + SCAN_TILE - 1) / SCAN_TILE;
+    eb.subs = ((total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS) * SCAN_ITEMS;
+  }
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -859,12 +865,12 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
       // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
       // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
       // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr, jb.g.scan_tmp};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits, nullptr};
     } else {
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr, jb.g.scan_tmp};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0, nullptr};
@@ -931,6 +937,7 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   eb.n = nviews;
   eb.P = P;
   eb.first = K1;
+  eb.subs = 1;
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -945,13 +952,13 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     const OpenMap om{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx};
     if (idx_bits >= 0) {
       eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits,
-                        jb.g.scount, om, jb.im.header + 3, jb.g.header};
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header + 2, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, jb.g.header};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header + 2, jb.im.ranges2, n_cap, idx_bits, jb.g.header};
     } else {
       eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0,
-                        jb.g.scount, om, jb.im.header + 3, jb.g.header};
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header + 2, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, jb.g.header};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header + 2, jb.im.ranges2, n_cap, 0, jb.g.header};
