@@ -72,6 +72,9 @@ void blend_forward_one(const B3gsScene& sc, const GeomView& g, const BinView& b,
                        float* out_depth, float* out_alpha, hipStream_t s) {
   BlendBatch batch;
   batch.n = 1;
+  batch.order = nullptr;
+  batch.order_buf = nullptr;
+  batch.cls_size = 0;
   batch.v[0] = b3gs_blend_view(sc, g, b, im);
   batch.v[0].out_color = out_color;
   batch.v[0].out_depth = out_depth;
@@ -313,6 +316,9 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   PreBatch pb;
   BinJob jobs[B3GS_MAX_FUSED_VIEWS];
   BlendBatch bb;
+  bb.order = nullptr;
+  bb.order_buf = nullptr;
+  bb.cls_size = 0;
   pb.n = bb.n = nviews;
   pb.raw_mode = 1;
   pb.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
@@ -442,6 +448,8 @@ int b3gs_backward_raw(const B3gsScene* view, const B3gsRawParams* params, const 
   if (phases & 1) {
     BlendBatch batch;
     batch.n = 1;
+    batch.order = nullptr;
+    batch.order_buf = im.order;
     batch.v[0] = blend_backward_view(sx.sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, scratch + 4, scratch + 6,
                                      scratch + 9, scratch, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW,
                                      B3GS_SCRATCH_ROW);
@@ -492,6 +500,8 @@ int b3gs_backward(const B3gsScene* sc, int32_t num_rendered, const int32_t* radi
   if (num_rendered != 0) {
     BlendBatch batch;
     batch.n = 1;
+    batch.order = nullptr;
+    batch.order_buf = im.order;
     batch.v[0] = blend_backward_view(*sc, g, b, im, dL_dcolor, dL_ddepth, dL_dalpha, rows + 4, rows + 6, rows + 9, rows,
                                      B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW);
     b3gs_launch_blend_backward(batch, s);
@@ -522,6 +532,9 @@ int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_st
   hipStream_t s = (hipStream_t)stream;
   BlendBatch batch;
   batch.n = nviews;
+  batch.order = nullptr;
+  batch.order_buf = nullptr;
+  batch.cls_size = 0;
   for (int k = 0; k < nviews; k++) {
     const B3gsBlendView& bv = views[k];
     if (!bv.out_color || !bv.out_depth || !bv.out_alpha) return fail(B3GS_ERR_ARG, "%s", "NULL output image");
@@ -550,6 +563,9 @@ int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_s
   hipStream_t s = (hipStream_t)stream;
   BlendBatch batch;
   batch.n = nviews;
+  batch.order = nullptr;
+  batch.order_buf = nullptr;
+  batch.cls_size = 0;
   for (int k = 0; k < nviews; k++) {
     const B3gsBlendView& bv = views[k];
     if (!bv.dL_dcolor || !bv.scratch) return fail(B3GS_ERR_ARG, "%s", "NULL dL_dcolor / scratch");
@@ -558,6 +574,7 @@ int b3gs_blend_backward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_s
     BinView b;
     b3gs_geom_view(const_cast<char*>(bv.geometry), bv.view->P, &g);
     b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
+    if (k == 0) batch.order_buf = im.order;
     b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, bv.binning_capacity > 0 ? bv.binning_capacity : 1, &b);
     batch.v[k] = blend_backward_view(*bv.view, g, b, im, bv.dL_dcolor, bv.dL_ddepth, bv.dL_dalpha, bv.scratch + 4,
                                      bv.scratch + 6, bv.scratch + 9, bv.scratch, B3GS_SCRATCH_ROW, B3GS_SCRATCH_ROW,

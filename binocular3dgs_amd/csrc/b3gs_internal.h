@@ -17,6 +17,7 @@
 // Every sub-array starts on a 256-byte boundary.  All sizes are functions of (P), (W,H), (P,N)
 // only, so forward and backward carve identical views out of the caller's bytes.
 
+#define B3GS_MAX_FUSED_VIEWS_ 8   /* == B3GS_MAX_FUSED_VIEWS (defined below the layout helpers) */
 #define B3GS_SCRATCH_ROW 10   /* floats per Gaussian of the blend backward's per-Gaussian sums (one 40-byte row) */
 
 struct GeomView {       // sized by P
@@ -49,6 +50,8 @@ struct ImgView {        // sized by W*H
   uint32_t* n_contrib;  // [H*W]
   uint2* ranges;        // [tiles]  segment 1 of every tile list
   uint2* ranges2;       // [tiles]  segment 2 (two-round binning, see BinJob::K1); empty = (0xFFFFFFFF, 0)
+  uint32_t* tile_work;  // [tiles]  deepest list position any pixel of the tile used (forward) = the tile's backward work
+  uint32_t* order;      // [8 * (tiles + 8)]  scheduling order of a batched blend-backward launch (view 0's array is used)
   unsigned long long* open_rows;  // [grid_y * ceil(grid_x / 64)] bit x % 64 of word (y, x / 64) set: tile (x, y) still has
                         //          an unterminated pixel after segment 1 (header[3] = their number); zeroed per forward
 };
@@ -138,6 +141,8 @@ static inline size_t b3gs_img_view(char* base, int32_t W, int32_t H, ImgView* v)
   t.n_contrib = b3gs_carve<uint32_t>(cur, hw ? hw : 1);
   t.ranges = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
   t.ranges2 = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
+  t.tile_work = b3gs_carve<uint32_t>(cur, tiles ? tiles : 1);
+  t.order = b3gs_carve<uint32_t>(cur, B3GS_MAX_FUSED_VIEWS_ * (tiles + 8));
   t.open_rows = b3gs_carve<unsigned long long>(cur, (size_t)((H + B3GS_TILE - 1) / B3GS_TILE + 1) * (size_t)(((W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64));
   if (v) *v = t;
   return (size_t)(cur - base);
@@ -239,6 +244,7 @@ struct BlendView {
   const uint32_t* point_list;
   const uint2* ranges2;    // segment 2 of the tile lists (two-round binning): list position q >= len(segment 1) reads
   const uint32_t* point_list2;   //   point_list2[ranges2[tile].x + q - len1]
+  uint32_t* tile_work;     // forward: written; backward scheduling: read
   unsigned long long* open_rows;  // forward, round 0: bitmap of the tiles with an unterminated pixel (null: not wanted)
   uint32_t* open_count;    //   ... and their number (image header word 3)
   int32_t row_words;       //   64-bit words per tile row of the bitmap
@@ -263,6 +269,12 @@ struct BlendView {
 };
 struct BlendBatch {
   int32_t n;
+  // Backward only: longest-tile-first scheduling.  Workgroup b serves default block 8 * order[(b & 7) * cls_size + (b >> 3)]
+  // + (b & 7): inside every XCD class (b & 7: the tiles of one band of every view) the tiles are visited in order of
+  // decreasing work, so the launch does not end on a late long tile.  null: default order.
+  const uint32_t* order;
+  int32_t cls_size;
+  uint32_t* order_buf;     // host side: where the launcher may build the order (view 0's ImgView::order), or null
   BlendView v[B3GS_MAX_FUSED_VIEWS];
 };
 BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im);

@@ -252,6 +252,15 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
       atomicAdd(bv.open_count, 1u);
     }
   }
+  {   // the tile's backward work: the deepest list position any of its pixels used
+    __shared__ uint32_t s_work[4];
+    uint32_t m = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (lane == 0) s_work[w] = m;
+    __syncthreads();
+    if (tid == 0) bv.tile_work[tile] = max(max(s_work[0], s_work[1]), max(s_work[2], s_work[3]));
+  }
   if (inside) {
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
     final_T[pix] = T;
@@ -364,7 +373,10 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_live = 0, n_lanes = 0;
-  const BlendView bv = select_view(batch, (int)blockIdx.x);
+  // longest-tile-first inside the XCD class (BlendBatch::order); placement never affects results
+  const int bid = batch.order ? 8 * (int)batch.order[(blockIdx.x & 7u) * (unsigned)batch.cls_size + (blockIdx.x >> 3)] + (int)(blockIdx.x & 7u)
+                              : (int)blockIdx.x;
+  const BlendView bv = select_view(batch, bid);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
   const float4* __restrict__ rec = bv.rec;
   const float* __restrict__ bg = bv.bg;
@@ -378,7 +390,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   float* __restrict__ dL_dopacity = bv.dL_dopacity;
   float* __restrict__ dL_dcov3D = bv.dL_dcov3D;
   const unsigned cov_stride = bv.cov_stride;
-  const int tile = tile_of_block((int)blockIdx.x - bv.block_base, ntiles);
+  const int tile = tile_of_block(bid - bv.block_base, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -610,6 +622,51 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
     hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, false>), dim3(total), dim3(256), 0, s, batch, nullptr);
 }
 
+namespace {
+// One workgroup per XCD class c: sort the class's cls_size default positions by decreasing tile work (counting sort
+// over 256 buckets of work / max work; the order inside a bucket is arbitrary: it only schedules).
+__global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint32_t* __restrict__ order, int cls_size) {
+  __shared__ uint32_t hist[256], cursor[256], s_max[4], tmp[8];
+  const int c = (int)blockIdx.x;
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  auto work_of = [&](int q) -> uint32_t {
+    const int bid = 8 * q + c;
+    const BlendView bv = select_view(batch, bid);
+    const int tile = tile_of_block(bid - bv.block_base, bv.ntiles);
+    return tile < bv.ntiles ? bv.tile_work[tile] : 0u;
+  };
+  uint32_t m = 0;
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) m = max(m, work_of(q));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  if (lane == 0) s_max[w] = m;
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const float scale = 255.0f / (float)max(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), 1u);
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) atomicAdd(&hist[255u - (uint32_t)((float)work_of(q) * scale)], 1u);
+  __syncthreads();
+  {   // exclusive scan of the 256 bucket counts (bucket 0 = heaviest)
+    const uint32_t v = hist[threadIdx.x];
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+      if (lane >= (unsigned)d) inc += o;
+    }
+    if (lane == 63) tmp[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (unsigned k = 0; k < w; k++) base += tmp[k];
+    cursor[threadIdx.x] = base + inc - v;
+  }
+  __syncthreads();
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) {
+    const uint32_t b = 255u - (uint32_t)((float)work_of(q) * scale);
+    order[(size_t)c * cls_size + atomicAdd(&cursor[b], 1u)] = (uint32_t)q;
+  }
+}
+}  // namespace
+
 void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   int total = 0;
   for (int k = 0; k < batch.n; k++) {
@@ -617,6 +674,16 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
     total += blocks_of(batch.v[k]);
   }
   if (total <= 0) return;
+  // longest-tile-first: the order array lives in view 0's image buffer (sized for 8 views of its tile count; batches of
+  // mixed resolutions that do not fit keep the default order)
+  static const bool lpt = getenv("B3GS_NO_LPT") == nullptr;
+  uint32_t* order = batch.order_buf;
+  batch.order = nullptr;
+  batch.cls_size = total / 8;
+  if (lpt && order && (size_t)total <= (size_t)B3GS_MAX_FUSED_VIEWS * (size_t)(batch.v[0].ntiles + 8)) {
+    hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(256), 0, s, batch, order, batch.cls_size);
+    batch.order = order;
+  }
   // B3GS_BWD_TRACE=1: per-wave {cycles, wall start|end, iterations, live iterations} (tools/bwd_trace.py)
   unsigned long long* trace = getenv("B3GS_BWD_TRACE") ? trace_buffer(total) : nullptr;
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
@@ -638,6 +705,7 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.point_list = b.val[0];
   v.ranges2 = im.ranges2;      // empty unless a second binning round ran (b3gs_launch_round2_batch); segment 2 sits
   v.point_list2 = b.val[0];    // behind segment 1 in the same array, its ranges are absolute positions
+  v.tile_work = im.tile_work;
   v.open_rows = nullptr;
   v.open_count = im.header + 3;
   v.row_words = (v.grid_x + 63) / 64;
