@@ -376,15 +376,24 @@ class FusedRasterizer:
         # two rounds pay once the tile split dominates: from ~6M instances per view; segment 1 sized for ~3M of them
         self.seg1_fraction = (0.0 if need < 6_000_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
         if self._seg1_auto and self.seg1_fraction > 0.0:
-            # ... unless the scene does not saturate: every tile left open after segment 1 is blended twice and gets
-            # its whole list anyway.  One trial forward: more than a quarter of the tiles open -> one round.
-            with torch.no_grad():
-                self.render_batch([(v[0], v[1]) for v in views], bg_color)
-            torch.cuda.synchronize(self.dev)
-            tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
-            opened = sum(int(self.slots[int(v[1])].img[:16].view(torch.int32)[3]) for v in views)
-            self.open_tile_fraction = opened / max(tiles * len(views), 1)
-            if self.open_tile_fraction > 0.25:
-                self.seg1_fraction = 0.0
+            # ... unless it does not pay on THIS scene (tiles that stay open after segment 1 are blended twice and get
+            # their whole list anyway): time the forward both ways and keep the faster (a few forwards at set-up and
+            # after a densification).
+            cand, best = self.seg1_fraction, None
+            for frac_try in (0.0, cand):
+                self.seg1_fraction = frac_try
+                with torch.no_grad():
+                    for _ in range(2):
+                        self.render_batch([(v[0], v[1]) for v in views], bg_color)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        self.render_batch([(v[0], v[1]) for v in views], bg_color)
+                    e1.record()
+                torch.cuda.synchronize(self.dev)
+                ms = e0.elapsed_time(e1)
+                if best is None or ms < best[0]:
+                    best = (ms, frac_try)
+            self.seg1_fraction = best[1]
             self.high_water.zero_()
         return self.capacity
