@@ -561,3 +561,54 @@ def test_two_round_binning_equals_one_round(scene):
         for x, y in zip(grads, ref_grads):
             if y.numel():
                 assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
+
+
+@pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16)])
+def test_two_round_binning_edge_sizes(P, W, H):
+    """Two-round binning at the edges: a single tile (no tile-sort pass: the ranges of segment 2 come from tile_ranges
+    with the device-side offset), K1 = 1, fewer Gaussians than a wave, ragged borders.  Bit-identical images to one round."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    model = synth.synth_model(P, seed=P, device="cuda", width=W, height=H, requires_grad=False)
+    with torch.no_grad():
+        model._scaling += 1.0
+        model._opacity -= 2.0          # tiles stay open: the second round has work
+    pairs = synth.synth_view_set(W, H, device="cuda")
+    bg = torch.tensor([0.2, 0.1, 0.0], device="cuda")
+    views = [(pairs[0][0], 0), (pairs[0][1], 1), (pairs[1][0], 2)]
+    res = []
+    for frac in (0.0, 0.3, 0.01):
+        fr = FusedRasterizer(model, W, H, num_slots=3, seg1_fraction=frac)
+        with torch.no_grad():
+            outs = fr.render_batch(views, bg)
+        torch.cuda.synchronize()
+        assert not fr.overflowed()
+        res.append([[o[k].clone() for k in ("render", "rendered_depth", "rendered_alpha", "radii")] for o in outs])
+    for other in res[1:]:
+        for a, b in zip(other, res[0]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+
+
+def test_two_round_binning_overflow_is_detected():
+    """Segment 2 sits behind segment 1 in the same arrays: N1 + N2 above the capacity truncates the lists (no write past
+    the buffers) and shows up in the device-side N / high-water mark like a one-round overflow."""
+    from binocular3dgs_amd.fused import FusedRasterizer
+    model, pairs, bg = _setup(P=5000, W=160, H=120)
+    with torch.no_grad():
+        model._opacity -= 4.0
+    full = FusedRasterizer(model, 160, 120, num_slots=1, seg1_fraction=0.0)
+    with torch.no_grad():
+        full.render(pairs[0][0], bg, slot=0)
+    n_full = full.num_rendered()[0]
+    fr = FusedRasterizer(model, 160, 120, num_slots=1, binning_capacity=max(n_full // 2, 64), seg1_fraction=0.2)
+    with torch.no_grad():
+        out = fr.render(pairs[0][0], bg, slot=0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["render"]).all()
+    assert fr.num_rendered()[0] > fr.capacity and fr.overflowed() and fr.check_overflow() > 0
+    with torch.no_grad():
+        out2 = fr.render(pairs[0][0], bg, slot=0)
+        ref = full.render(pairs[0][0], bg, slot=0)
+    torch.cuda.synchronize()
+    assert not fr.overflowed() and torch.equal(out2["render"], ref["render"])
