@@ -77,6 +77,9 @@ def parse():
                          "Adam on flat buffers at N=1); b3gs: all-reduce + replicated one-launch Adam; torch: "
                          "torch.optim.Adam(fused=True), 12 launches")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dense-grad-rows", action="store_true",
+                    help="A/B: store the zero gradient rows of untouched Gaussians and let Adam read them (default on one "
+                         "rank: sparse rows + bitmap, step.ViewShardedStep.sparse_grad_rows)")
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
                     help="fused: b3gs_forward_raw_batch / backward (activations in-kernel, persistent scratch, no host "
                          "sync); dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
@@ -155,7 +158,8 @@ class Job:
                                     schedule="serial" if args.serial_views else args.schedule)
         self.fused = fused
         pipe_ranges = args.pipeline_ranges if dp and fused is not None and args.optimizer == "b3gs" else 0
-        kw = dict(optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges, overflow_check_every=0)
+        kw = dict(optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges, overflow_check_every=0,
+                  sparse_grad_rows=not args.dense_grad_rows)
         if scaling == "weak":
             self.stepper = ViewShardedStep(model, gp, self.bg, PipelineParams(), **kw)
         else:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("B3GS_LIB") or os.path.join(_HERE, "libb3gs_raster.so")   # B3GS_LIB: A/B builds of the kernels
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -36,7 +36,7 @@ class B3gsRawParams(C.Structure):
 
 
 class B3gsRawGrads(C.Structure):
-    _fields_ = B3gsRawParams._fields_
+    _fields_ = B3gsRawParams._fields_ + [("touched_rows", C.c_void_p)]
 
 
 class B3gsFusedView(C.Structure):
@@ -76,7 +76,7 @@ class B3gsDensifyIO(C.Structure):
 
 class B3gsAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("count", C.c_int64), ("lr", C.c_float)]
+                ("count", C.c_int64), ("lr", C.c_float), ("row_len", C.c_int32), ("first_row", C.c_int32)]
 
 
 class B3gsDensifyStats(C.Structure):
@@ -182,7 +182,7 @@ def lib():
     L.b3gs_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_knn_mean_dist2.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+                                 C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int

@@ -605,6 +605,8 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
   if (rc) return rc;
   if (v0->P == 0 || count == 0) return B3GS_OK;
   if (first < 0 || count < 0 || (int64_t)first + count > v0->P) return fail(B3GS_ERR_ARG, "%s", "bad Gaussian range");
+  if (grads->touched_rows && overwrite && (first & 63))
+    return fail(B3GS_ERR_ARG, "%s", "sparse-row gradients (touched_rows) need a range that starts at a multiple of 64");
   if (!grads->xyz || !grads->features_dc || (v0->M > 1 && !grads->features_rest) || !grads->scaling ||
       !grads->rotation || !grads->opacity)
     return fail(B3GS_ERR_ARG, "%s", "NULL gradient buffer");

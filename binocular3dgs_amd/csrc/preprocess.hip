@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(256, 8)
         ds.denom[i] += st_cnt;
         ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
       }
-      if (mask == 0u && overwrite) {   // no view has a gradient for this Gaussian: its rows of the slab are zero
+      if (mask == 0u && overwrite && !rg.touched_rows) {   // no view has a gradient for this Gaussian: its rows of the slab are zero
         rg.xyz[i3] = 0.f; rg.xyz[i3 + 1] = 0.f; rg.xyz[i3 + 2] = 0.f;
         rg.scaling[i3] = 0.f; rg.scaling[i3 + 1] = 0.f; rg.scaling[i3 + 2] = 0.f;
         reinterpret_cast<float4*>(rg.rotation)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -757,6 +757,9 @@ __global__ void __launch_bounds__(256, 8)
       }
     }
     const unsigned long long b = __ballot(mask != 0u);
+    // sparse-row slab: the bitmap word of these 64 Gaussians replaces their zero rows (first % 64 == 0: word aligned)
+    if (overwrite && rg.touched_rows && lane == 0 && blk_first + j * 256 + (int)(threadIdx.x & ~63u) < end)
+      rg.touched_rows[(size_t)(blk_first + j * 256 + (int)(threadIdx.x & ~63u)) >> 6] = b;
     if (b) {
       const int leader = __builtin_ctzll(b);
       uint32_t at = 0;

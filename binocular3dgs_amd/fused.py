@@ -247,11 +247,19 @@ class FusedRasterizer:
         else:
             self._accumulate(pend, overwrite=False)
 
-    def _accumulate(self, pend, overwrite: bool, grads=None, first: int = 0, count: Optional[int] = None):
+    def _accumulate(self, pend, overwrite: bool, grads=None, first: int = 0, count: Optional[int] = None,
+                    touched_rows: Optional[torch.Tensor] = None):
         """grads: a B3gsRawGrads whose pointers are indexed by the global Gaussian index (default: the parameters'
-        .grad); [first, first+count): the Gaussians to process (default: all)."""
+        .grad); [first, first+count): the Gaussians to process (default: all).  touched_rows (int64, ceil(P/64) words):
+        sparse-row mode of B3gsRawGrads -- rows of Gaussians without any gradient are NOT stored, their bit is clear."""
         L, m = _lib.lib(), self.model
         gr = grads if grads is not None else self._bind_grads()
+        if touched_rows is not None:
+            if not overwrite or len(pend) > MAX_BATCH:
+                raise _lib.B3gsError("sparse gradient rows need overwrite mode and at most 8 views (one accumulate call)")
+            assert touched_rows.dtype == torch.int64 and touched_rows.numel() >= (self.P + 63) // 64
+        if grads is None or touched_rows is not None:
+            gr.touched_rows = None if touched_rows is None else touched_rows.data_ptr()
         count = self.P - first if count is None else count
         stats = None
         if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
@@ -315,16 +323,20 @@ class FusedRasterizer:
         Call it for disjoint ranges covering all Gaussians."""
         self._accumulate(pend, overwrite, grads, first, count)
 
-    def finish_deferred(self, overwrite: bool = True):
-        """overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them."""
+    def finish_deferred(self, overwrite: bool = True, touched_rows: Optional[torch.Tensor] = None):
+        """overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them.  With
+        `touched_rows` (int64 bitmap, one bit per Gaussian) the rows of Gaussians that received nothing are not stored
+        at all: only a consumer that reads the bitmap (FusedAdam / ShardedAdam `row_mask`) may use the gradients."""
         pend, self._deferred = self._deferred, None
         if not pend:
             if overwrite:
                 for p in self.model.parameters():
                     if p.grad is not None:
                         p.grad.zero_()
+                if touched_rows is not None:
+                    touched_rows.fill_(-1)          # every row valid (zero)
             return
-        self._accumulate(pend, overwrite)
+        self._accumulate(pend, overwrite, touched_rows=touched_rows)
 
     def resize(self):
         """The model's Gaussian count changed (densification): re-create every slot for the new P."""

@@ -76,15 +76,19 @@ class FlatGradSlab:
         return self.flat.numel() * 4
 
 
-def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev):
-    """One b3gs_adam_step launch over [(param_ptr, grad_ptr, m_ptr, v_ptr, count, lr), ...] (at most 8)."""
+def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev, row_mask=None):
+    """One b3gs_adam_step launch over [(param_ptr, grad_ptr, m_ptr, v_ptr, count, lr[, row_len, first_row]), ...] (at
+    most 8).  row_mask: the int64 touched-rows bitmap of a sparse-row gradient slab (segments then carry row_len)."""
     from . import _lib
     segs = (_lib.B3gsAdamSegment * max(len(segs_py), 1))()
-    for k, (p, g, m, v, n, lr) in enumerate(segs_py):
+    for k, seg in enumerate(segs_py):
+        p, g, m, v, n, lr = seg[:6]
         segs[k].param, segs[k].grad, segs[k].exp_avg, segs[k].exp_avg_sq = p or None, g or None, m or None, v or None
         segs[k].count, segs[k].lr = int(n), float(lr)
+        segs[k].row_len, segs[k].first_row = (int(seg[6]), int(seg[7])) if len(seg) > 6 else (0, 0)
     rc = _lib.lib().b3gs_adam_step(len(segs_py), segs, step_count.data_ptr(), betas[0], betas[1], eps,
                                    float(opacity_decay), int(opacity_seg), int(bool(decay_first)), int(bool(bump)),
+                                   None if row_mask is None else row_mask.data_ptr(),
                                    torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "b3gs_adam_step")
 
@@ -111,11 +115,12 @@ class FusedAdam:
         self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
         self.decay_first = bool(decay_first)
 
-    def step(self):
+    def step(self, row_mask: Optional[torch.Tensor] = None):
+        """row_mask: the touched-rows bitmap of a sparse-row gradient slab (FusedRasterizer.finish_deferred)."""
         P = self.params[0].shape[0]
-        self.step_rows(0, P, [p.grad.data_ptr() for p in self.params], last=True)
+        self.step_rows(0, P, [p.grad.data_ptr() for p in self.params], last=True, row_mask=row_mask)
 
-    def step_rows(self, first: int, count: int, grad_ptrs: Sequence[int], last: bool):
+    def step_rows(self, first: int, count: int, grad_ptrs: Sequence[int], last: bool, row_mask=None):
         """Adam for rows [first, first+count) of every tensor (row = one Gaussian); grad_ptrs[k] is the address of
         the gradient of row `first` of tensor k (rows contiguous).  The step counter advances when `last`."""
         segs, off = [], 0
@@ -123,10 +128,10 @@ class FusedAdam:
             assert p.is_contiguous()
             w = p.numel() // max(p.shape[0], 1)
             segs.append((p.data_ptr() + 4 * w * first, gp, self.exp_avg.data_ptr() + 4 * (off + w * first),
-                         self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr))
+                         self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr, w, first))
             off += p.numel()
         _adam_launch(segs, self.step_count, self.betas, self.eps, self.opacity_decay, self.opacity_index,
-                     self.decay_first, last, self.params[0].device)
+                     self.decay_first, last, self.params[0].device, row_mask)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
@@ -205,10 +210,16 @@ class ShardedAdam:
         return out
 
     # ---- one optimisation step ----------------------------------------------------------------------
-    def step(self, slab: FlatGradSlab, average: bool = False):
+    def collective(self) -> bool:
+        return _dist_on() and (self.world > 1 or self.force_collective)
+
+    def step(self, slab: FlatGradSlab, average: bool = False, row_mask: Optional[torch.Tensor] = None):
+        """row_mask: touched-rows bitmap of a sparse-row slab -- only without a collective (the reduce-scatter needs
+        dense rows) and with the HIP Adam."""
         assert slab.flat.numel() == self.padded_numel, "gradient slab must be padded to ShardedAdam.padded_numel"
         lo = self.rank * self.chunk
-        collective = _dist_on() and (self.world > 1 or self.force_collective)
+        collective = self.collective()
+        assert row_mask is None or (not collective and self.adam_impl is None and self.world == 1)
         if collective:
             if self.gshard is None:
                 self.gshard = torch.zeros(self.chunk, dtype=torch.float32, device=self.pflat.device)
@@ -228,9 +239,11 @@ class ShardedAdam:
         if self.adam_impl is not None:
             self.adam_impl(segs, self.step_count, self.betas, self.eps, decay, opacity_seg, self.decay_first)
         else:
-            _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr)
-                          for p, gg, m, v, lr in segs], self.step_count, self.betas, self.eps, decay, opacity_seg,
-                         self.decay_first, True, self.pflat.device)
+            P = max(self.params[0].shape[0], 1)
+            widths = [self.params[k].numel() // P for k, _, _ in self.my_segments()]
+            _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, w, 0)
+                          for (p, gg, m, v, lr), w in zip(segs, widths)], self.step_count, self.betas, self.eps, decay,
+                         opacity_seg, self.decay_first, True, self.pflat.device, row_mask)
         if collective:
             dist.all_gather_into_tensor(self.pflat, self.pflat[lo:lo + self.chunk], group=self.group)
 
@@ -342,7 +355,8 @@ class ViewShardedStep:
 
     def __init__(self, model, pairs, bg: torch.Tensor, pipe: Optional[PipelineParams] = None, optimizer=None,
                  average_over_world: bool = False, render_fn: Callable = render, fused=None, pipeline_ranges: int = 0,
-                 group=None, _views: Optional[List[_View]] = None, overflow_check_every: int = 32):
+                 group=None, _views: Optional[List[_View]] = None, overflow_check_every: int = 32,
+                 sparse_grad_rows: bool = True):
         self.model = model
         self.pairs = list(pairs)          # [(camera, shifted_camera_or_None, trans_dist)]  (whole local pairs)
         self.bg = bg
@@ -381,6 +395,12 @@ class ViewShardedStep:
         # Adam back to back (the all-reduce of 92 B/Gaussian is ~20 % of an iteration on 8 GPUs).
         self.pipeline_ranges = int(pipeline_ranges) if (fused is not None and isinstance(optimizer, FusedAdam)) else 0
         self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges > 1 else None
+        # Sparse gradient rows (single rank, fused path, HIP Adam): ~80 % of the Gaussians receive no gradient in an
+        # iteration; their slab rows are then neither written (chain-rule pass) nor read (Adam) -- a bitmap says which
+        # rows are valid.  After such a step `p.grad` holds STALE rows: use sparse_grad_rows=False to inspect it.
+        self.sparse_grad_rows = bool(sparse_grad_rows)
+        self.touched_rows = None
+        self._row_mask = None             # bitmap of the gradients now in the slab (None = dense)
 
     @classmethod
     def from_global(cls, model, global_pairs, bg, rank: Optional[int] = None, world: Optional[int] = None, **kw):
@@ -428,17 +448,41 @@ class ViewShardedStep:
                                  f"fewer; they have been grown to {self.fused.capacity} -- repeat the steps since the "
                                  f"last check (at most {self.overflow_check_every})")
 
+    def _sparse_rows(self) -> Optional[torch.Tensor]:
+        """The touched-rows bitmap when this step may leave untouched gradient rows unwritten, else None."""
+        opt = self.optimizer
+        if not (self.sparse_grad_rows and self.fused is not None and self.range_slab is None and self.views
+                and len(self.views) <= 8):
+            return None
+        if isinstance(opt, ShardedAdam):
+            if opt.collective() or opt.adam_impl is not None or opt.world != 1:
+                return None
+        elif isinstance(opt, FusedAdam):
+            if _dist_on() and (dist.get_world_size(self.group) > 1 or self.slab.force_collective):
+                return None
+        else:
+            return None
+        words = (self.model.get_xyz.shape[0] + 63) // 64
+        if self.touched_rows is None or self.touched_rows.numel() != words:
+            self.touched_rows = torch.zeros(words, dtype=torch.int64, device=self.bg.device)
+        return self.touched_rows
+
     def reduce_and_update(self):
         """The exchange step of the data-parallel path (one collective over the flat slab) + optimiser."""
         if self.range_slab is not None:
             return self._reduce_and_update_pipelined()
+        mask, self._row_mask = self._row_mask, None
         if isinstance(self.optimizer, ShardedAdam):
             self.slab.rebind()
-            return self.optimizer.step(self.slab, average=self.average)
+            return self.optimizer.step(self.slab, average=self.average, row_mask=mask)
+        assert mask is None or isinstance(self.optimizer, FusedAdam)
         self.slab.all_reduce(self.average, self.group)
         if self.optimizer is not None:
             self.slab.rebind()
-            self.optimizer.step()
+            if mask is not None:
+                self.optimizer.step(row_mask=mask)
+            else:
+                self.optimizer.step()
 
     def densify_and_prune(self, max_grad: float, min_opacity: float, extent: float, max_screen_size=None,
                           percent_dense: float = 0.01, noise=None, generator=None, group=None) -> int:
@@ -555,7 +599,8 @@ class ViewShardedStep:
             self._update_densify_stats(pkgs)
         if self.fused is not None:
             if self.range_slab is None:
-                self.fused.finish_deferred(overwrite=True)
+                self._row_mask = self._sparse_rows()
+                self.fused.finish_deferred(overwrite=True, touched_rows=self._row_mask)
             else:   # reduce_and_update() runs the chain rule range by range
                 self._pending_views = self.fused.take_deferred()
         self.last_stats = {"views": len(self.views)}

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 4
+#define B3GS_ABI_VERSION 5
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -129,6 +129,12 @@ typedef struct B3gsRawParams {
 } B3gsRawParams;
 typedef struct B3gsRawGrads {  /* accumulated into (+=); same shapes as B3gsRawParams */
   float* xyz; float* features_dc; float* features_rest; float* scaling; float* rotation; float* opacity;
+  /* Optional sparse-row mode of b3gs_backward_raw_accumulate[_range] with overwrite != 0 (NULL = dense; ignored by
+   * every other entry point): a bitmap of ceil(P / 64) words, bit (i & 63) of word (i >> 6) = "Gaussian i received a
+   * gradient from at least one view of the call".  Rows whose bit is clear are NOT stored (most Gaussians of an
+   * iteration: ~80 % at the headline workload) -- their content is stale and only a consumer that reads the bitmap
+   * (b3gs_adam_step with row_mask) may use the buffers.  Range calls need first % 64 == 0. */
+  uint64_t* touched_rows;
 } B3gsRawGrads;
 
 /* Sync-free forward (see b3gs_forward_capacity) on raw parameters.  `view` supplies P, D, M (= total
@@ -257,10 +263,15 @@ typedef struct B3gsAdamSegment {
   float* exp_avg_sq;
   int64_t count;  /* floats */
   float lr;
+  int32_t row_len;    /* floats per Gaussian row of this tensor; only read when row_mask != NULL (0 = segment not masked) */
+  int32_t first_row;  /* Gaussian index of the segment's first float (a segment starts at a row boundary when masked) */
 } B3gsAdamSegment;
+/* `row_mask` (may be NULL): the touched_rows bitmap of B3gsRawGrads.  Element e of a segment with row_len > 0 belongs to
+ * Gaussian first_row + e / row_len; when that Gaussian's bit is clear the gradient is taken as 0 WITHOUT reading it
+ * (moments and parameter still follow Adam: same result as a dense zero gradient, 4 of 28 bytes per float less). */
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
                    float eps, float opacity_decay, int32_t opacity_segment, int32_t opacity_decay_first,
-                   int32_t bump_step_after, b3gs_stream_t stream);
+                   int32_t bump_step_after, const uint64_t* row_mask, b3gs_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------------------
  * Value and pixel gradients of the per-pair training loss of train.py:123-148 in 4 launches:

@@ -239,7 +239,8 @@ def test_pipelined_data_parallel_tail_equals_the_plain_tail():
         model.init_densification_stats()
         opt = FusedAdam(model.parameters(), [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05], eps=1e-15)
         fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
-        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, pipeline_ranges=K)
+        # (the gradients are compared below: the plain tail must leave DENSE rows in the slab)
+        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, pipeline_ranges=K, sparse_grad_rows=False)
         assert (st.range_slab is not None) == (K > 1)
         for _ in range(3):
             st.step(pair_grad_fn=fn)
@@ -433,7 +434,7 @@ def test_adam_reference_decay_order_empty_segment_and_error_text():
             assert float((p - q).abs().max()) < 5e-6 * max(1.0, float(p.abs().max()))
     seg = (_lib.B3gsAdamSegment * 1)()
     seg[0].count, seg[0].lr = 5, 1e-3          # non-empty segment with NULL pointers
-    rc = _lib.lib().b3gs_adam_step(1, seg, mine.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None)
+    rc = _lib.lib().b3gs_adam_step(1, seg, mine.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None, None)
     assert rc == -1 and b"b3gs_adam_step" in _lib.lib().b3gs_last_error()
     io = _lib.B3gsDensifyIO()
     io.P, io.M = 4, 0
@@ -612,3 +613,91 @@ def test_two_round_binning_overflow_is_detected():
         ref = full.render(pairs[0][0], bg, slot=0)
     torch.cuda.synchronize()
     assert not fr.overflowed() and torch.equal(out2["render"], ref["render"])
+
+
+@pytest.mark.parametrize("P", [4096, 5003])
+def test_adam_row_mask_skips_untouched_rows_bit_exact(P):
+    """b3gs_adam_step(row_mask): the gradient of a Gaussian whose bit is clear is 0 WITHOUT being read -- the masked-out
+    rows hold NaN here -- and the result is bit-identical to the dense step on gradients zeroed by the same mask.
+    P = 4096: every tensor 16-byte aligned (float4 kernel); P = 5003: scalar kernel, ragged last bitmap word."""
+    from binocular3dgs_amd.step import FusedAdam
+    torch.manual_seed(P)
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 3), (P, 4), (P, 1)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+    a = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    dense = FusedAdam(a, lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True)
+    sparse = FusedAdam(b, lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True)
+    for it in range(4):
+        live = torch.rand(P, device="cuda") < (0.2 if it else 0.0)           # first step: nothing touched at all
+        bits = torch.zeros(((P + 63) // 64) * 64, dtype=torch.int64, device="cuda")
+        bits[:P] = live.to(torch.int64)
+        words = (bits.view(-1, 64) << torch.arange(64, device="cuda")).sum(1)   # wraps into the sign bit: fine
+        for p, q in zip(a, b):
+            g = torch.randn_like(p) * 0.01
+            sel = live.view(-1, *([1] * (p.dim() - 1)))
+            p.grad = torch.where(sel, g, torch.zeros_like(g))
+            q.grad = torch.where(sel, g, torch.full_like(g, float("nan")))
+        dense.step()
+        sparse.step(row_mask=words)
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        assert torch.equal(p, q)
+    assert torch.equal(dense.exp_avg, sparse.exp_avg) and torch.equal(dense.exp_avg_sq, sparse.exp_avg_sq)
+    assert not any(bool(torch.isnan(q).any()) for q in b)
+
+
+@pytest.mark.parametrize("P", [9001, 9024])
+def test_sparse_gradient_rows_equal_dense_rows(P):
+    """Sparse-row gradient slab (B3gsRawGrads.touched_rows, single rank): the chain-rule pass stores only the rows of
+    Gaussians that received a gradient and a bitmap of them; Adam reads the bitmap.  (i) the stored rows equal the dense
+    pass, every skipped row is a zero row of the dense pass and keeps its sentinel; (ii) training with it gives the dense
+    run's parameters (same atomics-order tolerance as two dense runs)."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+    W, H = 160, 120
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    fn = lambda i, pkg, spkg: [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]  # noqa: E731
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+    # (i) one backward, no optimiser: dense vs sparse rows
+    rows = {}
+    for sparse in (False, True):
+        model, pairs, bg = _setup(P=P, W=W, H=H)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+        st = ViewShardedStep(model, pairs, bg, fused=fr, sparse_grad_rows=False)
+        st.slab.flat.fill_(-7.0)                                     # sentinel: a skipped row keeps it
+        st.slab.rebind()
+        words = torch.zeros((P + 63) // 64, dtype=torch.int64, device="cuda")
+        fr.begin_deferred()
+        pkgs = st._render_views()
+        outs, grads = [], []
+        for k in range(0, len(pkgs), 2):
+            for o, g in fn(k // 2, pkgs[k], pkgs[k + 1]):
+                outs.append(o)
+                grads.append(g)
+        torch.autograd.backward(outs, grads)
+        fr.finish_deferred(overwrite=True, touched_rows=words if sparse else None)
+        torch.cuda.synchronize()
+        rows[sparse] = ([p.grad.detach().clone().reshape(P, -1) for p in model.parameters()], words)
+    bit = ((rows[True][1][torch.arange(P, device="cuda") >> 6] >> (torch.arange(P, device="cuda") & 63)) & 1).bool()
+    assert 0 < int(bit.sum()) < P
+    for d, s in zip(*[r[0] for r in rows.values()]):
+        assert rel_l2(s[bit].cpu().numpy(), d[bit].cpu().numpy()) < 1e-5
+        assert float(d[~bit].abs().max()) == 0.0 and bool((s[~bit] == -7.0).all())
+    # (ii) the training step
+    res = []
+    for cls, sparse in ((FusedAdam, False), (FusedAdam, True), (ShardedAdam, True)):
+        model, pairs, bg = _setup(P=P, W=W, H=H)
+        model.init_densification_stats()
+        opt = cls(model.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, sparse_grad_rows=sparse)
+        assert (st._sparse_rows() is not None) == sparse
+        for _ in range(4):
+            st.step(pair_grad_fn=fn)
+        torch.cuda.synchronize()
+        res.append([p.detach().clone() for p in model.parameters()] + [model.denom.clone(), model.xyz_gradient_accum.clone()])
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6
