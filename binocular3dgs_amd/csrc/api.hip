@@ -388,7 +388,17 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
       if (K1 >= P) K1 = 0;
     }
   }
-  for (int k = 0; k < nviews; k++) jobs[k].K1 = K1;
+  for (int k = 0; k < nviews; k++) {
+    jobs[k].K1 = K1;
+    if (!K1) continue;
+    // the tiles the previous two-round forward into this image buffer left unterminated are predicted open now
+    pb.out[k].pred_rows = jobs[k].im.pred_rows;
+    pb.out[k].pred_next = jobs[k].im.pred_next;
+    bb.v[k].pred_rows = jobs[k].im.pred_rows;
+    bb.v[k].pred_next = jobs[k].im.pred_next;
+    const int d = views[k].depth_order_from;
+    bb.v[k].z_clear = (d >= 0 ? jobs[d].g : jobs[k].g).skey[0] + (size_t)(3 * (int64_t)K1 / 4);   // sorted depth keys
+  }
   StageTimer tm(s);
   tm.mark(-1);
   if (phases & 1) {

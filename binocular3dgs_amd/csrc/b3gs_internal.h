@@ -53,7 +53,11 @@ struct ImgView {        // sized by W*H
   uint32_t* tile_work;  // [tiles]  deepest list position any pixel of the tile used (forward) = the tile's backward work
   uint32_t* order;      // [8 * (tiles + 8)]  scheduling order of a batched blend-backward launch (view 0's array is used)
   unsigned long long* open_rows;  // [grid_y * ceil(grid_x / 64)] bit x % 64 of word (y, x / 64) set: tile (x, y) still has
-                        //          an unterminated pixel after segment 1 (header[3] = their number); zeroed per forward
+                        //          an unterminated pixel after segment 1 AND was not predicted open (header[3] = their
+                        //          number): the tiles the second binning round repairs; zeroed per forward
+  unsigned long long* pred_rows;  // same shape: tiles PREDICTED open for this forward (= the tiles the previous two-round
+                        //          forward into this buffer left unterminated): segment 1 gives them their complete list
+  unsigned long long* pred_next;  // same shape: written by this forward, becomes pred_rows of the next one
 };
 
 #ifndef B3GS_SORT_ITEMS
@@ -143,7 +147,10 @@ static inline size_t b3gs_img_view(char* base, int32_t W, int32_t H, ImgView* v)
   t.ranges2 = b3gs_carve<uint2>(cur, tiles ? tiles : 1);
   t.tile_work = b3gs_carve<uint32_t>(cur, tiles ? tiles : 1);
   t.order = b3gs_carve<uint32_t>(cur, B3GS_MAX_FUSED_VIEWS_ * (tiles + 8));
-  t.open_rows = b3gs_carve<unsigned long long>(cur, (size_t)((H + B3GS_TILE - 1) / B3GS_TILE + 1) * (size_t)(((W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64));
+  const size_t row_words = (size_t)((H + B3GS_TILE - 1) / B3GS_TILE + 1) * (size_t)(((W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64);
+  t.open_rows = b3gs_carve<unsigned long long>(cur, row_words);
+  t.pred_rows = b3gs_carve<unsigned long long>(cur, row_words);
+  t.pred_next = b3gs_carve<unsigned long long>(cur, row_words);
   if (v) *v = t;
   return (size_t)(cur - base);
 }
@@ -184,6 +191,8 @@ struct PreOut {
   uint2* ranges;
   uint2* ranges2;
   unsigned long long* open_rows;
+  unsigned long long* pred_rows;   // two-round forward only (else null): pred_rows <- pred_next, pred_next <- 0
+  unsigned long long* pred_next;
   int32_t ntiles, nrowwords;
 };
 struct PreBatch {
@@ -223,6 +232,9 @@ struct BinJob {
   // Two-round ("termination-aware") binning, fused path: K1 in (0, P) bins only the nearest K1 Gaussians of the depth
   // order first (segment 1); after the blend forward has marked the tiles whose pixels all terminated, the remaining
   // Gaussians are binned into the OTHER tiles only (segment 2, b3gs_launch_round2_batch).  0 or >= P: one round.
+  // Tiles PREDICTED open (im.pred_rows: the ones the previous forward into this image buffer left unterminated) also
+  // receive the Gaussians behind K1 in segment 1 -- their complete list in one round; segment 2 then only repairs the
+  // tiles the prediction missed (none once it has settled).  Any bitmap gives the same images: it only moves work.
   int32_t K1;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
@@ -245,8 +257,12 @@ struct BlendView {
   const uint2* ranges2;    // segment 2 of the tile lists (two-round binning): list position q >= len(segment 1) reads
   const uint32_t* point_list2;   //   point_list2[ranges2[tile].x + q - len1]
   uint32_t* tile_work;     // forward: written; backward scheduling: read
-  unsigned long long* open_rows;  // forward, round 0: bitmap of the tiles with an unterminated pixel (null: not wanted)
+  unsigned long long* open_rows;  // forward, round 0: bitmap of the unterminated tiles that were not predicted open, i.e.
+                           //   whose list is only the K1 prefix (null: not wanted)
   uint32_t* open_count;    //   ... and their number (image header word 3)
+  const unsigned long long* pred_rows;   // forward, round 0: the tiles predicted open (complete list in segment 1)
+  unsigned long long* pred_next;         //   ... and the prediction for the next forward (every unterminated tile, and the
+  const uint32_t* z_clear; //   predicted ones that needed more than the depth key *z_clear = rank 3/4 K1 of the order)
   int32_t row_words;       //   64-bit words per tile row of the bitmap
   int32_t round;           // forward: 0 = first pass over all tiles; 1 = second pass, only tiles with a segment 2
   uint32_t idx_mask;       // Gaussian index = point_list[j] & idx_mask (packed tile|index words, see b3gs_packed_idx_bits)

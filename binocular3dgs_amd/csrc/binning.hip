@@ -83,6 +83,15 @@ struct SortBatch {
   SortJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
+// A set of tiles as a bitmap: word (y, x / 64), bit x % 64 (ImgView::open_rows / pred_rows).
+struct OpenMap {
+  const unsigned long long* rows;
+  uint32_t row_words, grid_x, grid_y;
+};
+__host__ __device__ inline OpenMap open_map(const unsigned long long* rows, int W, int H) {
+  const int gx = (W + B3GS_TILE - 1) / B3GS_TILE, gy = (H + B3GS_TILE - 1) / B3GS_TILE;
+  return OpenMap{rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx, (uint32_t)gy};
+}
 struct ScanJob {
   const uint32_t* order;    // depth order (own or the donor view's)
   const uint2* rect;        // tile rectangles by Gaussian (element i at rect[i * rect_stride])
@@ -96,17 +105,14 @@ struct ScanJob {
   uint32_t* header;
   uint32_t* img_header;
   int32_t* n_out;
+  uint32_t* scount;         // two-round: instance count of every Gaussian behind K1 (its tiles predicted open), depth order
+  OpenMap pred;             // two-round: the tiles predicted open
 };
 struct ScanBatch {
-  int32_t n, P, tiles_per_chunk, nchunks;
+  int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
   ScanJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
-// The tiles still open after segment 1 as a bitmap: word (y, x / 64), bit x % 64 (ImgView::open_rows).
-struct OpenMap {
-  const unsigned long long* rows;
-  uint32_t row_words, grid_x;
-};
 struct EmitJob {
   const uint32_t* order;
   const uint32_t* soffs;
@@ -116,14 +122,16 @@ struct EmitJob {
   uint32_t n_cap;
   int32_t grid_x;
   int32_t idx_bits;
-  const uint32_t* scount;   // round 2: tiles of the rect still open (null in round 1: all tiles of the rect)
-  OpenMap open;             // round 2: the bitmap of the open tiles
+  const uint32_t* scount;   // round 2: tiles of the rect still open; round 1 of a two-round forward: tiles predicted
+                            //   open, for the Gaussians behind K1 (the others emit their whole rect)
+  OpenMap open;             // the bitmap that goes with scount
   const uint32_t* open_count;   // round 2: their number (0: nothing to emit)
   const uint32_t* off_ptr;      // round 2: device word N1: the instances go behind segment 1 in the same arrays
   const uint32_t* chunk_base;   // round 1: exclusive instance offset of every scan chunk (soffs holds the sub-block sums)
 };
 struct EmitBatch {
   int32_t n, P, first, subs;    // Gaussians [first, P) of the depth order; round 1: 256-Gaussian sub-blocks per scan chunk
+  int32_t K1;                   // round 1: Gaussians behind K1 go to the predicted-open tiles only (K1 == P: one round)
   EmitJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -144,6 +152,41 @@ struct RangeBatch {
   RangeJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
+// bits of row y inside columns [x0, x1) of 64-column block wb, shifted so that bit 0 is column max(x0, 64 wb)
+__device__ __forceinline__ unsigned long long open_bits(const OpenMap& om, uint32_t y, uint32_t wb, uint32_t x0, uint32_t x1,
+                                                        uint32_t* col0) {
+  const uint32_t lo = max(x0, wb * 64u), hi = min(x1, wb * 64u + 64u);
+  const unsigned long long m = om.rows[(size_t)y * om.row_words + wb] >> (lo & 63u);
+  *col0 = lo;
+  const uint32_t w = hi - lo;
+  return w >= 64u ? m : (m & ((1ull << w) - 1ull));
+}
+// number of open tiles inside the rect
+__device__ __forceinline__ uint32_t open_tiles(uint2 rc, const OpenMap& om) {
+  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+  if (x1 <= x0) return 0u;
+  uint32_t n = 0, c0;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) n += (uint32_t)__builtin_popcountll(open_bits(om, y, wb, x0, x1, &c0));
+  return n;
+}
+// k-th open tile of the rect in row-major order (k < open_tiles(rc))
+__device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const OpenMap& om) {
+  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
+      uint32_t c0;
+      unsigned long long m = open_bits(om, y, wb, x0, x1, &c0);
+      const uint32_t c = (uint32_t)__builtin_popcountll(m);
+      if (k < c) {
+        for (uint32_t j = 0; j < k; j++) m &= m - 1ull;
+        return y * om.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
+      }
+      k -= c;
+    }
+  return y0 * om.grid_x + x0;   // not reached
+}
+
 // ---------------------------------------------------------------------------------------------
 // scan of tiles_touched in depth order: soffs[s] = sum_{s' <= s} tiles_touched[order[s']]
 // two launches: per-chunk sums + per-256-Gaussian sub-block sums, scan of chunk sums (+ N, V to the headers); the
@@ -163,10 +206,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // One pass gathers the rects in depth order (the random access of the binning), stores them sorted, and produces the
 // chunk sums AND the sums of every 256-Gaussian sub-block (iteration r of the strided loop = sub-block r): the emission
 // kernel scans inside its own sub-block, so no per-Gaussian offset array is written or read.
-constexpr int SCAN_MAX_SUBS = 64;   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
+constexpr int SCAN_MAX_SUBS = 64;
+constexpr int SCAN_PRED_WORDS = 512;   // LDS copy of a tile bitmap (4 KB): up to 512 tile rows of <= 64 tiles, 256 of <= 128, ...   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
   __shared__ uint32_t ssub[2][4][SCAN_MAX_SUBS];
+  __shared__ unsigned long long s_pred[2][SCAN_PRED_WORDS];
   const ScanJob& job = sb.j[blockIdx.y];
   if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
   const uint32_t* __restrict__ order = job.order;
@@ -175,44 +220,103 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   uint32_t sum = 0, vis = 0, sum2 = 0, vis2 = 0;
+  // Gaussians behind segment 1 count their tiles in the predicted-open bitmap: a few dependent word loads per rect, so
+  // the bitmap (304 bytes at 800x600) is staged in LDS when it fits
+  OpenMap pa = job.pred, pb2 = job.partner >= 0 ? sb.j[job.partner].pred : job.pred;
+  if (end > (int64_t)sb.K1) {
+    const uint32_t na = pa.grid_y * pa.row_words, nb = pb2.grid_y * pb2.row_words;
+    if (na <= (uint32_t)SCAN_PRED_WORDS && nb <= (uint32_t)SCAN_PRED_WORDS) {
+      for (uint32_t k = threadIdx.x; k < na; k += SCAN_THREADS) s_pred[0][k] = pa.rows[k];
+      if (job.partner >= 0)
+        for (uint32_t k = threadIdx.x; k < nb; k += SCAN_THREADS) s_pred[1][k] = pb2.rows[k];
+      __syncthreads();
+      pa.rows = s_pred[0];
+      pb2.rows = s_pred[1];
+    }
+  }
   // tiles_touched == area of the rectangle (preprocess keeps them consistent)
+  // (sub-blocks in batches of four: the four index loads, then the four dependent rect gathers, are in flight together)
   if (job.partner >= 0) {
     const ScanJob& pj = sb.j[job.partner];
     const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
     uint2* __restrict__ sa = job.srect;
     uint2* __restrict__ sb2 = pj.srect;
-    for (int r = 0; r < subs; r++) {
-      const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
-      uint32_t ta = 0, tb = 0;
-      if (i < end) {
-        const uint4 rr = rect2[order[i]];   // the random access of the binning: one line for both views of the pair
-        const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
-        sa[i] = ra;
-        sb2[i] = rb;
-        ta = rect_area(ra);
-        tb = rect_area(rb);
+    for (int r0 = 0; r0 < subs; r0 += 4) {   // subs is a multiple of 16
+      uint32_t oi[4];
+      uint4 rr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+        oi[k] = i < end ? order[i] : 0u;
       }
-      sum += ta; vis += (ta != 0);
-      sum2 += tb; vis2 += (tb != 0);
-      const uint32_t wa = wave_sum(ta), wb = wave_sum(tb);
-      if (lane == 0) { ssub[0][w][r] = wa; ssub[1][w][r] = wb; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+        rr[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < end) rr[k] = rect2[oi[k]];   // the random access of the binning: one line for both views of the pair
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = r0 + k;
+        const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
+        uint32_t ta = 0, tb = 0;
+        if (i < end) {
+          const uint2 ra = make_uint2(rr[k].x, rr[k].y), rb = make_uint2(rr[k].z, rr[k].w);
+          sa[i] = ra;
+          sb2[i] = rb;
+          if (i < sb.K1) {
+            ta = rect_area(ra);
+            tb = rect_area(rb);
+          } else {   // behind segment 1: only the tiles predicted open
+            ta = open_tiles(ra, pa);
+            tb = open_tiles(rb, pb2);
+            job.scount[i] = ta;
+            pj.scount[i] = tb;
+          }
+        }
+        sum += ta; vis += (ta != 0);
+        sum2 += tb; vis2 += (tb != 0);
+        const uint32_t wa = wave_sum(ta), wb = wave_sum(tb);
+        if (lane == 0) { ssub[0][w][r] = wa; ssub[1][w][r] = wb; }
+      }
     }
   } else {
     const uint2* __restrict__ rect = job.rect;
     const size_t stride = (size_t)job.rect_stride;
     uint2* __restrict__ srect = job.srect;
-    for (int r = 0; r < subs; r++) {
-      const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
-      uint32_t t = 0;
-      if (i < end) {
-        const uint2 rc = rect[order[i] * stride];
-        srect[i] = rc;
-        t = rect_area(rc);
+    for (int r0 = 0; r0 < subs; r0 += 4) {
+      uint32_t oi[4];
+      uint2 rr[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+        oi[k] = i < end ? order[i] : 0u;
       }
-      sum += t;
-      vis += (t != 0);
-      const uint32_t wa = wave_sum(t);
-      if (lane == 0) ssub[0][w][r] = wa;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+        rr[k] = make_uint2(0u, 0u);
+        if (i < end) rr[k] = rect[oi[k] * stride];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int r = r0 + k;
+        const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
+        uint32_t t = 0;
+        if (i < end) {
+          srect[i] = rr[k];
+          if (i < sb.K1) {
+            t = rect_area(rr[k]);
+          } else {
+            t = open_tiles(rr[k], pa);
+            job.scount[i] = t;
+          }
+        }
+        sum += t;
+        vis += (t != 0);
+        const uint32_t wa = wave_sum(t);
+        if (lane == 0) ssub[0][w][r] = wa;
+      }
     }
   }
   uint32_t tot, tot2;
@@ -455,41 +559,6 @@ void radix_pass(SortBatch& sb, int shift, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // instance emission in depth order (wave-cooperative expansion)
 // ---------------------------------------------------------------------------------------------
-// bits of row y inside columns [x0, x1) of 64-column block wb, shifted so that bit 0 is column max(x0, 64 wb)
-__device__ __forceinline__ unsigned long long open_bits(const OpenMap& om, uint32_t y, uint32_t wb, uint32_t x0, uint32_t x1,
-                                                        uint32_t* col0) {
-  const uint32_t lo = max(x0, wb * 64u), hi = min(x1, wb * 64u + 64u);
-  const unsigned long long m = om.rows[(size_t)y * om.row_words + wb] >> (lo & 63u);
-  *col0 = lo;
-  const uint32_t w = hi - lo;
-  return w >= 64u ? m : (m & ((1ull << w) - 1ull));
-}
-// number of open tiles inside the rect
-__device__ __forceinline__ uint32_t open_tiles(uint2 rc, const OpenMap& om) {
-  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-  if (x1 <= x0) return 0u;
-  uint32_t n = 0, c0;
-  for (uint32_t y = y0; y < y1; y++)
-    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) n += (uint32_t)__builtin_popcountll(open_bits(om, y, wb, x0, x1, &c0));
-  return n;
-}
-// k-th open tile of the rect in row-major order (k < open_tiles(rc))
-__device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const OpenMap& om) {
-  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-  for (uint32_t y = y0; y < y1; y++)
-    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
-      uint32_t c0;
-      unsigned long long m = open_bits(om, y, wb, x0, x1, &c0);
-      const uint32_t c = (uint32_t)__builtin_popcountll(m);
-      if (k < c) {
-        for (uint32_t j = 0; j < k; j++) m &= m - 1ull;
-        return y * om.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
-      }
-      k -= c;
-    }
-  return y0 * om.grid_x + x0;   // not reached
-}
-
 template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ uint32_t s_end[4][64];
@@ -510,11 +579,20 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     if (s < P) cnt = job.scount[s];
     if (__ballot(cnt != 0) == 0) return;
   }
+  if (!ROUND2 && job.soffs[blockIdx.x] == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
   if (s < P) {
-    gid = job.order[s];
-    rc = job.srect[s];
-    if (!ROUND2) cnt = rect_area(rc);
-    else end = job.soffs[s];
+    if (ROUND2) {
+      gid = job.order[s];
+      rc = job.srect[s];
+      end = job.soffs[s];
+    } else if (s < eb.K1) {
+      gid = job.order[s];
+      rc = job.srect[s];
+      cnt = rect_area(rc);
+    } else if ((cnt = job.scount[s]) != 0u) {   // behind segment 1: almost every count is zero (4 bytes instead of 16)
+      gid = job.order[s];
+      rc = job.srect[s];
+    }
   }
   if (!ROUND2) {
     // inclusive end of every Gaussian's instance run: offset of this 256-Gaussian sub-block (chunk base + the sums of
@@ -535,6 +613,29 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
 
   const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu;
   const uint32_t rw = x1 - x0;
+  if (!ROUND2 && (int)(blockIdx.x * 256 + w * 64) >= eb.K1) {
+    // a wave behind segment 1 of a two-round forward: a handful of its Gaussians reach a predicted-open tile, a few
+    // instances each -- every lane walks its own rect over the bitmap (no cooperative expansion, no search)
+    if (cnt != 0u) {
+      uint32_t pos = end - cnt;
+      const uint32_t y1 = rc.y >> 16;
+      for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
+          uint32_t c0;
+          unsigned long long m = open_bits(job.open, y, wb, x0, x1, &c0);
+          while (m) {
+            const uint32_t tile = y * job.open.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            if (pos < n_cap) {
+              if (idx_out) { tile_out[pos] = tile; idx_out[pos] = gid; }
+              else tile_out[pos] = (tile << job.idx_bits) | gid;
+            }
+            pos++;
+          }
+        }
+    }
+    return;
+  }
   for (uint32_t j0 = wave_begin; wave_active && j0 < wave_end; j0 += 64) {
     const uint32_t j = j0 + lane;
     // smallest src with s_end[src] > j
@@ -548,15 +649,17 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     const uint32_t src_cnt = __shfl(cnt, (int)lo, 64);
     const uint32_t src_gid = __shfl(gid, (int)lo, 64);
     const uint32_t src_x0 = __shfl(x0, (int)lo, 64), src_y0 = __shfl(y0, (int)lo, 64), src_rw = __shfl(rw, (int)lo, 64);
+    // the source lies behind segment 1 of a two-round forward: its instances are the predicted-open tiles of its rect
+    const bool masked = ROUND2 || (int)(blockIdx.x * 256 + w * 64 + lo) >= eb.K1;
     uint2 src_rc = make_uint2(0u, 0u);
-    if (ROUND2) {
+    if (ROUND2 || (int)(blockIdx.x * 256 + w * 64 + 63) >= eb.K1) {   // (wave-uniform)
       src_rc.x = __shfl(rc.x, (int)lo, 64);
       src_rc.y = __shfl(rc.y, (int)lo, 64);
     }
     if (j < wave_end && j < n_cap) {
       const uint32_t k = j - (src_end - src_cnt);
       uint32_t tile;
-      if (ROUND2) {
+      if (masked) {
         tile = kth_open_tile(src_rc, k, job.open);
       } else {
         const uint32_t ry = k / src_rw, rx = k - ry * src_rw;
@@ -577,11 +680,7 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
 // tiles that segment 1 did not finish
 // ---------------------------------------------------------------------------------------------
 struct Scan2Job {
-  const uint32_t* order;
-  const uint2* rect;
-  int32_t rect_stride;
-  int32_t partner;          // as ScanJob::partner: >= 0 gathers both views of a binocular pair with one 16-byte load
-  uint2* srect;
+  const uint2* srect;       // rects in depth order (written for all P Gaussians by the first scan)
   uint32_t* scount;
   uint32_t* soffs;
   uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
@@ -598,50 +697,21 @@ struct Scan2Batch {
 __global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_sums(Scan2Batch sb) {
   __shared__ uint32_t tmp[8];
   const Scan2Job& job = sb.j[blockIdx.y];
-  if (job.partner == -2) return;
-  {   // no tile left open (in either view of a pair): segment 2 is empty, the chunk sum is all that is needed
-    const bool none = job.img_header[3] == 0u && (job.partner < 0 || sb.j[job.partner].img_header[3] == 0u);
-    if (none) {
-      if (threadIdx.x == 0) {
-        job.chunk_sums[blockIdx.x] = 0u;
-        if (job.partner >= 0) sb.j[job.partner].chunk_sums[blockIdx.x] = 0u;
-      }
-      return;
-    }
+  if (job.img_header[3] == 0u) {   // no tile to repair: segment 2 is empty, the chunk sum is all that is needed
+    if (threadIdx.x == 0) job.chunk_sums[blockIdx.x] = 0u;
+    return;
   }
-  const uint32_t* __restrict__ order = job.order;
   const int64_t begin = (int64_t)sb.K1 + (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
-  uint32_t sum = 0, sum2 = 0;
-  if (job.partner >= 0) {
-    const Scan2Job& pj = sb.j[job.partner];
-    const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
-    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-      const uint4 rr = rect2[order[i]];
-      const uint2 ra = make_uint2(rr.x, rr.y), rb = make_uint2(rr.z, rr.w);
-      const uint32_t ta = open_tiles(ra, job.open), tb = open_tiles(rb, pj.open);
-      job.srect[i] = ra; job.scount[i] = ta;
-      pj.srect[i] = rb; pj.scount[i] = tb;
-      sum += ta;
-      sum2 += tb;
-    }
-  } else {
-    const uint2* __restrict__ rect = job.rect;
-    const size_t stride = (size_t)job.rect_stride;
-    for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-      const uint2 rc = rect[order[i] * stride];
-      const uint32_t t = open_tiles(rc, job.open);
-      job.srect[i] = rc; job.scount[i] = t;
-      sum += t;
-    }
+  uint32_t sum = 0;
+  for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
+    const uint32_t t = open_tiles(job.srect[i], job.open);
+    job.scount[i] = t;
+    sum += t;
   }
   uint32_t tot;
   block_excl_scan_256(sum, tmp, &tot);
   if (threadIdx.x == 0) job.chunk_sums[blockIdx.x] = tot;
-  if (job.partner >= 0) {
-    block_excl_scan_256(sum2, tmp, &tot);
-    if (threadIdx.x == 0) sb.j[job.partner].chunk_sums[blockIdx.x] = tot;
-  }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_offsets(Scan2Batch sb) {
@@ -793,10 +863,11 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
 
   // ---- 2. scan of tiles_touched in depth order -> soffs, N, V (segment 1 = the first K1 Gaussians of the order)
   const int K1 = b3gs_seg1_count(jobs[0], P);
-  const int total_tiles = (K1 + SCAN_TILE - 1) / SCAN_TILE;
+  const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
   ScanBatch sc;
   sc.n = nviews;
-  sc.P = K1;
+  sc.P = P;
+  sc.K1 = K1;
   sc.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
@@ -804,7 +875,8 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
     const int32_t rstride = jb.rect ? jb.rect_stride : 1;
     sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
-                      jb.g.header, jb.im.header, jb.n_out};
+                      jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
+                      open_map(jb.im.pred_rows, jb.W, jb.H)};
   }
   // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
   // into d's gather
@@ -844,10 +916,11 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   const int K1 = b3gs_seg1_count(jobs[0], P);
   EmitBatch eb;
   eb.n = nviews;
-  eb.P = K1;
+  eb.P = P;
+  eb.K1 = K1;
   eb.first = 0;
   {   // the chunking of b3gs_launch_depth_order_batch's scan
-    const int total_tiles = (K1 + SCAN_TILE - 1) / SCAN_TILE;
+    const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
     eb.subs = ((total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS) * SCAN_ITEMS;
   }
   SortBatch tb;
@@ -861,23 +934,24 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
     max_cap = n_cap > max_cap ? n_cap : max_cap;
     const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
     const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
+    const OpenMap pm = open_map(jb.im.pred_rows, jb.W, jb.H);
     if (idx_bits >= 0) {
       // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
       // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
       // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr, jb.g.scan_tmp};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits, nullptr};
     } else {
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, nullptr, OpenMap{nullptr, 0u, 0u}, nullptr, nullptr, jb.g.scan_tmp};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0, nullptr};
     }
   }
   if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
-  hipLaunchKernelGGL(emit_instances<false>, dim3((K1 + 255) / 256, nviews), dim3(256), 0, s, eb);
+  hipLaunchKernelGGL(emit_instances<false>, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
   for (int p = 0; p < passes; p++) {
@@ -912,19 +986,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
-    const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
-    const int32_t rstride = jb.rect ? jb.rect_stride : 1;
-    const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
-    sc.j[v] = Scan2Job{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp,
-                       jb.g.header, jb.im.header, jb.n_out, OpenMap{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx}};
-  }
-  for (int v = 0; v < nviews; v++) {
-    const int d = jobs[v].order_from;
-    if (d < 0 || sc.j[d].partner != -1 || sc.j[v].rect_stride != 2 || sc.j[d].rect_stride != 2 ||
-        sc.j[v].rect != sc.j[d].rect + 1)
-      continue;
-    sc.j[d].partner = v;
-    sc.j[v].partner = -2;
+    sc.j[v] = Scan2Job{jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp, jb.g.header, jb.im.header, jb.n_out,
+                       open_map(jb.im.open_rows, jb.W, jb.H)};
   }
   hipLaunchKernelGGL(scan2_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
   hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
@@ -936,6 +999,7 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   EmitBatch eb;
   eb.n = nviews;
   eb.P = P;
+  eb.K1 = P;
   eb.first = K1;
   eb.subs = 1;
   SortBatch tb;
@@ -949,7 +1013,7 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     max_cap = n_cap > max_cap ? n_cap : max_cap;
     const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
     const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
-    const OpenMap om{jb.im.open_rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx};
+    const OpenMap om = open_map(jb.im.open_rows, jb.W, jb.H);
     if (idx_bits >= 0) {
       eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits,
                         jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr};

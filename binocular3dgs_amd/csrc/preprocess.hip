@@ -196,7 +196,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
       pb.out[v].ranges2[i] = make_uint2(0xFFFFFFFFu, 0u);
     }
   for (int v = 0; v < pb.n; v++)
-    if (i < pb.out[v].nrowwords) pb.out[v].open_rows[i] = 0ull;
+    if (i < pb.out[v].nrowwords) {
+      pb.out[v].open_rows[i] = 0ull;
+      if (pb.out[v].pred_rows) {   // two-round forward: the tiles the previous forward left unterminated are predicted open
+        pb.out[v].pred_rows[i] = pb.out[v].pred_next[i];
+        pb.out[v].pred_next[i] = 0ull;
+      }
+    }
   if (i >= pb.sc[0].P) return;
   // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
   // scale modifier), activated opacity
@@ -877,6 +883,8 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.ranges = im.ranges;
   o.ranges2 = im.ranges2;
   o.open_rows = im.open_rows;
+  o.pred_rows = nullptr;   // set by the two-round forward (b3gs_forward_raw_batch)
+  o.pred_next = nullptr;
   o.nrowwords = ((sc.H + B3GS_TILE - 1) / B3GS_TILE) * (((sc.W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64);
   o.ntiles = ((sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   return o;

@@ -245,13 +245,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
       if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
     }
   }
-  if (bv.round == 0 && bv.open_rows != nullptr) {   // (all threads of the workgroup are still here: no early return above)
-    const int all_done = __syncthreads_and(Tw == 0.0f);
-    if (tid == 0 && !all_done) {   // an unterminated pixel: the tile stays open for the second binning round
-      atomicOr(&bv.open_rows[(size_t)tile_y * bv.row_words + (tile_x >> 6)], 1ull << (tile_x & 63));
-      atomicAdd(bv.open_count, 1u);
-    }
-  }
+  // (all threads of the workgroup are still here: no early return above)
+  const int all_done = (bv.round == 0 && bv.open_rows != nullptr) ? __syncthreads_and(Tw == 0.0f) : 1;
   {   // the tile's backward work: the deepest list position any of its pixels used
     __shared__ uint32_t s_work[4];
     uint32_t m = last_contributor;
@@ -259,7 +254,31 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     if (lane == 0) s_work[w] = m;
     __syncthreads();
-    if (tid == 0) bv.tile_work[tile] = max(max(s_work[0], s_work[1]), max(s_work[2], s_work[3]));
+    if (tid == 0) {
+      const uint32_t work = max(max(s_work[0], s_work[1]), max(s_work[2], s_work[3]));
+      bv.tile_work[tile] = work;
+      if (bv.round == 0 && bv.open_rows != nullptr) {   // two-round forward
+        const size_t word = (size_t)tile_y * bv.row_words + (tile_x >> 6);
+        const unsigned long long bit = 1ull << (tile_x & 63);
+        const bool predicted = bv.pred_rows && (bv.pred_rows[word] & bit);
+        if (!all_done) {
+          // an unterminated pixel: with the K1 prefix only, the tile is open for the second binning round; with its
+          // complete list (predicted open) it is simply finished.  Either way it is predicted open next time.
+          if (!predicted) {
+            atomicOr(&bv.open_rows[word], bit);
+            atomicAdd(bv.open_count, 1u);
+          }
+          if (bv.pred_next) atomicOr(&bv.pred_next[word], bit);
+        } else if (predicted && bv.pred_next && work > 0u) {
+          // terminated with the complete list: keep predicting it open unless the deepest Gaussian it used lies well
+          // inside segment 1 (depth key below the one at rank 3/4 K1: hysteresis against repairing every other step)
+          const uint32_t wq = work - 1u;
+          const uint32_t lw = wq < tl.len1 ? tl.list1[tl.first1 + wq] : tl.list2[tl.first2 + (wq - tl.len1)];
+          const float zdeep = reinterpret_cast<const float*>(rec + 4 * (size_t)(lw & bv.idx_mask) + 2)[1];
+          if (!(__float_as_uint(zdeep) < *bv.z_clear)) atomicOr(&bv.pred_next[word], bit);
+        }
+      }
+    }
   }
   if (inside) {
     const size_t pix = (size_t)py * W + px, hw = (size_t)H * W;
@@ -707,6 +726,9 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.point_list2 = b.val[0];    // behind segment 1 in the same array, its ranges are absolute positions
   v.tile_work = im.tile_work;
   v.open_rows = nullptr;
+  v.pred_rows = nullptr;
+  v.pred_next = nullptr;
+  v.z_clear = nullptr;
   v.open_count = im.header + 3;
   v.row_words = (v.grid_x + 63) / 64;
   v.round = 0;

@@ -38,7 +38,9 @@ class _Slot:
         u8 = dict(dtype=torch.uint8, device=dev)
         self.geom = torch.empty(L.b3gs_geometry_bytes(P), **u8)
         self.binning = torch.empty(L.b3gs_binning_bytes(P, capacity), **u8)
-        self.img = torch.empty(L.b3gs_image_bytes(W, H), **u8)
+        # zeroed: the image buffer carries the open-tile prediction of two-round binning from one forward to the next
+        # (any content is safe -- the prediction only moves work between the binning rounds -- but zero is deterministic)
+        self.img = torch.zeros(L.b3gs_image_bytes(W, H), **u8)
         self.capacity = capacity
         f = dict(dtype=torch.float32, device=dev)
         self.color = torch.empty((3, H, W), **f)
@@ -385,17 +387,18 @@ class FusedRasterizer:
         self.high_water.zero_()
         if need * margin > self.capacity:
             self.grow(factor=margin, need=need)
-        # two rounds pay once the tile split dominates: from ~6M instances per view; segment 1 sized for ~3M of them
-        self.seg1_fraction = (0.0 if need < 6_000_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
+        # two rounds: the nearest fraction of the depth order everywhere + the rest into the tiles predicted open
+        # (the ones the previous forward of that slot left unterminated); segment 1 sized for ~0.75M instances of a view
+        self.seg1_fraction = (0.0 if need < 200_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
         if self._seg1_auto and self.seg1_fraction > 0.0:
-            # ... unless it does not pay on THIS scene (tiles that stay open after segment 1 are blended twice and get
-            # their whole list anyway): time the forward both ways and keep the faster (a few forwards at set-up and
-            # after a densification).
+            # ... unless it does not pay on THIS scene (few tiles terminate, or the views of a slot change so much that
+            # the prediction keeps missing): time the forward both ways -- prediction settled: three warm-up forwards --
+            # and keep the faster (a few forwards at set-up and after a densification).
             cand, best = self.seg1_fraction, None
             for frac_try in (0.0, cand):
                 self.seg1_fraction = frac_try
                 with torch.no_grad():
-                    for _ in range(2):
+                    for _ in range(3):
                         self.render_batch([(v[0], v[1]) for v in views], bg_color)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()

@@ -171,7 +171,12 @@ typedef struct B3gsForwardView {
    * all terminated inside it (T < 1e-4: nothing behind can contribute), and the remaining Gaussians are binned into the
    * OTHER tiles only (segment 2), which are then blended again over segment 1 + segment 2.  Images, n_contrib-relative
    * gradients and the order inside every list are those of one-round binning; only the instances no pixel could have
-   * reached are never emitted or sorted.  0 or >= 1: one round.  All views of a batch use views[0]'s value. */
+   * reached are never emitted or sorted.  0 or >= 1: one round.  All views of a batch use views[0]'s value.
+   * The `image` buffer carries a prediction from one two-round forward to the next one into the SAME buffer: the tiles
+   * left unterminated are predicted open and receive their complete list in segment 1 (then nothing is left for segment
+   * 2 on a settled scene).  Any buffer content is valid -- the prediction only moves work between the rounds, the
+   * results do not depend on it -- but a caller that wants the saving keeps one image buffer per camera (and zeroes a
+   * fresh one). */
   float seg1_fraction;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,

@@ -506,7 +506,8 @@ def test_step_detects_binning_overflow_and_grows():
 
 @pytest.mark.parametrize("scene", ["dense", "thin"])
 def test_two_round_binning_equals_one_round(scene):
-    """Termination-aware binning (B3gsForwardView.seg1_fraction): bin the nearest fraction of the depth order, blend, bin
+    """Termination-aware binning (B3gsForwardView.seg1_fraction): bin the nearest fraction of the depth order (plus, into the
+    tiles predicted open -- the ones the previous forward of the slot left unterminated -- everything behind it), blend, bin
     the rest only into the tiles that are not finished, blend those again.  Every pixel walks the same list prefix in the
     same order as with one-round binning, so images, final_T and n_contrib are BIT-identical and the gradients equal up
     to the order of the fp32 atomics -- for any fraction, including ones so small that almost every tile needs the second
@@ -525,43 +526,54 @@ def test_two_round_binning_equals_one_round(scene):
     for i, (cam, scam, _t) in enumerate(pairs):
         views += [(cam, 2 * i, True), (scam, 2 * i + 1, False)]
 
-    def run(frac):
+    # the same cameras on other slots: the open-tile prediction a slot carries over then comes from a DIFFERENT view
+    rot = [(views[(k + 2) % len(views)][0], views[k][1], views[(k + 2) % len(views)][2]) for k in range(len(views))]
+
+    def one(fr, vs):
         model.init_densification_stats()
-        fr = FusedRasterizer(model, W, H, num_slots=len(views), seg1_fraction=frac)
-        fr.fit_capacity(views, bg)
         for p in model.parameters():
             p.grad = torch.zeros_like(p)
-        outs = fr.render_batch(views, bg)
+        outs = fr.render_batch(vs, bg)
         o, g = [], []
-        for k, x in enumerate(outs):
+        for x, v in zip(outs, vs):
             o.append(x["render"]); g.append(gc)
-            if k % 2 == 0:
+            if v[2]:
                 o += [x["rendered_depth"], x["rendered_alpha"]]; g += [gd, ga]
         torch.autograd.backward(o, g)
         torch.cuda.synchronize()
         assert not fr.overflowed()
         imgs = [[x[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha")] for x in outs]
-        st = [state_views(P, W, H, fr.capacity, s.geom, s.binning, s.img) for s in fr.slots]
+        st = [state_views(P, W, H, fr.capacity, fr.slots[v[1]].geom, fr.slots[v[1]].binning, fr.slots[v[1]].img) for v in vs]
         aux = [(v["final_T"].clone(), v["n_contrib"].clone(), int(v["counts"][0]), int(v["counts"][2])) for v in st]
-        return imgs, aux, [p.grad.clone() for p in model.parameters()], model.denom.clone(), fr.num_rendered()
+        n = fr.num_rendered()
+        return imgs, aux, [p.grad.clone() for p in model.parameters()], model.denom.clone(), [n[v[1]] for v in vs]
 
-    ref_imgs, ref_aux, ref_grads, ref_denom, ref_n = run(0.0)
-    assert all(a[3] == 0 for a in ref_aux)
+    def run(frac):
+        fr = FusedRasterizer(model, W, H, num_slots=len(views), seg1_fraction=frac)
+        fr.fit_capacity(views, bg)
+        # first forward: no prediction yet, every unterminated tile is repaired by the second round; second forward:
+        # those tiles are predicted open and get their complete list in round 1; third: the prediction of another view
+        return one(fr, views), one(fr, views), one(fr, rot)
+
+    ref = run(0.0)
+    assert all(a[3] == 0 for r in ref for a in r[1])
     for frac in (0.5, 0.125, 0.01):
-        imgs, aux, grads, denom, n = run(frac)
-        second = sum(a[3] for a in aux)
+        got = run(frac)
+        second = [sum(a[3] for a in r[1]) for r in got]
         if frac == 0.01 or scene == "thin":
-            assert second > 0, "the second round must have had work"
-        for (a, b) in zip(imgs, ref_imgs):
-            for x, y in zip(a, b):
-                assert torch.equal(x, y)
-        for a, b, nn, rn in zip(aux, ref_aux, n, ref_n):
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-            assert nn == a[2] + a[3] <= rn          # never more instances than one-round binning
-        assert torch.equal(denom, ref_denom)
-        for x, y in zip(grads, ref_grads):
-            if y.numel():
-                assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
+            assert second[0] > 0, "the second round must have had work"
+            assert second[1] == 0, "same view again: every open tile was predicted, nothing left to repair"
+        for (imgs, aux, grads, denom, n), (ref_imgs, ref_aux, ref_grads, ref_denom, ref_n) in zip(got, ref):
+            for (a, b) in zip(imgs, ref_imgs):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y)
+            for a, b, nn, rn in zip(aux, ref_aux, n, ref_n):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+                assert nn == a[2] + a[3] <= rn          # never more instances than one-round binning
+            assert torch.equal(denom, ref_denom)
+            for x, y in zip(grads, ref_grads):
+                if y.numel():
+                    assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
 
 
 @pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16)])
