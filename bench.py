@@ -111,7 +111,7 @@ class Job:
     """One workload on this rank: model, view set, step object, optional HIP graph."""
 
     def __init__(self, args, dev, rank, world, dp, P, W, H, fov, views, scaling, path="fused", graph=True, loss="synthetic",
-                 scale_mult=1.0):
+                 scale_mult=1.0, seg1_fraction="auto"):
         from binocular3dgs_amd import synth
         from binocular3dgs_amd.render import PipelineParams
         from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
@@ -155,7 +155,7 @@ class Job:
             # materialised unless asked for
             model.init_densification_stats()
             fused = FusedRasterizer(model, W, H, num_slots=max(local_views, 1), want_means2D=bool(args.viewspace_grads),
-                                    schedule="serial" if args.serial_views else args.schedule)
+                                    schedule="serial" if args.serial_views else args.schedule, seg1_fraction=seg1_fraction)
         self.fused = fused
         pipe_ranges = args.pipeline_ranges if dp and fused is not None and args.optimizer == "b3gs" else 0
         kw = dict(optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges, overflow_check_every=0,
@@ -494,6 +494,22 @@ def main():
                                                 round((44.0 * inst + 28.0 * W * H * 6) / (msh["render_bwd"] * 6 / 1e3) / 1e9, 1)),
                 "config": "the headline workload with scale_mult = 3 (median splat 0.06 instead of 0.02): same 1M Gaussians, "
                           "800x600, 6 views"}
+            del j
+            torch.cuda.empty_cache()
+            # the headline workload with two-round binning switched on (the automatic choice considers two rounds
+            # from 6M instances per view on: below, the gain is within the noise of its timing probe): same images and gradients, ~70 % fewer instances emitted / sorted
+            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", seg1_fraction=0.125)
+            j.prepare(max(args.warmup, 3))
+            k2 = min(args.steps, 10)
+            el = j.timed(k2)
+            ms2, inst2 = j.kernel_times(k2)
+            extras["headline_two_round_binning"] = {
+                "iters_per_s": round(k2 / el, 2), "ms_per_step": round(el / k2 * 1e3, 3), "steps": k2, "seg1_fraction": 0.125,
+                "instances_emitted_per_view": None if inst2 is None else int(inst2 / 6),
+                "stage_ms_per_view": {k_: round(v_, 4) for k_, v_ in ms2.items()},
+                "what": "B3gsForwardView.seg1_fraction = 1/8 with open-tile prediction; the blend kernels walk the same list "
+                        "prefixes as with one round (bit-identical images), so `roofline` above -- bytes per instance HANDED "
+                        "to the blend backward -- would read lower here for the same kernel time"}
             del j
             torch.cuda.empty_cache()
             dargs = argparse.Namespace(**vars(args))

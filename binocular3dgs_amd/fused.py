@@ -111,10 +111,16 @@ class FusedRasterizer:
         self._want_m2d = want_means2D
         # Two-round binning (schedule "batched"): bin the nearest seg1_fraction of the depth order, blend, bin the rest
         # only into the tiles that are not finished (B3gsForwardView.seg1_fraction; 0 or >= 1: one round).  It removes
-        # the emission and the tile split of every instance behind a tile's saturation point at the price of ~12 more
-        # (mostly idle) launches and a second, short blend pass: measured on MI355X it breaks even at 4.8M instances
-        # per view (1M Gaussians, 800x600: 504 vs 500-503 iters/s), loses 5 % at 2.4M and wins 32-45 % at 25M (3x larger
-        # splats: 291 -> 382-422 iters/s).  "auto": decided from the measured N whenever fit_capacity() runs.
+        # the emission and the tile split of every instance behind a tile's saturation point at the price of ~11 more
+        # launches (idle once the open-tile prediction has settled: the tiles a slot's previous forward left unterminated
+        # get their complete list in round 1).  Measured on MI355X: +3 % at 4.8M instances per view (1M Gaussians,
+        # 800x600: 559-563 vs 543-549 iters/s), +9 % over the pre-prediction two-round version at 3x larger splats
+        # (435 -> 475).  "auto", whenever fit_capacity() runs: from `two_round_min_instances` per view on, the forward is
+        # timed both ways and two rounds must win by `two_round_margin`.  The threshold keeps the choice deterministic
+        # where the gain is within the timing noise of a short eager probe (the headline workload: +3...5 % of an
+        # iteration; set seg1_fraction=0.125 to have it anyway -- bench.py reports it as extras.headline_two_round_binning).
+        self.two_round_min_instances = 6_000_000
+        self.two_round_margin = 0.05
         self._seg1_auto = seg1_fraction == "auto"
         self.seg1_fraction = 0.0 if self._seg1_auto else float(seg1_fraction)
         # N of every slot's last forward lives on the device (no read-back per view); `high_water` keeps the largest N
@@ -389,7 +395,8 @@ class FusedRasterizer:
             self.grow(factor=margin, need=need)
         # two rounds: the nearest fraction of the depth order everywhere + the rest into the tiles predicted open
         # (the ones the previous forward of that slot left unterminated); segment 1 sized for ~0.75M instances of a view
-        self.seg1_fraction = (0.0 if need < 200_000 else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
+        self.seg1_fraction = (0.0 if need < self.two_round_min_instances else min(0.125, max(0.02, 0.75e6 / need))) \
+            if self._seg1_auto else frac
         if self._seg1_auto and self.seg1_fraction > 0.0:
             # ... unless it does not pay on THIS scene (few tiles terminate, or the views of a slot change so much that
             # the prediction keeps missing): time the forward both ways -- prediction settled: three warm-up forwards --
@@ -407,7 +414,9 @@ class FusedRasterizer:
                     e1.record()
                 torch.cuda.synchronize(self.dev)
                 ms = e0.elapsed_time(e1)
-                if best is None or ms < best[0]:
+                # two rounds carry state (the prediction) and ~11 more launches: they must beat one round's forward by
+                # a margin, else the simpler pipeline stays
+                if best is None or ms < best[0] * (1.0 - self.two_round_margin):
                     best = (ms, frac_try)
             self.seg1_fraction = best[1]
             self.high_water.zero_()
