@@ -430,7 +430,9 @@ __global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
 
 // HAS_VAL = false: keys only (packed tile|index words): no value staging buffer, 22 KB instead of 38 KB of LDS
 // per workgroup (7 instead of 4 workgroups per CU)
-template <bool HAS_VAL>
+// BITS: significant bits of this pass's digit (the last tile-split pass sees only the top bits of the tile id: 3 at
+// 800x600) -- the ballot ranking costs one round per bit
+template <bool HAS_VAL, int BITS>
 __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int pass_shift) {
   __shared__ uint32_t wave_cnt[4][256];
   __shared__ uint32_t blk_start[256];  // first slot of digit d inside this workgroup's reorder buffer
@@ -478,7 +480,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
     const uint32_t d = (key[r] >> shift) & 0xFF;
     u64 m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < BITS; b++) {
       const bool bit = (d >> b) & 1u;
       const u64 bal = __ballot(bit);
       m &= bit ? bal : ~bal;
@@ -544,7 +546,14 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
 }
 
 // one pass over all jobs; swaps every job's in/out buffers afterwards (vin becomes non-null)
-void radix_pass(SortBatch& sb, int shift, hipStream_t s) {
+template <int BITS>
+void launch_scatter(const SortBatch& sb, bool any_val, uint32_t max_blk, int shift, hipStream_t s) {
+  if (any_val) hipLaunchKernelGGL((radix_scatter<true, BITS>), dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
+  else hipLaunchKernelGGL((radix_scatter<false, BITS>), dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
+}
+
+// `bits`: how many bits of the digit at `shift` can be non-zero in any key of the batch (8 unless the caller knows)
+void radix_pass(SortBatch& sb, int shift, hipStream_t s, int bits = 8) {
   uint32_t max_blk = 0;
   for (int k = 0; k < sb.n; k++) max_blk = sb.j[k].nblk > max_blk ? sb.j[k].nblk : max_blk;
   if (sb.n <= 0 || max_blk == 0) return;
@@ -552,8 +561,10 @@ void radix_pass(SortBatch& sb, int shift, hipStream_t s) {
   hipLaunchKernelGGL(radix_rowscan, dim3(256, sb.n), dim3(256), 0, s, sb);
   bool any_val = false;
   for (int k = 0; k < sb.n; k++) any_val = any_val || sb.j[k].vout != nullptr;
-  if (any_val) hipLaunchKernelGGL(radix_scatter<true>, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
-  else hipLaunchKernelGGL(radix_scatter<false>, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift);
+  if (bits <= 2) launch_scatter<2>(sb, any_val, max_blk, shift, s);
+  else if (bits <= 4) launch_scatter<4>(sb, any_val, max_blk, shift, s);
+  else if (bits <= 6) launch_scatter<6>(sb, any_val, max_blk, shift, s);
+  else launch_scatter<8>(sb, any_val, max_blk, shift, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -954,10 +965,12 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   hipLaunchKernelGGL(emit_instances<false>, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
+  int tbits = 0;
+  for (int v = 0; v < nviews; v++) tbits = max(tbits, b3gs_tile_bits(jobs[v].W, jobs[v].H));
   for (int p = 0; p < passes; p++) {
     if (p == passes - 1)
       for (int v = 0; v < nviews; v++) tb.j[v].ranges = jobs[v].im.ranges;
-    radix_pass(tb, 8 * p, s);
+    radix_pass(tb, 8 * p, s, min(8, tbits - 8 * p));
     for (int v = 0; v < nviews; v++) {
       SortJob& j = tb.j[v];
       const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
@@ -1030,10 +1043,12 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   }
   if (max_cap == 0) return;
   hipLaunchKernelGGL(emit_instances<true>, dim3((rest + 255) / 256, nviews), dim3(256), 0, s, eb);
+  int tbits = 0;
+  for (int v = 0; v < nviews; v++) tbits = max(tbits, b3gs_tile_bits(jobs[v].W, jobs[v].H));
   for (int p = 0; p < passes; p++) {
     if (p == passes - 1)
       for (int v = 0; v < nviews; v++) tb.j[v].ranges = jobs[v].im.ranges2;
-    radix_pass(tb, 8 * p, s);
+    radix_pass(tb, 8 * p, s, min(8, tbits - 8 * p));
     for (int v = 0; v < nviews; v++) {
       SortJob& j = tb.j[v];
       const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
