@@ -1,0 +1,18 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/final_prof.sh <tag> -- the evidence set kept under profiles/ for one version:
+# kernel stats + JSON line of the profiled driver command, the full default JSON line, three PMC passes
+tag=$1
+tools/prof.sh ${tag}_default --no-extras --no-pmc > gpurun_out/${tag}_prof_stdout.txt 2>&1
+grep '^{"metric"' gpurun_out/${tag}_default_bench.log | tail -1 > gpurun_out/${tag}_profiled_run_bench_line.json
+python bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/${tag}_default_bench_line.json
+export PMC_TARGET="bench.py --inner --no-extras --no-pmc --no-cpu-baseline --steps 3 --warmup 1"
+tools/pmc.sh ${tag}_pmc_fetch_size "FETCH_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_f.txt 2>&1
+tools/pmc.sh ${tag}_pmc_write_size "WRITE_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_w.txt 2>&1
+tools/pmc.sh ${tag}_pmc_valu "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_v.txt 2>&1
+head -16 gpurun_out/${tag}_default_kernel_stats.csv
+python -c "
+import json
+d=json.load(open('gpurun_out/${tag}_default_bench_line.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('valu',{}).get('frac'), d.get('hbm_measured',{}).get('frac_of_peak'), {k:(v.get('iters_per_s') if isinstance(v,dict) else v) for k,v in d['extras'].items() if k!='dropin_what'})
+p=json.load(open('gpurun_out/${tag}_profiled_run_bench_line.json')); print('profiled run avg_launch_ms', p['roofline']['avg_launch_ms'], p['value'])"
+cat gpurun_out/${tag}_pmc_v.txt | tail -12
