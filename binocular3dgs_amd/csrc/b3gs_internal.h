@@ -87,7 +87,8 @@ static inline int b3gs_packed_idx_bits(int32_t P, int W, int H) {
 
 // radix-sort scratch: 1280 header words (global digit histograms, tickets) + one status word per
 // (pass <= 4, workgroup, digit) for the chained scan; also covers the 3-launch variant's 256*(nblk+1)
-static inline size_t b3gs_sort_scratch_words(int64_t n) { return 1280 + (size_t)4 * 256 * (b3gs_sort_blocks(n) + 1); }
+// (+ 4096: the histogram rows are padded to a multiple of 16 columns, binning.hip::hist_stride)
+static inline size_t b3gs_sort_scratch_words(int64_t n) { return 1280 + 4096 + (size_t)4 * 256 * (b3gs_sort_blocks(n) + 1); }
 
 // carve: if base == nullptr only the size is computed
 template <typename T>
