@@ -16,6 +16,10 @@ struct AdamSegs {
   uint32_t start[9];  // cumulative element offsets
 };
 
+// workgroup-completion counter of the in-kernel step bump (left at zero by every launch; launches that bump are ordered
+// on one stream -- optimisers stepping concurrently on several streams of one device would need a counter each)
+__device__ uint32_t g_adam_done = 0u;
+
 // One element's update; returns the new parameter value.
 __device__ __forceinline__ float adam_one(float pi, float grad, float& mi, float& vi, float beta1, float beta2, float eps,
                                           float bc1, float bc2_sqrt, float lr, bool decay, float opacity_decay,
@@ -40,7 +44,7 @@ __device__ __forceinline__ float adam_one(float pi, float grad, float& mi, float
 // iteration is 0 without being read (its slab row is stale, B3gsRawGrads::touched_rows).
 template <int VEC>
 __global__ void __launch_bounds__(256)
-    adam_kernel(AdamSegs segs, const int32_t* __restrict__ step_ptr, float beta1, float beta2, float eps,
+    adam_kernel(AdamSegs segs, int32_t* __restrict__ step_ptr, int bump, float beta1, float beta2, float eps,
                 float opacity_decay, int opacity_seg, int decay_first, const unsigned long long* __restrict__ row_mask) {
   const float t = (float)(*step_ptr + 1);
   const float bc1 = 1.0f - powf(beta1, t);
@@ -103,6 +107,14 @@ __global__ void __launch_bounds__(256)
       p[e] = pi;
     }
   }
+  // the workgroup that finishes last advances the step counter (every workgroup has read it by then): no second launch
+  if (bump) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&g_adam_done, 1u) == gridDim.x - 1u) {
+      g_adam_done = 0u;
+      *step_ptr += 1;
+    }
+  }
 }
 
 __global__ void bump_step(int32_t* step_ptr) { *step_ptr += 1; }
@@ -145,11 +157,10 @@ extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t
   const unsigned blocks = (unsigned)((items + 255) / 256 < 256u * 32u ? (items + 255) / 256 : 256u * 32u);
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(row_mask);
   if (vec4)
-    hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, a, device_step, beta1, beta2, eps, opacity_decay,
-                       opacity_segment, opacity_decay_first, mask);
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask);
   else
-    hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, a, device_step, beta1, beta2, eps, opacity_decay,
-                       opacity_segment, opacity_decay_first, mask);
-  if (bump_step_after) hipLaunchKernelGGL(bump_step, dim3(1), dim3(1), 0, s, device_step);
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask);
   return b3gs_launch_status("b3gs_adam_step");
 }
