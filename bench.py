@@ -436,7 +436,8 @@ def main():
                        "loss": args.loss, "optimizer_in_step": job.opt is not None, "densify_stats_in_step": fused is not None,
                        "optimizer": None if job.opt is None else args.optimizer, "path": args.path,
                        "hip_graph": bool(job.use_graph), "schedule": None if fused is None else fused.schedule,
-                       "binning_rounds": None if fused is None else (2 if 0.0 < fused.seg1_fraction < 1.0 else 1),
+                       "binning_rounds": None if fused is None else
+                       (2 if 0.0 < float(os.environ.get("B3GS_SEG1_FRAC", fused.seg1_fraction)) < 1.0 else 1),
                        "dp_tail_ranges": job.pipe_ranges,
                        "parallelism": f"dp{world} (views sharded, params replicated"
                                       + (", Adam state sharded: reduce-scatter + all-gather)" if args.optimizer == "sharded" else ")")},
