@@ -520,8 +520,8 @@ def main():
             el = j.timed(5)
             extras["dropin_iters_per_s"] = round(5 / el, 2)
             extras["dropin_what"] = ("the same iteration through the reference-shaped surface: render() -> "
-                                     "GaussianRasterizer -> _C.rasterize_gaussians per view, PyTorch activations, "
-                                     "one host read-back of num_rendered per forward")
+                                     "GaussianRasterizer -> _C.rasterize_gaussians per view, PyTorch activations; "
+                                     "num_rendered read back for the first render of a shape only (rasterizer._LazyN)")
             del j
             torch.cuda.empty_cache()
     if rank == 0:

@@ -16,6 +16,7 @@ CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -106,15 +107,74 @@ def _scene(background, means3D, colors, opacity, scales, rotations, scale_modifi
     return sc, keep, dev, P, M
 
 
+class _LazyN:
+    """Sync-free forward of the autograd surface: the one blocking read-back of num_rendered per forward (upstream
+    sizes the binning buffer from it; `api.hip`: b3gs_forward) is paid only by the FIRST render of a (device, P, W, H)
+    shape.  Later renders of that shape run b3gs_forward_capacity with a binning buffer of twice the largest N seen, N
+    stays on the device and travels to pinned host memory behind the kernels; it is looked at when its copy has
+    completed -- normally at the next render -- to grow the capacity while N is still below it.  An N above the
+    capacity (the list of that render was truncated) raises B3gsError at that point: one call late, never silently.
+    P changes at every densification, so each new Gaussian set starts with an exact, synchronous render."""
+    HEADROOM, REGROW_AT, RING = 2.0, 0.6, 64
+
+    def __init__(self):
+        self.capacity = {}     # (device index, P, W, H) -> instances the binning buffer is sized for
+        self.pending = []      # [(key, capacity used, pinned int32[1], event)]
+        self.pinned = None
+        self.slot = 0
+        self.enabled = os.environ.get("B3GS_DROPIN_SYNC", "0") != "1"
+
+    def note(self, key, n):
+        self.capacity[key] = max(self.capacity.get(key, 0), int(n * self.HEADROOM), 1 << 16)
+
+    def poll(self, force=False):
+        keep, over = [], None
+        for key, cap, host, ev in self.pending:
+            if not (force or ev.query()):
+                keep.append((key, cap, host, ev))
+                continue
+            ev.synchronize()
+            n = int(host[0])
+            if n > cap * self.REGROW_AT:
+                self.note(key, n)
+            if n > cap and over is None:
+                over = (key, n, cap)
+        self.pending = keep
+        if over is not None:
+            key, n, cap = over
+            raise _lib.B3gsError(f"B3GS_ERR_CAPACITY: an earlier render of shape {key[1:]} produced {n} tile instances, its "
+                                 f"binning buffer held {cap} (truncated lists); the capacity is now {self.capacity[key]} "
+                                 f"-- repeat the step")
+
+    def track(self, key, cap, n_dev):
+        if self.pinned is None:
+            self.pinned = torch.zeros((self.RING,), dtype=torch.int32).pin_memory()
+        if len(self.pending) >= self.RING - 1:
+            self.poll(force=True)
+        host = self.pinned[self.slot:self.slot + 1]
+        self.slot = (self.slot + 1) % self.RING
+        host.copy_(n_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(n_dev.device))
+        self.pending.append((key, cap, host, ev))
+
+
+_lazy = _LazyN()
+
+
 class _CModule:
     """Stands in for the `_C` torch-extension module of the upstream package."""
 
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, debug):
+                            campos, prefiltered, debug, lazy_num_rendered=False):
         """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32,
-               geomBuffer, binningBuffer, imgBuffer)   (uint8 state tensors, opaque)"""
+               geomBuffer, binningBuffer, imgBuffer)   (uint8 state tensors, opaque)
+
+        lazy_num_rendered (not part of the upstream signature; set by the autograd surface, which never shows
+        num_rendered to its caller): sync-free forward, see _LazyN -- the returned count is then the CAPACITY of the
+        binning buffer (what the backward needs to find its arrays), not N."""
         L = _lib.lib()
         sc, keep, dev, P, _ = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
@@ -124,6 +184,24 @@ class _CModule:
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), P, W, H)
+        if lazy_num_rendered and _lazy.enabled and not debug and P > 0:
+            _lazy.poll()
+            cap = _lazy.capacity.get(key)
+            if cap is not None:
+                u8 = dict(dtype=torch.uint8, device=dev)
+                geom = torch.empty((L.b3gs_geometry_bytes(P),), **u8)
+                binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+                img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
+                n_dev = torch.empty((1,), dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    rc = L.b3gs_forward_capacity(C.byref(sc), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                                 color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii),
+                                                 n_dev.data_ptr(), _stream(dev))
+                    _lib.check(rc, "b3gs_forward_capacity")
+                    _lazy.track(key, cap, n_dev)
+                del keep
+                return cap, color, depth, alpha, radii, geom, binning, img
         bufs = {}
 
         def mk(key):
@@ -140,6 +218,8 @@ class _CModule:
                                 depth.data_ptr(), alpha.data_ptr(), _ptr(radii), C.byref(n), _stream(dev))
         _lib.check(rc, "b3gs_forward")
         del keep
+        if lazy_num_rendered:
+            _lazy.note(key, int(n.value))
         return (int(n.value), color, depth, alpha, radii, bufs["geom"],
                 bufs.get("binning", torch.empty(0, dtype=torch.uint8, device=dev)), bufs["img"])
 
@@ -215,7 +295,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, lazy_num_rendered=True)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom,

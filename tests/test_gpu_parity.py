@@ -346,3 +346,52 @@ def test_forward_capacity_entry_point_and_overflow():
             assert torch.equal(color, out["color"]) and torch.equal(depth, out["depth"]) and torch.equal(alpha, out["alpha"])
         else:
             assert int(n.item()) > cap and torch.isfinite(color).all()   # truncated lists: caller must grow and repeat
+
+
+def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
+    """GaussianRasterizer (the surface render() uses) pays the blocking read-back of num_rendered only for the first
+    render of a (P, W, H) shape; afterwards it runs b3gs_forward_capacity with twice the largest N seen and looks at N one
+    call late (rasterizer._LazyN).  Same images and gradients bit for bit / to atomics order; an N above the capacity is
+    reported at the next render, and the render after that is complete again."""
+    from binocular3dgs_amd import _lib, rasterizer, synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H, P = 160, 112, 4000
+    model = synth.synth_model(P, seed=5, device="cuda", width=W, height=H)
+    cam = synth.synth_view_set(W, H, device="cuda")[0][0]
+    bg = torch.tensor([0.1, 0.2, 0.3], device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=2, device="cuda")
+    lz = rasterizer._lazy
+    assert lz.enabled
+    key = (torch.cuda.current_device(), P, W, H)
+    lz.capacity.pop(key, None)
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        pkg = render(cam, model, PipelineParams(), bg)
+        torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+        torch.cuda.synchronize()
+        return ([pkg[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha", "radii")],
+                [p.grad.clone() for p in model.parameters()] + [pkg["viewspace_points"].grad.clone()])
+
+    first = run()                                   # synchronous: learns N
+    cap = lz.capacity[key]
+    lz.poll(force=True)
+    second = run()                                  # sync-free: capacity path
+    assert [k for k, *_ in lz.pending] == [key]     # its N is on the way to the host, nobody waited for it
+    for a, b in zip(first[0], second[0]):
+        assert torch.equal(a, b)
+    for a, b in zip(first[1], second[1]):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    lz.poll(force=True)                             # N of the second render: well inside the capacity
+    assert lz.capacity[key] == cap
+    # a scene that outgrew the buffer: reported one render late, capacity grown, next render complete
+    lz.capacity[key] = 256
+    run()                                           # truncated lists (nobody knows yet)
+    with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
+        lz.poll(force=True)
+    assert lz.capacity[key] >= cap // 2 and lz.capacity[key] > 256
+    third = run()
+    for a, b in zip(first[0], third[0]):
+        assert torch.equal(a, b)
+    lz.poll(force=True)
