@@ -713,3 +713,37 @@ def test_sparse_gradient_rows_equal_dense_rows(P):
     for other in res[1:]:
         for x, y in zip(res[0], other):
             assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6
+
+
+def test_sparse_row_and_row_mask_argument_errors():
+    """(i) sparse-row accumulate over a Gaussian range must start at a multiple of 64 (the bitmap is written word-wise);
+    (ii) a masked Adam step rejects negative row geometry; both leave a message in b3gs_last_error."""
+    import ctypes as C
+    from binocular3dgs_amd import _lib
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam
+    W, H, P = 96, 64, 1000
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    fr = FusedRasterizer(model, W, H, num_slots=2)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    fr.begin_deferred()
+    outs = fr.render_batch([(pairs[0][0], 0, True), (pairs[0][1], 1, False)], bg)
+    torch.autograd.backward([o["render"] for o in outs], [torch.ones_like(o["render"]) for o in outs])
+    pend = fr.take_deferred()
+    words = torch.zeros((P + 63) // 64, dtype=torch.int64, device="cuda")
+    gr = fr._bind_grads()
+    with pytest.raises(_lib.B3gsError, match="multiple of 64"):
+        fr._accumulate(pend, True, gr, first=32, count=P - 32, touched_rows=words)
+    fr._accumulate(pend, True, gr, first=64, count=P - 64, touched_rows=words)     # aligned start: fine
+    fr._accumulate(pend, True, gr, first=0, count=64, touched_rows=words)
+    torch.cuda.synchronize()
+    assert int(words[1:].abs().sum()) != 0
+    opt = FusedAdam(list(model.parameters()), [1e-3] * 6)
+    seg = (_lib.B3gsAdamSegment * 1)()
+    p0 = opt.params[0]
+    seg[0].param, seg[0].grad = p0.data_ptr(), p0.grad.data_ptr()
+    seg[0].exp_avg, seg[0].exp_avg_sq = opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr()
+    seg[0].count, seg[0].lr, seg[0].row_len, seg[0].first_row = p0.numel(), 1e-3, -3, 0
+    rc = _lib.lib().b3gs_adam_step(1, seg, opt.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, words.data_ptr(), None)
+    assert rc == -1 and b"row_len" in _lib.lib().b3gs_last_error()

@@ -395,3 +395,24 @@ def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
     for a, b in zip(first[0], third[0]):
         assert torch.equal(a, b)
     lz.poll(force=True)
+
+
+def test_lazy_num_rendered_survives_more_renders_than_pinned_slots():
+    """More sync-free renders in a row than the ring of pinned read-back slots (64): the oldest are drained before a slot
+    is reused, every N is still checked."""
+    from binocular3dgs_amd import rasterizer, synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H, P = 64, 48, 500
+    model = synth.synth_model(P, seed=9, device="cuda", width=W, height=H, requires_grad=False)
+    cam = synth.synth_view_set(W, H, device="cuda")[0][0]
+    bg = torch.zeros(3, device="cuda")
+    lz = rasterizer._lazy
+    lz.poll(force=True)
+    with torch.no_grad():
+        ref = render(cam, model, PipelineParams(), bg)["render"].clone()
+        for _ in range(lz.RING + 10):
+            out = render(cam, model, PipelineParams(), bg)["render"]
+    assert len(lz.pending) < lz.RING
+    assert torch.equal(out, ref)
+    lz.poll(force=True)
+    assert lz.pending == []
