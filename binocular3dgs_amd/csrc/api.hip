@@ -371,6 +371,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     jobs[k].rect = pb.out[k].rect;
     jobs[k].rect_stride = pb.out[k].rect_stride;
   }
+  bb.order_buf = jobs[0].im.order;   // the forward follows the longest-tile-first order of the previous backward, if any
   pb.raw = *params;
   // two-round binning: the same K1 for every view of the batch; needs packed instance words and one tile-sort depth
   const int32_t P = views[0].view->P;

@@ -292,6 +292,10 @@ struct BlendBatch {
   const uint32_t* order;
   int32_t cls_size;
   uint32_t* order_buf;     // host side: where the launcher may build the order (view 0's ImgView::order), or null
+  // Forward: the order the PREVIOUS backward of the same batch shape left in order_buf is reused (tile work changes little
+  // between iterations).  It is trusted only when the two words at order[sig_off] carry the magic number and this
+  // launch's shape signature: a fresh or differently shaped buffer keeps the default order.
+  uint32_t sig_off, sig;
   BlendView v[B3GS_MAX_FUSED_VIEWS];
 };
 BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im);

@@ -39,6 +39,7 @@ __device__ __forceinline__ u64 uniform_u64(u64 v) {
   return ((u64)hi << 32) | lo;
 }
 
+constexpr uint32_t B3GS_ORDER_MAGIC = 0xB365A0D1u;
 // XCD-aware tile assignment: workgroup b is observed to run on XCD b % 8; give each XCD a
 // contiguous band of tiles.  Placement only affects L2 hit rate, never results.
 __device__ __forceinline__ int tile_of_block(int bid, int ntiles) {
@@ -173,7 +174,11 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_chunks = 0;
-  const BlendView bv = select_view(batch, (int)blockIdx.x);
+  // longest-tile-first order of the previous backward of this batch shape, if the buffer holds one (BlendBatch::sig)
+  int bid = (int)blockIdx.x;
+  if (batch.order && batch.order[batch.sig_off] == B3GS_ORDER_MAGIC && batch.order[batch.sig_off + 1] == batch.sig)
+    bid = 8 * (int)batch.order[(blockIdx.x & 7u) * (unsigned)batch.cls_size + (blockIdx.x >> 3)] + (int)(blockIdx.x & 7u);
+  const BlendView bv = select_view(batch, bid);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
   const float4* __restrict__ rec = bv.rec;
   const float* __restrict__ bg = bv.bg;
@@ -182,7 +187,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   float* __restrict__ out_color = bv.out_color;
   float* __restrict__ out_depth = bv.out_depth;
   float* __restrict__ out_alpha = bv.out_alpha;
-  const int tile = tile_of_block((int)blockIdx.x - bv.block_base, ntiles);
+  const int tile = tile_of_block(bid - bv.block_base, ntiles);
   if (tile >= ntiles) return;
   const int tile_x = tile % grid_x, tile_y = tile / grid_x;
   const unsigned tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -628,6 +633,16 @@ namespace {
 int blocks_of(const BlendView& v) { return ((v.ntiles + 7) / 8) * 8; }
 }  // namespace
 
+namespace {
+// where the signature of an order array sits, and what it says: (views, total blocks) of the batch it was built for
+bool order_fits(const BlendBatch& batch, int total, uint32_t* sig_off, uint32_t* sig) {
+  const size_t words = (size_t)B3GS_MAX_FUSED_VIEWS * (size_t)(batch.v[0].ntiles + 8);
+  *sig_off = (uint32_t)(words - 2);
+  *sig = (uint32_t)total * 16u + (uint32_t)batch.n;
+  return (size_t)total <= words - 2;
+}
+}  // namespace
+
 void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
   int total = 0;
   for (int k = 0; k < batch.n; k++) {
@@ -635,6 +650,10 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
     total += blocks_of(batch.v[k]);
   }
   if (total <= 0) return;
+  static const bool lpt = getenv("B3GS_NO_LPT") == nullptr && getenv("B3GS_NO_FWD_LPT") == nullptr;
+  batch.order = nullptr;
+  batch.cls_size = total / 8;
+  if (lpt && batch.order_buf && order_fits(batch, total, &batch.sig_off, &batch.sig)) batch.order = batch.order_buf;
   if (getenv("B3GS_FWD_TRACE"))  // debug: per-wave cycle trace (tools/bwd_trace.py fwd)
     hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, true>), dim3(total), dim3(256), 0, s, batch, trace_buffer(total));
   else
@@ -683,6 +702,10 @@ __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint
     const uint32_t b = 255u - (uint32_t)((float)work_of(q) * scale);
     order[(size_t)c * cls_size + atomicAdd(&cursor[b], 1u)] = (uint32_t)q;
   }
+  if (c == 0 && threadIdx.x == 0) {   // the next forward of this batch shape may reuse the order
+    order[batch.sig_off] = B3GS_ORDER_MAGIC;
+    order[batch.sig_off + 1] = batch.sig;
+  }
 }
 }  // namespace
 
@@ -699,7 +722,7 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   uint32_t* order = batch.order_buf;
   batch.order = nullptr;
   batch.cls_size = total / 8;
-  if (lpt && order && (size_t)total <= (size_t)B3GS_MAX_FUSED_VIEWS * (size_t)(batch.v[0].ntiles + 8)) {
+  if (lpt && order && order_fits(batch, total, &batch.sig_off, &batch.sig)) {
     hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(256), 0, s, batch, order, batch.cls_size);
     batch.order = order;
   }

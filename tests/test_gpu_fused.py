@@ -747,3 +747,42 @@ def test_sparse_row_and_row_mask_argument_errors():
     seg[0].count, seg[0].lr, seg[0].row_len, seg[0].first_row = p0.numel(), 1e-3, -3, 0
     rc = _lib.lib().b3gs_adam_step(1, seg, opt.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, words.data_ptr(), None)
     assert rc == -1 and b"row_len" in _lib.lib().b3gs_last_error()
+
+
+def test_forward_reuses_the_backward_tile_order_without_changing_the_images():
+    """The batched forward follows the longest-tile-first order the previous backward of the same batch shape left in
+    view 0's image buffer (signature-checked; placement only).  Same images bit for bit before and after an order exists,
+    and after the batch shape changes (the old order must be ignored, not misread)."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H, P = 208, 144, 20000
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    gc, _, _ = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+    views = []
+    for i, (cam, scam, _t) in enumerate(pairs):
+        views += [(cam, 2 * i, True), (scam, 2 * i + 1, False)]
+    fr = FusedRasterizer(model, W, H, num_slots=len(views))
+
+    def fwd(vs, backward):
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        outs = fr.render_batch(vs, bg)
+        imgs = [o["render"].detach().clone() for o in outs]
+        if backward:
+            torch.autograd.backward([o["render"] for o in outs], [gc] * len(outs))
+        torch.cuda.synchronize()
+        return imgs
+
+    first = fwd(views, True)            # no order yet -> default placement; the backward leaves one for 6 views
+    second = fwd(views, True)           # follows it
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    sub = fwd(views[:4], True)          # 4 views: another shape, the 6-view order must be ignored
+    for a, b in zip(first[:4], sub):
+        assert torch.equal(a, b)
+    again = fwd(views[:4], False)       # follows the 4-view order
+    for a, b in zip(sub, again):
+        assert torch.equal(a, b)
+    third = fwd(views, False)           # back to 6 views with a 4-view order in the buffer
+    for a, b in zip(first, third):
+        assert torch.equal(a, b)
