@@ -663,6 +663,7 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
 namespace {
 // One workgroup per XCD class c: sort the class's cls_size default positions by decreasing tile work (counting sort
 // over 256 buckets of work / max work; the order inside a bucket is arbitrary: it only schedules).
+constexpr int ORDER_CACHE = 4096;
 __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint32_t* __restrict__ order, int cls_size) {
   __shared__ uint32_t hist[256], cursor[256], s_max[4], tmp[8];
   const int c = (int)blockIdx.x;
@@ -673,15 +674,21 @@ __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint
     const int tile = tile_of_block(bid - bv.block_base, bv.ntiles);
     return tile < bv.ntiles ? bv.tile_work[tile] : 0u;
   };
+  // the work of the class's tiles is read once into LDS (the three passes below recompute nothing); classes larger than
+  // the cache fall back to reading it again
+  __shared__ uint32_t s_work[ORDER_CACHE];
+  for (int q = (int)threadIdx.x; q < cls_size && q < ORDER_CACHE; q += 256) s_work[q] = work_of(q);
+  __syncthreads();
+  auto work_at = [&](int q) -> uint32_t { return q < ORDER_CACHE ? s_work[q] : work_of(q); };
   uint32_t m = 0;
-  for (int q = (int)threadIdx.x; q < cls_size; q += 256) m = max(m, work_of(q));
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) m = max(m, work_at(q));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
   if (lane == 0) s_max[w] = m;
   hist[threadIdx.x] = 0;
   __syncthreads();
   const float scale = 255.0f / (float)max(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), 1u);
-  for (int q = (int)threadIdx.x; q < cls_size; q += 256) atomicAdd(&hist[255u - (uint32_t)((float)work_of(q) * scale)], 1u);
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) atomicAdd(&hist[255u - (uint32_t)((float)work_at(q) * scale)], 1u);
   __syncthreads();
   {   // exclusive scan of the 256 bucket counts (bucket 0 = heaviest)
     const uint32_t v = hist[threadIdx.x];
@@ -699,7 +706,7 @@ __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint
   }
   __syncthreads();
   for (int q = (int)threadIdx.x; q < cls_size; q += 256) {
-    const uint32_t b = 255u - (uint32_t)((float)work_of(q) * scale);
+    const uint32_t b = 255u - (uint32_t)((float)work_at(q) * scale);
     order[(size_t)c * cls_size + atomicAdd(&cursor[b], 1u)] = (uint32_t)q;
   }
   if (c == 0 && threadIdx.x == 0) {   // the next forward of this batch shape may reuse the order
