@@ -56,3 +56,14 @@ print("iterations per wave: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (it
 print("corr(iters, duration) %.3f" % np.corrcoef(it, e_us - s_us)[0, 1])
 late = s_us > 0.5 * span
 print("waves started in the second half: %d, their mean duration %.1f us" % (late.sum(), (e_us - s_us)[late].mean() if late.any() else 0))
+# imbalance between the four quadrant waves of a workgroup (they live until the tile is done): the share of wave-slot time
+# held by waves that had fewer candidates than the busiest wave of their tile
+full = buf[:n].reshape(-1, 4)
+if len(full) % 4 == 0:
+    wg_it = full[:, 2].astype(np.float64).reshape(-1, 4)
+    wg_dur = ((full[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64) - ((full[:, 1] >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF)).astype(np.float64).reshape(-1, 4) / 100.0
+    live = wg_it.max(1) > 0
+    mx = wg_it[live].max(1, keepdims=True)
+    idle = (wg_dur[live] * (1.0 - wg_it[live] / mx)).sum() / wg_dur[live].sum()
+    print("workgroups %d; candidates per wave / busiest wave of its tile: mean %.2f; wave-slot time held by the lighter waves: %.1f %%"
+          % (int(live.sum()), float((wg_it[live] / mx).mean()), 100.0 * idle))
