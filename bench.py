@@ -497,20 +497,23 @@ def main():
                           "800x600, 6 views"}
             del j
             torch.cuda.empty_cache()
-            # the headline workload with two-round binning switched on (the automatic choice considers two rounds
-            # from 6M instances per view on: below, the gain is within the noise of its timing probe): same images and gradients, ~70 % fewer instances emitted / sorted
-            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", seg1_fraction=0.125)
+            # the headline workload with ONE binning round (the automatic rule picks two from 2M instances per view on):
+            # same images and gradients, every instance emitted and sorted
+            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", seg1_fraction=0.0)
             j.prepare(max(args.warmup, 3))
             k2 = min(args.steps, 10)
             el = j.timed(k2)
             ms2, inst2 = j.kernel_times(k2)
-            extras["headline_two_round_binning"] = {
-                "iters_per_s": round(k2 / el, 2), "ms_per_step": round(el / k2 * 1e3, 3), "steps": k2, "seg1_fraction": 0.125,
+            extras["headline_one_round_binning"] = {
+                "iters_per_s": round(k2 / el, 2), "ms_per_step": round(el / k2 * 1e3, 3), "steps": k2, "seg1_fraction": 0.0,
                 "instances_emitted_per_view": None if inst2 is None else int(inst2 / 6),
                 "stage_ms_per_view": {k_: round(v_, 4) for k_, v_ in ms2.items()},
-                "what": "B3gsForwardView.seg1_fraction = 1/8 with open-tile prediction; the blend kernels walk the same list "
-                        "prefixes as with one round (bit-identical images), so `roofline` above -- bytes per instance HANDED "
-                        "to the blend backward -- would read lower here for the same kernel time"}
+                "render_bwd_algorithmic_GBps": (None if inst2 is None or ms2["render_bwd"] <= 0 else
+                                                round((44.0 * inst2 + 28.0 * W * H * 6) / (ms2["render_bwd"] * 6 / 1e3) / 1e9, 1)),
+                "what": "FusedRasterizer(seg1_fraction=0): every tile instance is emitted, sorted and handed to the blend "
+                        "kernels, which walk the same list prefixes as with two rounds (bit-identical images); SURVEY 8(d)'s "
+                        "roofline unit -- bytes per instance HANDED to the blend backward -- is 3.3x larger here for the same "
+                        "kernel time"}
             del j
             torch.cuda.empty_cache()
             dargs = argparse.Namespace(**vars(args))

@@ -110,6 +110,7 @@ struct ScanJob {
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
+  uint32_t* repair_barrier;   // two-round forward: arrival counter of the repair kernel's grid barrier, reset here
   ScanJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -347,6 +348,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
   __shared__ uint32_t tmp[8];
   const ScanJob& job = sb.j[blockIdx.x];
   const int nchunks = sb.nchunks;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sb.repair_barrier) *sb.repair_barrier = 0u;
   // nchunks <= 2048: 8 per thread, sequential
   uint32_t loc[8], s = 0, v = 0;
 #pragma unroll
@@ -417,14 +419,13 @@ __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix_hist(Sor
     *reinterpret_cast<uint4*>(job.hist + (size_t)t * hist_stride(job.nblk) + blk0) = make_uint4(h[0][t], h[1][t], h[2][t], h[3][t]);
 }
 
-__global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
-  __shared__ uint32_t tmp[8];
-  const SortJob& job = sb.j[blockIdx.y];
+__device__ __forceinline__ void radix_rowscan_body(const SortBatch& sb, uint32_t bx, uint32_t by, uint32_t* tmp) {
+  const SortJob& job = sb.j[by];
   const uint32_t nblk = job.nblk;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
   const uint32_t used = min(nblk, (n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);   // columns the histogram pass wrote
-  uint32_t* row = job.hist + (size_t)blockIdx.x * hist_stride(nblk);
+  uint32_t* row = job.hist + (size_t)bx * hist_stride(nblk);
   uint32_t carry = 0;
   for (uint32_t b0 = 0; b0 < used; b0 += 256) {
     uint32_t i = b0 + threadIdx.x;
@@ -434,24 +435,39 @@ __global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
     if (i < used) row[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) job.hist[(size_t)256 * hist_stride(nblk) + blockIdx.x] = carry;  // totals
+  if (threadIdx.x == 0) job.hist[(size_t)256 * hist_stride(nblk) + bx] = carry;  // totals
+}
+__global__ void __launch_bounds__(256) radix_rowscan(SortBatch sb) {
+  __shared__ uint32_t tmp[8];
+  radix_rowscan_body(sb, blockIdx.x, blockIdx.y, tmp);
 }
 
 // HAS_VAL = false: keys only (packed tile|index words): no value staging buffer, 22 KB instead of 38 KB of LDS
 // per workgroup (7 instead of 4 workgroups per CU)
 // BITS: significant bits of this pass's digit (the last tile-split pass sees only the top bits of the tile id: 3 at
 // 800x600) -- the ballot ranking costs one round per bit
+template <bool HAS_VAL>
+struct ScatterShared {
+  uint32_t wave_cnt[4][256];
+  uint32_t blk_start[256];  // first slot of digit d inside this workgroup's reorder buffer
+  uint32_t gbase[256];      // global destination of that first slot
+  uint32_t tmp[8];
+  uint32_t s_key[B3GS_SORT_TILE];
+  uint32_t s_val[HAS_VAL ? B3GS_SORT_TILE : 1];
+};
+// (bx, by) = (radix tile, job): blockIdx of the stand-alone launch, a loop index inside the repair kernel
 template <bool HAS_VAL, int BITS>
-__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int pass_shift) {
-  __shared__ uint32_t wave_cnt[4][256];
-  __shared__ uint32_t blk_start[256];  // first slot of digit d inside this workgroup's reorder buffer
-  __shared__ uint32_t gbase[256];      // global destination of that first slot
-  __shared__ uint32_t tmp[8];
-  __shared__ uint32_t s_key[B3GS_SORT_TILE];
-  __shared__ uint32_t s_val[HAS_VAL ? B3GS_SORT_TILE : 1];
+__device__ __forceinline__ void radix_scatter_body(const SortBatch& sb, int pass_shift, uint32_t bx, uint32_t by,
+                                                   ScatterShared<HAS_VAL>& sh) {
+  uint32_t (&wave_cnt)[4][256] = sh.wave_cnt;
+  uint32_t (&blk_start)[256] = sh.blk_start;
+  uint32_t (&gbase)[256] = sh.gbase;
+  uint32_t (&tmp)[8] = sh.tmp;
+  uint32_t (&s_key)[B3GS_SORT_TILE] = sh.s_key;
+  uint32_t (&s_val)[HAS_VAL ? B3GS_SORT_TILE : 1] = sh.s_val;
 
-  const SortJob& job = sb.j[blockIdx.y];
-  if (blockIdx.x >= job.nblk) return;
+  const SortJob& job = sb.j[by];
+  if (bx >= job.nblk) return;
   const int shift = pass_shift + job.shift_base;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t* __restrict__ keys_in = job.kin + off;
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
   const uint32_t hstride = hist_stride(nblk);
   const uint32_t* __restrict__ totals = job.hist + (size_t)256 * hstride;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
-  const uint32_t tile_base = blockIdx.x * B3GS_SORT_TILE;
+  const uint32_t tile_base = bx * B3GS_SORT_TILE;
   if (tile_base >= n) return;  // uniform per workgroup
   const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
@@ -518,7 +534,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
     wave_cnt[2][d] = start + c0 + c1;
     wave_cnt[3][d] = start + c0 + c1 + c2;
     blk_start[d] = start;
-    gbase[d] = dig_base + hist[(size_t)d * hstride + blockIdx.x];
+    gbase[d] = dig_base + hist[(size_t)d * hstride + bx];
   }
   __syncthreads();
 
@@ -554,6 +570,11 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
     }
   }
 }
+template <bool HAS_VAL, int BITS>
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int pass_shift) {
+  __shared__ ScatterShared<HAS_VAL> sh;
+  radix_scatter_body<HAS_VAL, BITS>(sb, pass_shift, blockIdx.x, blockIdx.y, sh);
+}
 
 // one pass over all jobs; swaps every job's in/out buffers afterwards (vin becomes non-null)
 template <int BITS>
@@ -580,18 +601,22 @@ void radix_pass(SortBatch& sb, int shift, hipStream_t s, int bits = 8) {
 // ---------------------------------------------------------------------------------------------
 // instance emission in depth order (wave-cooperative expansion)
 // ---------------------------------------------------------------------------------------------
+struct EmitShared {
+  uint32_t s_end[4][64];
+  uint32_t s_tmp[8];
+};
 template <bool ROUND2>
-__global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
-  __shared__ uint32_t s_end[4][64];
-  __shared__ uint32_t s_tmp[8];
-  const EmitJob& job = eb.j[blockIdx.y];
+__device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_t bx, uint32_t by, EmitShared& sh) {
+  uint32_t (&s_end)[4][64] = sh.s_end;
+  uint32_t (&s_tmp)[8] = sh.s_tmp;
+  const EmitJob& job = eb.j[by];
   const int P = eb.P;
   const uint32_t off = (ROUND2 && job.off_ptr) ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t n_cap = job.n_cap - off;
   uint32_t* __restrict__ tile_out = job.tile_out + off;
   uint32_t* __restrict__ idx_out = job.idx_out ? job.idx_out + off : nullptr;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  const int s = eb.first + (int)(blockIdx.x * 256 + threadIdx.x);
+  const int s = eb.first + (int)(bx * 256 + threadIdx.x);
   uint32_t gid = 0, cnt = 0, end = 0;
   uint2 rc = make_uint2(0, 0);
   if (ROUND2) {
@@ -600,7 +625,7 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     if (s < P) cnt = job.scount[s];
     if (__ballot(cnt != 0) == 0) return;
   }
-  if (!ROUND2 && job.soffs[blockIdx.x] == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
+  if (!ROUND2 && job.soffs[bx] == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
   if (s < P) {
     if (ROUND2) {
       gid = job.order[s];
@@ -618,7 +643,7 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   if (!ROUND2) {
     // inclusive end of every Gaussian's instance run: offset of this 256-Gaussian sub-block (chunk base + the sums of
     // the sub-blocks before it: uniform scalar loads) + the scan inside the sub-block
-    const uint32_t chunk = blockIdx.x / (uint32_t)eb.subs, sub = blockIdx.x % (uint32_t)eb.subs;
+    const uint32_t chunk = bx / (uint32_t)eb.subs, sub = bx % (uint32_t)eb.subs;
     uint32_t base = job.chunk_base[chunk];
     for (uint32_t k = 0; k < sub; k++) base += job.soffs[(size_t)chunk * eb.subs + k];
     uint32_t tot;
@@ -634,7 +659,7 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
 
   const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu;
   const uint32_t rw = x1 - x0;
-  if (!ROUND2 && (int)(blockIdx.x * 256 + w * 64) >= eb.K1) {
+  if (!ROUND2 && (int)(bx * 256 + w * 64) >= eb.K1) {
     // a wave behind segment 1 of a two-round forward: a handful of its Gaussians reach a predicted-open tile, a few
     // instances each -- every lane walks its own rect over the bitmap (no cooperative expansion, no search)
     if (cnt != 0u) {
@@ -671,9 +696,9 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     const uint32_t src_gid = __shfl(gid, (int)lo, 64);
     const uint32_t src_x0 = __shfl(x0, (int)lo, 64), src_y0 = __shfl(y0, (int)lo, 64), src_rw = __shfl(rw, (int)lo, 64);
     // the source lies behind segment 1 of a two-round forward: its instances are the predicted-open tiles of its rect
-    const bool masked = ROUND2 || (int)(blockIdx.x * 256 + w * 64 + lo) >= eb.K1;
+    const bool masked = ROUND2 || (int)(bx * 256 + w * 64 + lo) >= eb.K1;
     uint2 src_rc = make_uint2(0u, 0u);
-    if (ROUND2 || (int)(blockIdx.x * 256 + w * 64 + 63) >= eb.K1) {   // (wave-uniform)
+    if (ROUND2 || (int)(bx * 256 + w * 64 + 63) >= eb.K1) {   // (wave-uniform)
       src_rc.x = __shfl(rc.x, (int)lo, 64);
       src_rc.y = __shfl(rc.y, (int)lo, 64);
     }
@@ -695,6 +720,11 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
     }
   }
 }
+template <bool ROUND2>
+__global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
+  __shared__ EmitShared sh;
+  emit_instances_body<ROUND2>(eb, blockIdx.x, blockIdx.y, sh);
+}
 
 // ---------------------------------------------------------------------------------------------
 // round 2 of the two-round binning: count / scan of the Gaussians [K1, P) of the depth order, restricted to the
@@ -715,29 +745,41 @@ struct Scan2Batch {
   Scan2Job j[B3GS_MAX_FUSED_VIEWS];
 };
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_sums(Scan2Batch sb) {
-  __shared__ uint32_t tmp[8];
-  const Scan2Job& job = sb.j[blockIdx.y];
+__device__ __forceinline__ void scan2_chunk_sums_body(const Scan2Batch& sb, uint32_t bx, uint32_t by, uint32_t* tmp) {
+  const Scan2Job& job = sb.j[by];
   if (job.img_header[3] == 0u) {   // no tile to repair: segment 2 is empty, the chunk sum is all that is needed
-    if (threadIdx.x == 0) job.chunk_sums[blockIdx.x] = 0u;
+    if (threadIdx.x == 0) job.chunk_sums[bx] = 0u;
     return;
   }
-  const int64_t begin = (int64_t)sb.K1 + (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  const int64_t begin = (int64_t)sb.K1 + (int64_t)bx * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   uint32_t sum = 0;
-  for (int64_t i = begin + threadIdx.x; i < end; i += SCAN_THREADS) {
-    const uint32_t t = open_tiles(job.srect[i], job.open);
-    job.scount[i] = t;
-    sum += t;
+  const uint2* __restrict__ srect = job.srect;
+  uint32_t* __restrict__ scount = job.scount;
+  for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * SCAN_THREADS) {   // four rect loads in flight per thread
+    uint2 rc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
+      rc[k] = i < end ? srect[i] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
+      if (i < end) {
+        const uint32_t t = open_tiles(rc[k], job.open);
+        scount[i] = t;
+        sum += t;
+      }
+    }
   }
   uint32_t tot;
   block_excl_scan_256(sum, tmp, &tot);
-  if (threadIdx.x == 0) job.chunk_sums[blockIdx.x] = tot;
+  if (threadIdx.x == 0) job.chunk_sums[bx] = tot;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_offsets(Scan2Batch sb) {
-  __shared__ uint32_t tmp[8];
-  const Scan2Job& job = sb.j[blockIdx.x];
+__device__ __forceinline__ void scan2_chunk_offsets_body(const Scan2Batch& sb, uint32_t bx, uint32_t* tmp) {
+  const Scan2Job& job = sb.j[bx];
   const int nchunks = sb.nchunks;
   uint32_t loc[8], s = 0;
 #pragma unroll
@@ -761,16 +803,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_offsets(Scan2Batch s
   }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_apply(Scan2Batch sb) {
-  __shared__ uint32_t wave_tot[4];
-  const Scan2Job& job = sb.j[blockIdx.y];
+__device__ __forceinline__ void scan2_chunk_apply_body(const Scan2Batch& sb, uint32_t bx, uint32_t by, uint32_t* wave_tot) {
+  const Scan2Job& job = sb.j[by];
   if (job.img_header[3] == 0u) return;   // no open tile: no segment 2, nobody reads the offsets
   const uint32_t* __restrict__ scount = job.scount;
   uint32_t* __restrict__ soffs = job.soffs;
   const int P = sb.P;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  uint32_t carry = job.chunk_sums[blockIdx.x];
-  const int64_t begin = (int64_t)sb.K1 + (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  uint32_t carry = job.chunk_sums[bx];
+  const int64_t begin = (int64_t)sb.K1 + (int64_t)bx * sb.tiles_per_chunk * SCAN_TILE;
   for (int t = 0; t < sb.tiles_per_chunk; t++) {
     const int64_t tb = begin + (int64_t)t * SCAN_TILE;
     if (tb >= P) break;
@@ -802,6 +843,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_apply(Scan2Batch sb)
   }
 }
 
+// stand-alone launches of the round-2 scans (B3GS_ROUND2_LEGACY=1, and tile grids deeper than two radix passes)
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_sums(Scan2Batch sb) {
+  __shared__ uint32_t tmp[8];
+  scan2_chunk_sums_body(sb, blockIdx.x, blockIdx.y, tmp);
+}
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_offsets(Scan2Batch sb) {
+  __shared__ uint32_t tmp[8];
+  scan2_chunk_offsets_body(sb, blockIdx.x, tmp);
+}
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_chunk_apply(Scan2Batch sb) {
+  __shared__ uint32_t wave_tot[4];
+  scan2_chunk_apply_body(sb, blockIdx.x, blockIdx.y, wave_tot);
+}
+
 __global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
   const RangeJob& job = rb.j[blockIdx.y];
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
@@ -813,6 +868,148 @@ __global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
   const uint32_t t = tile_sorted[j] >> sh;
   if (j == 0 || (tile_sorted[j - 1] >> sh) != t) job.ranges[t].x = off + j;
   if (j == n - 1 || (tile_sorted[j + 1] >> sh) != t) job.ranges[t].y = off + j + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second binning round as ONE launch ("repair kernel").  After the blend forward over segment 1 the image header says
+// how many tiles are still open and were not predicted open (word 3).  In the steady state that number is zero -- the
+// prediction has settled -- and the ten launches of the round (three scans, emission, two radix passes of three kernels)
+// did nothing but start and exit (~60-90 us per iteration at the headline workload).  Here one persistent grid of
+// REPAIR_GRID workgroups looks at the counts once: all zero -> exit (one launch boundary); otherwise it walks the same
+// phases with the same device code as the stand-alone kernels, workgroups striding over each phase's blocks, and an
+// agent-scope grid barrier between phases (monotonic counter; lane 0 releases before it arrives and acquires after
+// the poll, MI355X_MICROARCH.md "barrier-counter").  REPAIR_GRID = one workgroup per CU: resident at once with room to
+// spare (<= 40 KB of LDS, 256 threads), so the barrier cannot starve; the spin is bounded all the same and a time-out
+// is reported through the status word instead of hanging the queue.
+// ---------------------------------------------------------------------------------------------
+constexpr int REPAIR_GRID = 256;
+struct RepairArgs {
+  Scan2Batch sc;
+  EmitBatch eb;
+  SortBatch tb[2];          // tile-split passes (in / out already swapped for pass 1; ranges set on the last one)
+  int32_t passes, bits[2];
+  uint32_t emit_blocks, max_blk;
+  uint32_t* barrier;        // [2] arrival counter (zeroed by scan_chunk_offsets of the same forward) | status (bit 0: time-out)
+};
+
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target) {
+  __shared__ uint32_t s_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0, ok = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 22)) { ok = 0; break; }   // seconds: a workgroup of the grid never became resident
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0u;
+}
+
+// one radix tile of 4096 keys counted by 256 threads (the stand-alone radix_hist counts four per 1024-thread workgroup)
+__device__ __forceinline__ void radix_hist_tile_body(const SortBatch& sb, int pass_shift, uint32_t blk, uint32_t by, uint32_t* h) {
+  const SortJob& job = sb.j[by];
+  if (blk >= job.nblk) return;
+  const int shift = pass_shift + job.shift_base;
+  const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
+  const uint32_t* __restrict__ keys = job.kin + off;
+  const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
+  if ((uint64_t)blk * B3GS_SORT_TILE >= n) return;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blk * B3GS_SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+    const uint64_t i = base + k * B3GS_SORT_THREADS + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  job.hist[(size_t)threadIdx.x * hist_stride(job.nblk) + blk] = h[threadIdx.x];
+}
+
+template <bool HAS_VAL>
+union RepairShared {
+  uint32_t tmp[8];
+  uint32_t hist[256];
+  EmitShared emit;
+  ScatterShared<HAS_VAL> scatter;
+};
+
+template <bool HAS_VAL>
+__global__ void __launch_bounds__(256) repair_kernel(RepairArgs ra) {
+  __shared__ RepairShared<HAS_VAL> sh;
+  // anything to repair?  (word 3 of every view's image header, final since the blend forward completed)
+  bool any = false;
+  for (int v = 0; v < ra.sc.n; v++) any = any || ra.sc.j[v].img_header[3] != 0u;
+  if (!any) {
+    // segment 2 is empty: N2 = 0 was stored by the first scan, *n_out already holds N1
+    return;
+  }
+  const uint32_t G = gridDim.x, wg = blockIdx.x;
+  uint32_t phase = 0;
+  bool ok = true;
+#define REPAIR_SYNC()                                                   \
+  do {                                                                  \
+    ok = ok && grid_barrier(ra.barrier, ++phase * G);                   \
+    if (!ok) {                                                          \
+      if (threadIdx.x == 0) atomicOr(ra.barrier + 1, 1u);               \
+      return;                                                           \
+    }                                                                   \
+  } while (0)
+  const uint32_t nv = (uint32_t)ra.sc.n;
+  for (uint32_t b = wg; b < (uint32_t)ra.sc.nchunks * nv; b += G) {
+    scan2_chunk_sums_body(ra.sc, b % (uint32_t)ra.sc.nchunks, b / (uint32_t)ra.sc.nchunks, sh.tmp);
+    __syncthreads();
+  }
+  REPAIR_SYNC();
+  for (uint32_t b = wg; b < nv; b += G) {
+    scan2_chunk_offsets_body(ra.sc, b, sh.tmp);
+    __syncthreads();
+  }
+  REPAIR_SYNC();
+  for (uint32_t b = wg; b < (uint32_t)ra.sc.nchunks * nv; b += G) {
+    scan2_chunk_apply_body(ra.sc, b % (uint32_t)ra.sc.nchunks, b / (uint32_t)ra.sc.nchunks, sh.tmp);
+    __syncthreads();
+  }
+  REPAIR_SYNC();
+  for (uint32_t b = wg; b < ra.emit_blocks * nv; b += G) {
+    emit_instances_body<true>(ra.eb, b % ra.emit_blocks, b / ra.emit_blocks, sh.emit);
+    __syncthreads();
+  }
+  // radix tiles that hold instances of segment 2 (N2 is on the device since the second phase; the host only knows
+  // the capacity): the widest view bounds the loops below
+  uint32_t used_blk = 0;
+  for (uint32_t v = 0; v < nv; v++) {
+    const SortJob& j = ra.tb[0].j[v];
+    const uint32_t off = min(*j.off_ptr, j.n_cap);
+    const uint32_t n = min(*j.n_ptr, j.n_cap - off);
+    used_blk = max(used_blk, (n + (uint32_t)B3GS_SORT_TILE - 1u) / (uint32_t)B3GS_SORT_TILE);
+  }
+  used_blk = min(used_blk, ra.max_blk);
+  for (int p = 0; p < ra.passes; p++) {
+    const SortBatch& tb = ra.tb[p];
+    REPAIR_SYNC();
+    for (uint32_t b = wg; b < used_blk * nv; b += G) {
+      radix_hist_tile_body(tb, 8 * p, b % used_blk, b / used_blk, sh.hist);
+      __syncthreads();
+    }
+    REPAIR_SYNC();
+    for (uint32_t b = wg; b < 256u * nv; b += G) {
+      radix_rowscan_body(tb, b & 255u, b >> 8, sh.tmp);
+      __syncthreads();
+    }
+    REPAIR_SYNC();
+    for (uint32_t b = wg; b < used_blk * nv; b += G) {
+      radix_scatter_body<HAS_VAL, 8>(tb, 8 * p, b % used_blk, b / used_blk, sh.scatter);
+      __syncthreads();
+    }
+  }
+#undef REPAIR_SYNC
 }
 
 int tile_sort_passes(int W, int H) {
@@ -891,6 +1088,11 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   sc.K1 = K1;
   sc.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
+  sc.repair_barrier = (K1 < P && jobs[0].im.header) ? jobs[0].im.header + B3GS_HDR_REPAIR_BARRIER : nullptr;
+  if (sc.tiles_per_chunk * SCAN_ITEMS > SCAN_MAX_SUBS) {   // LDS sub-block sums of scan_chunk_sums (P < 2^24 keeps it at 32)
+    (void)b3gs_fail(B3GS_ERR_ARG, "b3gs_launch_depth_order_batch", "too many Gaussians for the scan's sub-block table");
+    return;
+  }
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
     const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
@@ -1012,9 +1214,13 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     sc.j[v] = Scan2Job{jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp, jb.g.header, jb.im.header, jb.n_out,
                        open_map(jb.im.open_rows, jb.W, jb.H)};
   }
-  hipLaunchKernelGGL(scan2_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
-  hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
-  hipLaunchKernelGGL(scan2_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  static const bool legacy = getenv("B3GS_ROUND2_LEGACY") != nullptr;
+  const bool one_launch = !legacy && passes >= 1 && passes <= 2 && jobs[0].im.header != nullptr;
+  if (!one_launch) {
+    hipLaunchKernelGGL(scan2_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+    hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
+    hipLaunchKernelGGL(scan2_chunk_apply, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  }
 
   // emission + stable split by tile id BEHIND segment 1 in the same ping-pong arrays (element offset N1 = header[0],
   // read on the device): the lists end in val[0] / key[0] like segment 1's, the ranges hold absolute positions
@@ -1054,6 +1260,37 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     }
   }
   if (max_cap == 0) return;
+  if (one_launch) {
+    // the whole round as one persistent launch (repair_kernel): exits at once when no tile is open
+    RepairArgs ra;
+    ra.sc = sc;
+    ra.eb = eb;
+    ra.passes = passes;
+    ra.emit_blocks = (uint32_t)((rest + 255) / 256);
+    ra.max_blk = 0;
+    bool any_val = false;
+    for (int v = 0; v < nviews; v++) {
+      ra.max_blk = tb.j[v].nblk > ra.max_blk ? tb.j[v].nblk : ra.max_blk;
+      any_val = any_val || tb.j[v].vout != nullptr;
+    }
+    for (int p = 0; p < 2; p++) {
+      ra.bits[p] = min(8, max(0, tbits - 8 * p));
+      if (p == passes - 1)
+        for (int v = 0; v < nviews; v++) tb.j[v].ranges = jobs[v].im.ranges2;
+      ra.tb[p] = tb;
+      for (int v = 0; v < nviews; v++) {
+        SortJob& j = tb.j[v];
+        const uint32_t* k = j.kin; const uint32_t* vv = j.vin;
+        j.kin = j.kout; j.vin = j.vout;
+        j.kout = const_cast<uint32_t*>(k); j.vout = const_cast<uint32_t*>(vv);
+      }
+    }
+    ra.barrier = jobs[0].im.header + B3GS_HDR_REPAIR_BARRIER;
+    static_assert(sizeof(RepairArgs) <= 4000, "kernel arguments of the repair kernel");
+    if (any_val) hipLaunchKernelGGL(repair_kernel<true>, dim3(REPAIR_GRID), dim3(256), 0, s, ra);
+    else hipLaunchKernelGGL(repair_kernel<false>, dim3(REPAIR_GRID), dim3(256), 0, s, ra);
+    return;
+  }
   hipLaunchKernelGGL(emit_instances<true>, dim3((rest + 255) / 256, nviews), dim3(256), 0, s, eb);
   for (int p = 0; p < passes; p++) {
     if (p == passes - 1)

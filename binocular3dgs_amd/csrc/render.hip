@@ -168,17 +168,13 @@ __device__ __forceinline__ float blend_power(const float4& A, float cyy, float d
 // Batching the views of an iteration into one launch lets the dispatcher pack ~11k tiles over the
 // machine (one view's 1900 tiles fill it exactly once, so every launch paid its own tail:
 // measured 126 us for one view, 446 us for six in one launch).
+// `bid` = default block index (tile of a view, see select_view / tile_of_block); `slot` = where a trace record goes
 template <int CHUNK, bool TRACE>
-__global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
-  __shared__ TileShared<CHUNK> sh;
+__device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, unsigned slot, TileShared<CHUNK>& sh,
+                                                uint32_t (&s_work)[4], unsigned long long* __restrict__ trace) {
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_chunks = 0;
-  // longest-tile-first order of the previous backward of this batch shape, if the buffer holds one (BlendBatch::sig)
-  int bid = (int)blockIdx.x;
-  if (batch.order && batch.order[batch.sig_off] == B3GS_ORDER_MAGIC && batch.order[batch.sig_off + 1] == batch.sig)
-    bid = 8 * (int)batch.order[(blockIdx.x & 7u) * (unsigned)batch.cls_size + (blockIdx.x >> 3)] + (int)(blockIdx.x & 7u);
-  const BlendView bv = select_view(batch, bid);
   const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
   const float4* __restrict__ rec = bv.rec;
   const float* __restrict__ bg = bv.bg;
@@ -253,7 +249,6 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
   // (all threads of the workgroup are still here: no early return above)
   const int all_done = (bv.round == 0 && bv.open_rows != nullptr) ? __syncthreads_and(Tw == 0.0f) : 1;
   {   // the tile's backward work: the deepest list position any of its pixels used
-    __shared__ uint32_t s_work[4];
     uint32_t m = last_contributor;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
@@ -281,6 +276,11 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
           const uint32_t lw = wq < tl.len1 ? tl.list1[tl.first1 + wq] : tl.list2[tl.first2 + (wq - tl.len1)];
           const float zdeep = reinterpret_cast<const float*>(rec + 4 * (size_t)(lw & bv.idx_mask) + 2)[1];
           if (!(__float_as_uint(zdeep) < *bv.z_clear)) atomicOr(&bv.pred_next[word], bit);
+        } else if (!predicted && bv.pred_next && 4u * work > 3u * tl.len1) {
+          // terminated, but only in the last quarter of its segment-1 prefix: one optimiser step can push it over the
+          // end (measured at the headline: a tile at that margin was left open every other iteration, and every such
+          // miss costs the repair kernel's slow path) -- give it its complete list next time
+          atomicOr(&bv.pred_next[word], bit);
         }
       }
     }
@@ -296,11 +296,41 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsig
     out_alpha[pix] = Ac;
   }
   if (TRACE && lane == 0) {
-    unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
+    unsigned long long* t = trace + 4 * ((size_t)slot * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
     t[2] = n_iter;
     t[3] = n_chunks;
+  }
+}
+
+template <int CHUNK, bool TRACE>
+__global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
+  __shared__ TileShared<CHUNK> sh;
+  __shared__ uint32_t s_work[4];
+  // longest-tile-first order of the previous backward of this batch shape, if the buffer holds one (BlendBatch::sig)
+  int bid = (int)blockIdx.x;
+  if (batch.order && batch.order[batch.sig_off] == B3GS_ORDER_MAGIC && batch.order[batch.sig_off + 1] == batch.sig)
+    bid = 8 * (int)batch.order[(blockIdx.x & 7u) * (unsigned)batch.cls_size + (blockIdx.x >> 3)] + (int)(blockIdx.x & 7u);
+  render_fwd_tile<CHUNK, TRACE>(select_view(batch, bid), bid, blockIdx.x, sh, s_work, trace);
+}
+
+// Second blend pass of a two-round forward (BlendView::round = 1) as a small persistent grid: in the steady state no
+// tile was left open (image header word 3 of every view is zero) and the launch is one look at those words; otherwise
+// the workgroups stride over all tiles and re-blend the ones that received a segment 2.
+constexpr int REBLEND_GRID = 1024;
+template <int CHUNK>
+__global__ void __launch_bounds__(256) render_fwd_repair_kernel(BlendBatch batch, int total) {
+  __shared__ TileShared<CHUNK> sh;
+  __shared__ uint32_t s_work[4];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < B3GS_MAX_FUSED_VIEWS; k++)
+    if (k < batch.n) any = any || *batch.v[k].open_count != 0u;
+  if (!any) return;
+  for (int bid = (int)blockIdx.x; bid < total; bid += (int)gridDim.x) {
+    render_fwd_tile<CHUNK, false>(select_view(batch, bid), bid, 0u, sh, s_work, nullptr);
+    __syncthreads();
   }
 }
 
@@ -654,6 +684,12 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
   batch.order = nullptr;
   batch.cls_size = total / 8;
   if (lpt && batch.order_buf && order_fits(batch, total, &batch.sig_off, &batch.sig)) batch.order = batch.order_buf;
+  if (batch.v[0].round != 0) {   // second pass of a two-round forward: small persistent grid, usually nothing to do
+    batch.order = nullptr;
+    hipLaunchKernelGGL((render_fwd_repair_kernel<FWD_CHUNK>), dim3(total < REBLEND_GRID ? total : REBLEND_GRID), dim3(256), 0, s,
+                       batch, total);
+    return;
+  }
   if (getenv("B3GS_FWD_TRACE"))  // debug: per-wave cycle trace (tools/bwd_trace.py fwd)
     hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, true>), dim3(total), dim3(256), 0, s, batch, trace_buffer(total));
   else

@@ -111,16 +111,14 @@ class FusedRasterizer:
         self._want_m2d = want_means2D
         # Two-round binning (schedule "batched"): bin the nearest seg1_fraction of the depth order, blend, bin the rest
         # only into the tiles that are not finished (B3gsForwardView.seg1_fraction; 0 or >= 1: one round).  It removes
-        # the emission and the tile split of every instance behind a tile's saturation point at the price of ~11 more
-        # launches (idle once the open-tile prediction has settled: the tiles a slot's previous forward left unterminated
-        # get their complete list in round 1).  Measured on MI355X: +3 % at 4.8M instances per view (1M Gaussians,
-        # 800x600: 559-563 vs 543-549 iters/s), +9 % over the pre-prediction two-round version at 3x larger splats
-        # (435 -> 475).  "auto", whenever fit_capacity() runs: from `two_round_min_instances` per view on, the forward is
-        # timed both ways and two rounds must win by `two_round_margin`.  The threshold keeps the choice deterministic
-        # where the gain is within the timing noise of a short eager probe (the headline workload: +3...5 % of an
-        # iteration; set seg1_fraction=0.125 to have it anyway -- bench.py reports it as extras.headline_two_round_binning).
-        self.two_round_min_instances = 6_000_000
-        self.two_round_margin = 0.05
+        # the emission and the tile split of every instance behind a tile's saturation point.  The tiles a slot's previous
+        # forward left unterminated -- or saw terminate only in the last quarter of their segment-1 prefix -- are predicted
+        # open and get their complete list in round 1; the second round is ONE persistent launch (binning.hip
+        # repair_kernel) that exits at once when the prediction held.  "auto" is a deterministic rule applied whenever
+        # fit_capacity() runs: two rounds from `two_round_min_instances` tile instances per view on (measured on MI355X,
+        # 800x600, 6 views, tools/sizes_ab.sh: 0.44M instances per view -3 %, 1.2M -2 %, 2.4M +3 %, 4.8M +7 %, 9.6M
+        # +16 %), with segment 1 sized for ~0.75M instances of a view.
+        self.two_round_min_instances = 2_000_000
         self._seg1_auto = seg1_fraction == "auto"
         self.seg1_fraction = 0.0 if self._seg1_auto else float(seg1_fraction)
         # N of every slot's last forward lives on the device (no read-back per view); `high_water` keeps the largest N
@@ -377,10 +375,22 @@ class FusedRasterizer:
         sizes the binning buffer from N on every render: one blocking read-back per view.)"""
         hw = int(self.high_water.max().item())
         self.high_water.zero_()
+        self._check_repair_status()
         if hw <= self.capacity:
             return 0
         self.grow(need=hw)
         return hw
+
+    def _check_repair_status(self):
+        """Word 9 of slot 0's image header: bit 0 is set when a grid barrier of the second binning round's persistent
+        kernel timed out (a workgroup of its grid never became resident) -- that forward's repaired tiles are wrong."""
+        if self.seg1_fraction <= 0.0 or not self.slots:
+            return
+        st = int(self.slots[0].img[:48].view(torch.int32)[9].item())
+        if st:
+            self.slots[0].img[:48].view(torch.int32)[9] = 0
+            raise _lib.B3gsError("B3GS_ERR_HIP: the second binning round's grid barrier timed out; repeat the steps since "
+                                 "the last check (FusedRasterizer(seg1_fraction=0) selects one-round binning)")
 
     def fit_capacity(self, views: Sequence, bg_color: torch.Tensor, margin: float = 1.3) -> int:
         """Size the persistent binning buffers from the actual N of `views` ([(camera, slot), ...]): one forward without
@@ -397,27 +407,8 @@ class FusedRasterizer:
         # (the ones the previous forward of that slot left unterminated); segment 1 sized for ~0.75M instances of a view
         self.seg1_fraction = (0.0 if need < self.two_round_min_instances else min(0.125, max(0.02, 0.75e6 / need))) \
             if self._seg1_auto else frac
-        if self._seg1_auto and self.seg1_fraction > 0.0:
-            # ... unless it does not pay on THIS scene (few tiles terminate, or the views of a slot change so much that
-            # the prediction keeps missing): time the forward both ways -- prediction settled: three warm-up forwards --
-            # and keep the faster (a few forwards at set-up and after a densification).
-            cand, best = self.seg1_fraction, None
-            for frac_try in (0.0, cand):
-                self.seg1_fraction = frac_try
-                with torch.no_grad():
-                    for _ in range(3):
-                        self.render_batch([(v[0], v[1]) for v in views], bg_color)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(3):
-                        self.render_batch([(v[0], v[1]) for v in views], bg_color)
-                    e1.record()
-                torch.cuda.synchronize(self.dev)
-                ms = e0.elapsed_time(e1)
-                # two rounds carry state (the prediction) and ~11 more launches: they must beat one round's forward by
-                # a margin, else the simpler pipeline stays
-                if best is None or ms < best[0] * (1.0 - self.two_round_margin):
-                    best = (ms, frac_try)
-            self.seg1_fraction = best[1]
+        if self.seg1_fraction > 0.0:
+            with torch.no_grad():     # one forward settles the open-tile prediction (the first one repairs many tiles)
+                self.render_batch([(v[0], v[1]) for v in views], bg_color)
             self.high_water.zero_()
         return self.capacity
