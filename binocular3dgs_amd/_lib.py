@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("B3GS_LIB") or os.path.join(_HERE, "libb3gs_raster.so")   # B3GS_LIB: A/B builds of the kernels
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -55,7 +55,8 @@ class B3gsForwardView(C.Structure):
     _fields_ = [("view", C.POINTER(B3gsScene)), ("geometry", C.c_void_p), ("binning", C.c_void_p),
                 ("binning_capacity", C.c_int64), ("image", C.c_void_p), ("out_color", C.c_void_p),
                 ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
-                ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32), ("seg1_fraction", C.c_float)]
+                ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32), ("seg1_fraction", C.c_float),
+                ("high_water", C.c_void_p), ("overflow_flag", C.c_void_p)]
 
 
 class B3gsLossIO(C.Structure):
@@ -80,7 +81,8 @@ class B3gsAdamSegment(C.Structure):
 
 
 class B3gsDensifyStats(C.Structure):
-    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p)]
+    _fields_ = [("xyz_gradient_accum", C.c_void_p), ("denom", C.c_void_p), ("max_radii2D", C.c_void_p),
+                ("skip_if_nonzero", C.c_void_p)]
 
 
 class B3gsDebugViews(C.Structure):
@@ -182,7 +184,7 @@ def lib():
     L.b3gs_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_knn_mean_dist2.restype = C.c_int
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+                                 C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int

@@ -345,7 +345,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     pb.sc[k] = sc;
     pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
     jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr,
-                     nullptr, 1, 0};
+                     nullptr, 1, 0, fv.high_water, fv.overflow_flag};
     bb.v[k] = b3gs_blend_view(sc, g, b, im);
     bb.v[k].open_rows = im.open_rows;
     bb.v[k].out_color = fv.out_color;
@@ -556,6 +556,7 @@ int b3gs_blend_forward_batch(int32_t nviews, const B3gsBlendView* views, b3gs_st
     b3gs_img_view(const_cast<char*>(bv.image), bv.view->W, bv.view->H, &im);
     b3gs_bin_view(const_cast<char*>(bv.binning), bv.view->P, bv.binning_capacity > 0 ? bv.binning_capacity : 1, &b);
     batch.v[k] = b3gs_blend_view(*bv.view, g, b, im);
+    batch.v[k].round = 2;   // the state may come from a two-round forward: every tile walks segment 1 + segment 2
     batch.v[k].out_color = bv.out_color;
     batch.v[k].out_depth = bv.out_depth;
     batch.v[k].out_alpha = bv.out_alpha;

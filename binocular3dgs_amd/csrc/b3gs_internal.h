@@ -240,6 +240,9 @@ struct BinJob {
   // receive the Gaussians behind K1 in segment 1 -- their complete list in one round; segment 2 then only repairs the
   // tiles the prediction missed (none once it has settled).  Any bitmap gives the same images: it only moves work.
   int32_t K1;
+  // ABI 6 (optional): high_water <- max(high_water, N); overflow_flag <- 1 when N > n_bound (B3gsForwardView)
+  int32_t* high_water = nullptr;
+  int32_t* overflow_flag = nullptr;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,
@@ -268,7 +271,8 @@ struct BlendView {
   unsigned long long* pred_next;         //   ... and the prediction for the next forward (every unterminated tile, and the
   const uint32_t* z_clear; //   predicted ones that needed more than the depth key *z_clear = rank 3/4 K1 of the order)
   int32_t row_words;       //   64-bit words per tile row of the bitmap
-  int32_t round;           // forward: 0 = first pass over all tiles; 1 = second pass, only tiles with a segment 2
+  int32_t round;           // forward: 0 = first pass over all tiles (segment 1); 1 = second pass, only tiles with a segment 2;
+                           //          2 = all tiles over segment 1 + segment 2 (re-blend of a finished forward's state)
   uint32_t idx_mask;       // Gaussian index = point_list[j] & idx_mask (packed tile|index words, see b3gs_packed_idx_bits)
   const float4* rec;
   const float* bg;

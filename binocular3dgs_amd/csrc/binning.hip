@@ -107,6 +107,9 @@ struct ScanJob {
   int32_t* n_out;
   uint32_t* scount;         // two-round: instance count of every Gaussian behind K1 (its tiles predicted open), depth order
   OpenMap pred;             // two-round: the tiles predicted open
+  int32_t* high_water;      // optional: max(N) over the forwards since the host last looked
+  int32_t* overflow_flag;   // optional: set when N exceeds n_bound (the lists of this view are truncated)
+  uint32_t n_bound;
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
@@ -373,6 +376,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
     job.header[2] = 0u;    // N2: set by the second binning round, if one runs
     if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; job.img_header[2] = 0u; job.img_header[3] = 0u; }
     if (job.n_out) *job.n_out = (int32_t)tot;
+    if (job.high_water) atomicMax(job.high_water, (int32_t)min(tot, 0x7FFFFFFFu));
+    if (job.overflow_flag && tot > job.n_bound) atomicOr(job.overflow_flag, 1);
   }
 }
 
@@ -739,6 +744,9 @@ struct Scan2Job {
   uint32_t* img_header;
   int32_t* n_out;           // *n_out = N1 + N2
   OpenMap open;
+  int32_t* high_water;      // as ScanJob's, for N1 + N2
+  int32_t* overflow_flag;
+  uint32_t n_bound;
 };
 struct Scan2Batch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;
@@ -799,7 +807,10 @@ __device__ __forceinline__ void scan2_chunk_offsets_body(const Scan2Batch& sb, u
   if (threadIdx.x == 0) {
     job.header[2] = tot;   // N2
     if (job.img_header) job.img_header[2] = tot;
-    if (job.n_out) *job.n_out = (int32_t)(job.header[0] + tot);
+    const uint32_t n12 = job.header[0] + tot;
+    if (job.n_out) *job.n_out = (int32_t)n12;
+    if (job.high_water) atomicMax(job.high_water, (int32_t)min(n12, 0x7FFFFFFFu));
+    if (job.overflow_flag && n12 > job.n_bound) atomicOr(job.overflow_flag, 1);
   }
 }
 
@@ -1099,7 +1110,8 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     const int32_t rstride = jb.rect ? jb.rect_stride : 1;
     sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
                       jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
-                      open_map(jb.im.pred_rows, jb.W, jb.H)};
+                      open_map(jb.im.pred_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
+                      (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0)};
   }
   // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
   // into d's gather
@@ -1212,7 +1224,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
     sc.j[v] = Scan2Job{jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp, jb.g.header, jb.im.header, jb.n_out,
-                       open_map(jb.im.open_rows, jb.W, jb.H)};
+                       open_map(jb.im.open_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
+                       (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0)};
   }
   static const bool legacy = getenv("B3GS_ROUND2_LEGACY") != nullptr;
   const bool one_launch = !legacy && passes >= 1 && passes <= 2 && jobs[0].im.header != nullptr;

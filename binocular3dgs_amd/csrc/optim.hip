@@ -16,10 +16,6 @@ struct AdamSegs {
   uint32_t start[9];  // cumulative element offsets
 };
 
-// workgroup-completion counter of the in-kernel step bump (left at zero by every launch; launches that bump are ordered
-// on one stream -- optimisers stepping concurrently on several streams of one device would need a counter each)
-__device__ uint32_t g_adam_done = 0u;
-
 // One element's update; returns the new parameter value.
 __device__ __forceinline__ float adam_one(float pi, float grad, float& mi, float& vi, float beta1, float beta2, float eps,
                                           float bc1, float bc2_sqrt, float lr, bool decay, float opacity_decay,
@@ -45,7 +41,10 @@ __device__ __forceinline__ float adam_one(float pi, float grad, float& mi, float
 template <int VEC>
 __global__ void __launch_bounds__(256)
     adam_kernel(AdamSegs segs, int32_t* __restrict__ step_ptr, int bump, float beta1, float beta2, float eps,
-                float opacity_decay, int opacity_seg, int decay_first, const unsigned long long* __restrict__ row_mask) {
+                float opacity_decay, int opacity_seg, int decay_first, const unsigned long long* __restrict__ row_mask,
+                const int32_t* __restrict__ skip_if_nonzero) {
+  // a step rendered from truncated tile lists (B3gsForwardView::overflow_flag) is dropped here, on the device
+  if (skip_if_nonzero && *skip_if_nonzero != 0) return;
   const float t = (float)(*step_ptr + 1);
   const float bc1 = 1.0f - powf(beta1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
@@ -107,23 +106,29 @@ __global__ void __launch_bounds__(256)
       p[e] = pi;
     }
   }
-  // the workgroup that finishes last advances the step counter (every workgroup has read it by then): no second launch
+  // the workgroup that finishes last advances the step counter (every workgroup has read it by then): no second launch.
+  // The completion counter is the optimiser's own word next to its step (step_ptr[1], zero between launches).
   if (bump) {
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&g_adam_done, 1u) == gridDim.x - 1u) {
-      g_adam_done = 0u;
+    uint32_t* done = reinterpret_cast<uint32_t*>(step_ptr + 1);
+    if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1u) {
+      *done = 0u;
       *step_ptr += 1;
     }
   }
 }
 
-__global__ void bump_step(int32_t* step_ptr) { *step_ptr += 1; }
+__global__ void bump_step(int32_t* step_ptr, const int32_t* skip_if_nonzero) {
+  if (skip_if_nonzero && *skip_if_nonzero != 0) return;
+  *step_ptr += 1;
+}
 
 }  // namespace
 
 extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
                               float eps, float opacity_decay, int32_t opacity_segment, int32_t opacity_decay_first,
-                              int32_t bump_step_after, const uint64_t* row_mask, b3gs_stream_t stream) {
+                              int32_t bump_step_after, const uint64_t* row_mask, const int32_t* skip_if_nonzero,
+                              b3gs_stream_t stream) {
   if (nseg < 0 || nseg > 8 || (nseg > 0 && !segs) || !device_step)
     return b3gs_fail(B3GS_ERR_ARG, "b3gs_adam_step", "0..8 segments and a device step counter are required");
   AdamSegs a;
@@ -149,7 +154,7 @@ extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t
   a.start[nseg] = (uint32_t)tot;
   for (int k = nseg + 1; k < 9; k++) a.start[k] = (uint32_t)tot;
   if (tot == 0) {   // nothing to update (a rank whose shard is all padding); the step still counts
-    if (bump_step_after) hipLaunchKernelGGL(bump_step, dim3(1), dim3(1), 0, (hipStream_t)stream, device_step);
+    if (bump_step_after) hipLaunchKernelGGL(bump_step, dim3(1), dim3(1), 0, (hipStream_t)stream, device_step, skip_if_nonzero);
     return b3gs_launch_status("b3gs_adam_step");
   }
   hipStream_t s = (hipStream_t)stream;
@@ -158,9 +163,9 @@ extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(row_mask);
   if (vec4)
     hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
-                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask);
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero);
   else
     hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
-                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask);
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero);
   return b3gs_launch_status("b3gs_adam_step");
 }

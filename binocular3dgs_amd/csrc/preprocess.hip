@@ -714,6 +714,8 @@ __global__ void __launch_bounds__(256, 8)
   const unsigned lane = threadIdx.x & 63u;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int nrest = 3 * (base.M - 1);
+  // a step rendered from truncated tile lists leaves the densification statistics alone (B3gsDensifyStats)
+  const bool skip_stats = ds.skip_if_nonzero && *ds.skip_if_nonzero != 0;
 
   // ---- phase 1 ------------------------------------------------------------------------------------------
 #pragma unroll 1
@@ -747,7 +749,7 @@ __global__ void __launch_bounds__(256, 8)
           st_rad = max(st_rad, rad);
         }
       }
-      if (ds.denom && st_cnt > 0.f) {
+      if (ds.denom && st_cnt > 0.f && !skip_stats) {
         ds.xyz_gradient_accum[i] += st_norm;
         ds.denom[i] += st_cnt;
         ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
@@ -921,7 +923,7 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   MultiViews mv;
   mv.n = nviews;
   for (int v = 0; v < nviews; v++) mv.v[v] = views[v];
-  const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr};
+  const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr, nullptr};
   // scratch of the two-kernel pass: the depth-sort ping-pong arrays of view 0's geometry buffer (P words each) are idle
   // once the forward has built its tile lists
   const dim3 grid((count + ACC_BLOCK - 1) / ACC_BLOCK);

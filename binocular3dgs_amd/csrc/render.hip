@@ -193,9 +193,10 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
   const float fpx = (float)px, fpy = (float)py;
   // round 0: every tile, segment 1 only, and the per-tile "all pixels terminated" flag; round 1 (after the second
   // binning round): only the tiles that received a segment 2, recomputed over segment 1 + segment 2
-  if (bv.round != 0 && *bv.open_count == 0u) return;   // no tile of this view was left open: nothing to redo
+  // round 2 (b3gs_blend_forward_batch: re-blending a finished forward's state): every tile, both segments
+  if (bv.round == 1 && *bv.open_count == 0u) return;   // no tile of this view was left open: nothing to redo
   const TileList tl = tile_list(bv, tile, bv.round != 0);
-  if (bv.round != 0 && tl.total == tl.len1) return;
+  if (bv.round == 1 && tl.total == tl.len1) return;
   const int nchunks = (int)((tl.total + CHUNK - 1) / CHUNK);
 
   // A finished pixel is encoded as Tw == 0 (working transmittance): every later weight is then exactly zero, the
@@ -684,7 +685,7 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
   batch.order = nullptr;
   batch.cls_size = total / 8;
   if (lpt && batch.order_buf && order_fits(batch, total, &batch.sig_off, &batch.sig)) batch.order = batch.order_buf;
-  if (batch.v[0].round != 0) {   // second pass of a two-round forward: small persistent grid, usually nothing to do
+  if (batch.v[0].round == 1) {   // second pass of a two-round forward: small persistent grid, usually nothing to do
     batch.order = nullptr;
     hipLaunchKernelGGL((render_fwd_repair_kernel<FWD_CHUNK>), dim3(total < REBLEND_GRID ? total : REBLEND_GRID), dim3(256), 0, s,
                        batch, total);

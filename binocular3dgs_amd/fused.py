@@ -125,6 +125,10 @@ class FusedRasterizer:
         # seen since the last check_overflow(), updated by one tiny kernel per forward (graph-capturable)
         self._n_all = torch.zeros((num_slots,), dtype=torch.int32, device=self.dev)
         self.high_water = torch.zeros((num_slots,), dtype=torch.int32, device=self.dev)
+        # ... and a sticky device flag set by the binning kernels when a view's N exceeded the capacity (truncated lists):
+        # the optimiser and the densification statistics skip every step while it is set (B3gsForwardView::overflow_flag,
+        # b3gs_adam_step(skip_if_nonzero)), so check_overflow() finds the state of the last complete step
+        self.overflow_flag = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev), k) for k in range(num_slots)]
         self._deferred = None   # [(spec, B3gsScene)] while a deferred-accumulate section is open
         self._params = _lib.B3gsRawParams()
@@ -185,7 +189,9 @@ class FusedRasterizer:
 
     def _forward_batch(self, specs):
         self._forward_batch_launch(specs)
-        torch.maximum(self.high_water, self._n_all, out=self.high_water)
+        if self.schedule != "batched":    # (the batched launches update both words inside the binning kernels)
+            torch.maximum(self.high_water, self._n_all, out=self.high_water)
+            self.overflow_flag.bitwise_or_((self._n_all > self.capacity).any().to(torch.int32))
 
     def _forward_batch_launch(self, specs):
         L = _lib.lib()
@@ -208,6 +214,8 @@ class FusedRasterizer:
                     donor = getattr(sp["cam"], "same_depth_as", None)
                     arr[k].depth_order_from = -1
                     arr[k].seg1_fraction = self.seg1_fraction
+                    arr[k].high_water = self.high_water[sp["slot"]:sp["slot"] + 1].data_ptr()
+                    arr[k].overflow_flag = self.overflow_flag.data_ptr()
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
@@ -269,7 +277,8 @@ class FusedRasterizer:
         count = self.P - first if count is None else count
         stats = None
         if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
-            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr())
+            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr(),
+                                          self.overflow_flag.data_ptr())
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         for c0 in range(0, len(pend), MAX_BATCH):
             chunk = pend[c0:c0 + MAX_BATCH]
@@ -351,6 +360,7 @@ class FusedRasterizer:
         for i in range(len(self.slots)):
             self.slots[i] = self._new_slot(self.slots[i].stream, i)
         self.high_water.zero_()
+        self.overflow_flag.zero_()
 
     def num_rendered(self):
         """Host copy of every slot's N (synchronises).  N > capacity means that view was rendered
@@ -369,17 +379,21 @@ class FusedRasterizer:
         self.high_water.zero_()
 
     def check_overflow(self) -> int:
-        """One small read-back: the largest N any view produced since the last check.  Returns 0 when every list
-        fitted; otherwise grows the buffers (1.5 x what was needed) and returns that N -- the views of the
-        overflowing forwards were rendered from truncated lists, so the caller repeats those steps.  (The reference
-        sizes the binning buffer from N on every render: one blocking read-back per view.)"""
+        """One small read-back: the largest N any view produced since the last check, and the sticky overflow flag.
+        Returns 0 when every list fitted; otherwise grows the buffers (1.5 x what was needed), clears the flag and
+        returns that N.  From the overflowing step on, the optimiser update and the densification statistics were
+        dropped ON THE DEVICE (the Adam launch and the chain-rule pass read the flag), so the model is in the state of
+        the last complete step and the caller simply repeats from there.  (The reference sizes the binning buffer from
+        N on every render: one blocking read-back per view.)"""
         hw = int(self.high_water.max().item())
+        flagged = bool(int(self.overflow_flag.item()))
         self.high_water.zero_()
         self._check_repair_status()
-        if hw <= self.capacity:
+        if hw <= self.capacity and not flagged:
             return 0
+        self.overflow_flag.zero_()
         self.grow(need=hw)
-        return hw
+        return max(hw, 1)
 
     def _check_repair_status(self):
         """Word 9 of slot 0's image header: bit 0 is set when a grid barrier of the second binning round's persistent
@@ -401,6 +415,7 @@ class FusedRasterizer:
             self.render_batch([(v[0], v[1]) for v in views], bg_color)
         need = max(self.num_rendered())
         self.high_water.zero_()
+        self.overflow_flag.zero_()       # (a too-small start-up capacity is what this call is here to fix)
         if need * margin > self.capacity:
             self.grow(factor=margin, need=need)
         # two rounds: the nearest fraction of the depth order everywhere + the rest into the tiles predicted open

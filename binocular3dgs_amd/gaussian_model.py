@@ -3,8 +3,9 @@
 Same attribute and accessor names as the reference (`_xyz`, `_features_dc`, `_features_rest`,
 `_scaling`, `_rotation`, `_opacity`; `get_xyz`, `get_scaling`, `get_rotation`, `get_features`,
 `get_opacity`, `get_covariance`, `active_sh_degree`, `max_sh_degree`, `oneupSHdegree`:
-scene/gaussian_model.py:24-60,95-122), so render() accepts either class.  Densification, PLY I/O and
-the optimiser are "next" rows and deliberately absent.
+scene/gaussian_model.py:24-60,95-122), so render() accepts either class.  The "next" rows of SURVEY.md section 8f live
+beside it: densification (densify.py), PLY I/O and k-NN initialisation (init_points.py), the optimisers (step.py) and
+the checkpoint tuple (`capture()` / `restore()`, checkpoint.py).
 """
 from __future__ import annotations
 
@@ -41,6 +42,8 @@ class GaussianModel:
         e = torch.empty(0)
         self._xyz, self._features_dc, self._features_rest = e, e, e
         self._scaling, self._rotation, self._opacity = e, e, e
+        self.optimizer = None            # scene/gaussian_model.py:56-58
+        self.spatial_lr_scale = 0
 
     @classmethod
     def from_tensors(cls, xyz, features_dc, features_rest, scaling, rotation, opacity, sh_degree=1,
@@ -73,6 +76,21 @@ class GaussianModel:
         """train.py:178"""
         self.max_radii2D[visibility_filter] = torch.max(self.max_radii2D[visibility_filter],
                                                         radii[visibility_filter].float())
+
+    # ---- checkpoint tuple (scene/gaussian_model.py:61-93, train.py:41-43,200-202) ----------------------------
+    def capture(self, optimizer=None):
+        """The reference's 12-tuple; the optimiser entry has torch.optim.Adam's state_dict() layout whatever optimiser
+        of this build is in use (checkpoint.py)."""
+        from .checkpoint import capture
+        return capture(self, optimizer)
+
+    def restore(self, model_args, training_args=None, optimizer=None, optimizer_factory=None):
+        """Put a captured tuple (of this build or of the reference) back.  `training_args` is accepted for signature
+        compatibility with the reference (which rebuilds its optimiser from it); here the optimiser is passed in, or
+        built by `optimizer_factory(model)` once the parameters are in place."""
+        from .checkpoint import restore
+        del training_args
+        return restore(self, model_args, optimizer if optimizer is not None else self.optimizer, optimizer_factory)
 
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation, self._opacity]

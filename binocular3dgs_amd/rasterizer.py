@@ -16,6 +16,7 @@ CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import atexit
 import os
 from typing import NamedTuple, Optional
 
@@ -108,18 +109,24 @@ def _scene(background, means3D, colors, opacity, scales, rotations, scale_modifi
 
 
 class _LazyN:
-    """Sync-free forward of the autograd surface: the one blocking read-back of num_rendered per forward (upstream
-    sizes the binning buffer from it; `api.hip`: b3gs_forward) is paid only by the FIRST render of a (device, P, W, H)
-    shape.  Later renders of that shape run b3gs_forward_capacity with a binning buffer of twice the largest N seen, N
-    stays on the device and travels to pinned host memory behind the kernels; it is looked at when its copy has
-    completed -- normally at the next render -- to grow the capacity while N is still below it.  An N above the
-    capacity (the list of that render was truncated) raises B3gsError at that point: one call late, never silently.
-    P changes at every densification, so each new Gaussian set starts with an exact, synchronous render."""
+    """Sync-free forward of the autograd surface, TRAINING renders only: the one blocking read-back of num_rendered per
+    forward (upstream sizes the binning buffer from it; `api.hip`: b3gs_forward) is paid by the FIRST render of a
+    (device, P, W, H) shape and by every render that will not be differentiated (no input requires a gradient: evaluation
+    loops, render.py-style scripts -- they get the exact, synchronous forward).  Later differentiated renders of the shape
+    run b3gs_forward_capacity with a binning buffer of twice the largest N seen; N stays on the device and travels to
+    pinned host memory behind the kernels.  It is looked at
+      * at the entry of that render's BACKWARD (the loss sits between the two, so the copy has long completed): an N
+        above the capacity -- the image and the loss were computed from truncated tile lists -- raises B3gsError there,
+        i.e. before any gradient exists and before `optimizer.step()` of train.py:149-197 can consume it;
+      * at the next render (capacity grown while N is still inside it; renders whose backward never ran are checked here);
+      * at interpreter exit (a warning for anything still unchecked).
+    P changes at every densification, so each new Gaussian set starts with an exact, synchronous render.
+    B3GS_DROPIN_SYNC=1 selects the synchronous forward everywhere."""
     HEADROOM, REGROW_AT, RING = 2.0, 0.6, 64
 
     def __init__(self):
         self.capacity = {}     # (device index, P, W, H) -> instances the binning buffer is sized for
-        self.pending = []      # [(key, capacity used, pinned int32[1], event)]
+        self.pending = []      # [token] = [key, capacity used, pinned int32[1], event, checked]
         self.pinned = None
         self.slot = 0
         self.enabled = os.environ.get("B3GS_DROPIN_SYNC", "0") != "1"
@@ -127,24 +134,44 @@ class _LazyN:
     def note(self, key, n):
         self.capacity[key] = max(self.capacity.get(key, 0), int(n * self.HEADROOM), 1 << 16)
 
+    def _resolve(self, tok):
+        """wait for the token's copy, grow the capacity; returns (n, cap) when that render overflowed, else None"""
+        key, cap, host, ev, _ = tok
+        ev.synchronize()
+        tok[4] = True
+        n = int(host[0])
+        if n > cap * self.REGROW_AT:
+            self.note(key, n)
+        return (n, cap) if n > cap else None
+
+    def _error(self, key, n, cap, when):
+        return _lib.B3gsError(f"B3GS_ERR_CAPACITY: {when} render of shape {key[1:]} produced {n} tile instances, its "
+                              f"binning buffer held {cap} (truncated lists); the capacity is now {self.capacity[key]} "
+                              f"-- repeat the step")
+
     def poll(self, force=False):
         keep, over = [], None
-        for key, cap, host, ev in self.pending:
-            if not (force or ev.query()):
-                keep.append((key, cap, host, ev))
+        for tok in self.pending:
+            if tok[4]:
                 continue
-            ev.synchronize()
-            n = int(host[0])
-            if n > cap * self.REGROW_AT:
-                self.note(key, n)
-            if n > cap and over is None:
-                over = (key, n, cap)
+            if not (force or tok[3].query()):
+                keep.append(tok)
+                continue
+            r = self._resolve(tok)
+            if r is not None and over is None:
+                over = (tok[0],) + r
         self.pending = keep
         if over is not None:
-            key, n, cap = over
-            raise _lib.B3gsError(f"B3GS_ERR_CAPACITY: an earlier render of shape {key[1:]} produced {n} tile instances, its "
-                                 f"binning buffer held {cap} (truncated lists); the capacity is now {self.capacity[key]} "
-                                 f"-- repeat the step")
+            raise self._error(over[0], over[1], over[2], "an earlier")
+
+    def confirm(self, tok):
+        """Backward entry: this render's N must have fitted its buffer."""
+        if tok is None or tok[4]:
+            return
+        r = self._resolve(tok)
+        self.pending = [t for t in self.pending if t is not tok]
+        if r is not None:
+            raise self._error(tok[0], r[0], r[1], "this")
 
     def track(self, key, cap, n_dev):
         if self.pinned is None:
@@ -156,14 +183,25 @@ class _LazyN:
         host.copy_(n_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(n_dev.device))
-        self.pending.append((key, cap, host, ev))
+        tok = [key, cap, host, ev, False]
+        self.pending.append(tok)
+        return tok
+
+    def flush_at_exit(self):
+        try:
+            self.poll(force=True)
+        except Exception as exc:   # nothing can repeat the step any more: say so
+            import sys
+            print(f"[binocular3dgs_amd] WARNING at exit: {exc}", file=sys.stderr)
 
 
 _lazy = _LazyN()
+atexit.register(_lazy.flush_at_exit)
 
 
 class _CModule:
     """Stands in for the `_C` torch-extension module of the upstream package."""
+    last_lazy_token = None   # set by a sync-free forward: what _RasterizeGaussians.backward confirms
 
     @staticmethod
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -199,7 +237,7 @@ class _CModule:
                                                  color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii),
                                                  n_dev.data_ptr(), _stream(dev))
                     _lib.check(rc, "b3gs_forward_capacity")
-                    _lazy.track(key, cap, n_dev)
+                    _CModule.last_lazy_token = _lazy.track(key, cap, n_dev)
                 del keep
                 return cap, color, depth, alpha, radii, geom, binning, img
         bufs = {}
@@ -218,8 +256,8 @@ class _CModule:
                                 depth.data_ptr(), alpha.data_ptr(), _ptr(radii), C.byref(n), _stream(dev))
         _lib.check(rc, "b3gs_forward")
         del keep
-        if lazy_num_rendered:
-            _lazy.note(key, int(n.value))
+        if P > 0:
+            _lazy.note(key, int(n.value))     # every exact render teaches the capacity of its shape
         return (int(n.value), color, depth, alpha, radii, bufs["geom"],
                 bufs.get("binning", torch.empty(0, dtype=torch.uint8, device=dev)), bufs["img"])
 
@@ -283,19 +321,32 @@ _C = _CModule()
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    # will this render be differentiated?  (grad mode is invisible inside autograd.Function.forward, and
+    # ctx.needs_input_grad reflects requires_grad even under torch.no_grad())
+    differentiated = torch.is_grad_enabled() and any(
+        torch.is_tensor(t) and t.requires_grad
+        for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, differentiated)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, differentiated=None):
+        """`differentiated` (set by rasterize_gaussians(); absent when the Function is applied directly with the
+        upstream's nine arguments): the caller will run backward() on this render -- only then may the forward skip the
+        read-back of num_rendered (_LazyN); otherwise it is the exact synchronous forward."""
         rs = raster_settings
+        ctx.n_inputs = 9 if differentiated is None else 10
+        # sync-free only when this render will be differentiated: its backward then checks N before any gradient is
+        # produced; a render nobody differentiates (evaluation) takes the exact synchronous forward
+        _CModule.last_lazy_token = None
         num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, lazy_num_rendered=True)
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, lazy_num_rendered=bool(differentiated))
+        ctx.lazy_token, _CModule.last_lazy_token = _CModule.last_lazy_token, None
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom,
@@ -306,6 +357,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         rs = ctx.raster_settings
+        _lazy.confirm(ctx.lazy_token)   # raises when this render's tile lists were truncated: no gradient leaves here
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = \
             ctx.saved_tensors
         if grad_color is None:
@@ -326,7 +378,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (pick(grad_means3D, True, 0), pick(grad_means2D, True, 1), pick(grad_sh, sh.numel() != 0, 2),
                 pick(grad_colors_precomp, colors_precomp.numel() != 0, 3), pick(grad_opacities, True, 4),
                 pick(grad_scales, scales.numel() != 0, 5), pick(grad_rotations, rotations.numel() != 0, 6),
-                pick(grad_cov3Ds_precomp, cov3Ds_precomp.numel() != 0, 7), None)
+                pick(grad_cov3Ds_precomp, cov3Ds_precomp.numel() != 0, 7), None, None)[:ctx.n_inputs]
 
 
 class GaussianRasterizer(nn.Module):

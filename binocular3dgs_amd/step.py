@@ -76,9 +76,17 @@ class FlatGradSlab:
         return self.flat.numel() * 4
 
 
-def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev, row_mask=None):
+def _step_words(dev):
+    """{step, completion counter of the in-kernel bump}: the two int32 words b3gs_adam_step's `device_step` points to
+    (ABI 6); `[:1]` of it is the optimiser's `step_count`."""
+    return torch.zeros(2, dtype=torch.int32, device=dev)
+
+
+def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev, row_mask=None,
+                 skip_flag=None):
     """One b3gs_adam_step launch over [(param_ptr, grad_ptr, m_ptr, v_ptr, count, lr[, row_len, first_row]), ...] (at
-    most 8).  row_mask: the int64 touched-rows bitmap of a sparse-row gradient slab (segments then carry row_len)."""
+    most 8).  row_mask: the int64 touched-rows bitmap of a sparse-row gradient slab (segments then carry row_len).
+    skip_flag: device int32; != 0 at launch time turns the call into a no-op (overflowed step, B3gsForwardView)."""
     from . import _lib
     segs = (_lib.B3gsAdamSegment * max(len(segs_py), 1))()
     for k, seg in enumerate(segs_py):
@@ -89,6 +97,7 @@ def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, de
     rc = _lib.lib().b3gs_adam_step(len(segs_py), segs, step_count.data_ptr(), betas[0], betas[1], eps,
                                    float(opacity_decay), int(opacity_seg), int(bool(decay_first)), int(bool(bump)),
                                    None if row_mask is None else row_mask.data_ptr(),
+                                   None if skip_flag is None else skip_flag.data_ptr(),
                                    torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc, "b3gs_adam_step")
 
@@ -110,10 +119,12 @@ class FusedAdam:
         total = sum(p.numel() for p in self.params)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._step_words = _step_words(dev)
+        self.step_count = self._step_words[:1]
         self.betas, self.eps = betas, float(eps)
         self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
         self.decay_first = bool(decay_first)
+        self.skip_flag = None    # device int32: != 0 drops the update on the device (ViewShardedStep sets it)
 
     def step(self, row_mask: Optional[torch.Tensor] = None):
         """row_mask: the touched-rows bitmap of a sparse-row gradient slab (FusedRasterizer.finish_deferred)."""
@@ -131,7 +142,7 @@ class FusedAdam:
                          self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr, w, first))
             off += p.numel()
         _adam_launch(segs, self.step_count, self.betas, self.eps, self.opacity_decay, self.opacity_index,
-                     self.decay_first, last, self.params[0].device, row_mask)
+                     self.decay_first, last, self.params[0].device, row_mask, self.skip_flag)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
@@ -164,6 +175,7 @@ class ShardedAdam:
         self.adam_impl = adam_impl
         self.force_collective = False   # issue the collectives even in a 1-rank group (path check on one GPU)
         self.step_count = None
+        self.skip_flag = None           # device int32: != 0 drops the update on the device (ViewShardedStep sets it)
         self._flatten(list(params), None, None)
 
     # ---- layout ---------------------------------------------------------------------------------
@@ -197,7 +209,8 @@ class ShardedAdam:
             self.exp_avg_sq[:n].copy_(full_v[lo:lo + n])
         self.gshard = None              # reduce-scatter output, allocated on first use
         if self.step_count is None:
-            self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._step_words = _step_words(dev)
+            self.step_count = self._step_words[:1]
 
     def my_segments(self) -> List[Tuple[int, int, int]]:
         """[(tensor index, lo, hi)] in flat coordinates: the pieces of the tensors inside this rank's chunk."""
@@ -243,7 +256,7 @@ class ShardedAdam:
             widths = [self.params[k].numel() // P for k, _, _ in self.my_segments()]
             _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, w, 0)
                           for (p, gg, m, v, lr), w in zip(segs, widths)], self.step_count, self.betas, self.eps, decay,
-                         opacity_seg, self.decay_first, True, self.pflat.device, row_mask)
+                         opacity_seg, self.decay_first, True, self.pflat.device, row_mask, self.skip_flag)
         if collective:
             dist.all_gather_into_tensor(self.pflat, self.pflat[lo:lo + self.chunk], group=self.group)
 
@@ -383,6 +396,9 @@ class ViewShardedStep:
             assert len(fused.slots) >= len(self.views), "FusedRasterizer needs one slot per view of the step"
             if self.views:     # size the persistent binning buffers from the actual N of this rank's views
                 fused.fit_capacity([(v.cam, v.slot) for v in self.views], bg)
+            # an overflowing step must not reach the parameters: the optimiser reads the rasterizer's device-side flag
+            if hasattr(optimizer, "skip_flag"):
+                optimizer.skip_flag = fused.overflow_flag
         self.render = render_fn
         self.last_stats = {}
         self.overflow_check_every = int(overflow_check_every)
@@ -434,10 +450,13 @@ class ViewShardedStep:
 
     def check_capacity(self):
         """The persistent binning buffers hold `capacity` tile instances per view; a view with more renders (and
-        back-propagates) a truncated list.  The largest N seen since the last check is kept on the device
-        (FusedRasterizer.high_water): one small read-back here -- every `overflow_check_every` steps, at every
-        densification, at resize -- grows the buffers and raises, so the caller never trains on truncated lists
-        unknowingly.  (The reference sizes the binning buffer from N on every render: one host sync per view.)"""
+        back-propagates) a truncated list.  The binning kernels record the largest N and raise a sticky device-side
+        flag when a view overflowed; from that step on the Adam launch and the densification statistics drop their
+        updates ON THE DEVICE (b3gs_adam_step(skip_if_nonzero), B3gsDensifyStats::skip_if_nonzero), so nothing computed
+        from truncated lists ever reaches the parameters, the moments or the statistics.  This method -- every
+        `overflow_check_every` steps, at every densification, at resize -- reads both words back, grows the buffers,
+        clears the flag and raises: the model is in the state of the last complete step, the caller repeats from there.
+        (The reference sizes the binning buffer from N on every render: one host sync per view.)"""
         self._steps_since_check = 0
         if self.fused is None:
             return
@@ -445,8 +464,10 @@ class ViewShardedStep:
         if over:
             from . import _lib
             raise _lib.B3gsError(f"B3GS_ERR_CAPACITY: a view needed {over} tile instances, the binning buffers held "
-                                 f"fewer; they have been grown to {self.fused.capacity} -- repeat the steps since the "
-                                 f"last check (at most {self.overflow_check_every})")
+                                 f"fewer; they have been grown to {self.fused.capacity}.  The optimiser updates and "
+                                 f"statistics from the overflowing step on were dropped on the device: the model is in "
+                                 f"the state of the last complete step -- repeat from there (at most "
+                                 f"{self.overflow_check_every} steps)")
 
     def _sparse_rows(self) -> Optional[torch.Tensor]:
         """The touched-rows bitmap when this step may leave untouched gradient rows unwritten, else None."""
@@ -469,6 +490,7 @@ class ViewShardedStep:
 
     def reduce_and_update(self):
         """The exchange step of the data-parallel path (one collective over the flat slab) + optimiser."""
+        self._agree_on_overflow()
         if self.range_slab is not None:
             return self._reduce_and_update_pipelined()
         mask, self._row_mask = self._row_mask, None
@@ -483,6 +505,13 @@ class ViewShardedStep:
                 self.optimizer.step(row_mask=mask)
             else:
                 self.optimizer.step()
+
+    def _agree_on_overflow(self, group=None):
+        """Data parallel: a step is dropped by ALL replicas or by none -- the overflow flag is max-reduced (4 bytes)
+        before the optimiser reads it."""
+        group = group if group is not None else self.group
+        if self.fused is not None and _dist_on() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.fused.overflow_flag, op=dist.ReduceOp.MAX, group=group)
 
     def densify_and_prune(self, max_grad: float, min_opacity: float, extent: float, max_screen_size=None,
                           percent_dense: float = 0.01, noise=None, generator=None, group=None) -> int:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 5
+#define B3GS_ABI_VERSION 6
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -178,6 +178,14 @@ typedef struct B3gsForwardView {
    * results do not depend on it -- but a caller that wants the saving keeps one image buffer per camera (and zeroes a
    * fresh one). */
   float seg1_fraction;
+  /* ABI 6 -- overflow that cannot corrupt a step (both optional, device int32 words the caller keeps across forwards):
+   * high_water    <- max(high_water, N)           by the binning kernels themselves (no extra launch);
+   * overflow_flag <- 1 (sticky) when N > binning_capacity, i.e. this view was rendered from truncated tile lists.
+   * b3gs_adam_step(skip_if_nonzero = overflow_flag) and B3gsDensifyStats::skip_if_nonzero then turn every step from
+   * the overflowing one on into a no-op for the parameters, the Adam state and the statistics, until the host has read
+   * the flag, grown the buffers and cleared it: the steps since the last check can really be repeated. */
+  int32_t* high_water;
+  int32_t* overflow_flag;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);
@@ -238,6 +246,8 @@ typedef struct B3gsDensifyStats {
   float* xyz_gradient_accum; /* [P,1] */
   float* denom;              /* [P,1] */
   float* max_radii2D;        /* [P]   */
+  const int32_t* skip_if_nonzero;  /* ABI 6, may be NULL: device word; != 0 -> the statistics are left untouched (see
+                                    * B3gsForwardView::overflow_flag) */
 } B3gsDensifyStats;
 int b3gs_backward_raw_accumulate(int32_t nviews, const B3gsFusedView* views, const B3gsRawParams* params,
                                  const B3gsRawGrads* grads, int32_t overwrite, const B3gsDensifyStats* stats,
@@ -274,9 +284,15 @@ typedef struct B3gsAdamSegment {
 /* `row_mask` (may be NULL): the touched_rows bitmap of B3gsRawGrads.  Element e of a segment with row_len > 0 belongs to
  * Gaussian first_row + e / row_len; when that Gaussian's bit is clear the gradient is taken as 0 WITHOUT reading it
  * (moments and parameter still follow Adam: same result as a dense zero gradient, 4 of 28 bytes per float less). */
+/* ABI 6: `device_step` points to TWO int32 words the optimiser owns: {step, workgroup-completion counter of the
+ * in-kernel bump (zero between launches)} -- optimisers stepping concurrently on several streams no longer share a
+ * module-global counter.  `skip_if_nonzero` (may be NULL): device word; when it is != 0 at launch time the call changes
+ * NOTHING (parameters, moments, step counter): the update of a step rendered from truncated tile lists is dropped on the
+ * device, without a host round trip (B3gsForwardView::overflow_flag). */
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
                    float eps, float opacity_decay, int32_t opacity_segment, int32_t opacity_decay_first,
-                   int32_t bump_step_after, const uint64_t* row_mask, b3gs_stream_t stream);
+                   int32_t bump_step_after, const uint64_t* row_mask, const int32_t* skip_if_nonzero,
+                   b3gs_stream_t stream);
 
 /* ---- fused loss block ----------------------------------------------------------------
  * Value and pixel gradients of the per-pair training loss of train.py:123-148 in 4 launches:

@@ -174,9 +174,47 @@ def _tight_list_metrics(P, W, H, st, fv, radii_hip):
     return out
 
 
-def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
-    """All views of one iteration through FusedRasterizer.render_batch (the bench.py path) against the oracle."""
+def oracle_raw_grads(model, vlist, bg, W, H, per_view_cb=None):
+    """Oracle reference for one iteration of `vlist` = [(camera, is_primary, (dL_dcolor, dL_ddepth | None, dL_dalpha | None))]:
+    tile_ref forward + backward per view, gradients summed over the views in fp64 and chained through the fp64 activations
+    (sigmoid / exp / normalize / cat) to the RAW parameters; plus the densification statistics of the primary views.
+    per_view_cb(k, oracle_state, oracle_grads) is called for every view.  Returns (raw_grads {name: ndarray},
+    st_norm, st_cnt, st_rad)."""
     from oracle import tile_ref
+    P = model.get_xyz.shape[0]
+    act = activated(model)
+    acc = {k: np.zeros(tuple(act[n].shape), np.float64) for k, n in
+           (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"),
+            ("dL_drotations", "rotations"), ("dL_dsh", "shs"))}
+    st_norm, st_cnt, st_rad = np.zeros(P, np.float64), np.zeros(P, np.float64), np.zeros(P, np.float64)
+    for k, (cam, is_primary, (a, b, c)) in enumerate(vlist):
+        st = tile_ref.forward(**oracle_kw(act, cam, bg, W, H, 1))
+        ref = tile_ref.backward(st, a.cpu().numpy(), None if b is None else b.cpu().numpy(),
+                                None if c is None else c.cpu().numpy())
+        for kk in acc:
+            acc[kk] += ref[kk].astype(np.float64).reshape(acc[kk].shape)
+        if is_primary:
+            vis = st.radii > 0
+            st_norm[vis] += np.linalg.norm(ref["dL_dmeans2D"][vis, :2].astype(np.float64), axis=1)
+            st_cnt[vis] += 1
+            st_rad[vis] = np.maximum(st_rad[vis], st.radii[vis])
+        if per_view_cb is not None:
+            per_view_cb(k, st, ref)
+    raw = {n: getattr(model, "_" + n).detach().cpu().double().requires_grad_(True)
+           for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    acts = [raw["xyz"], torch.sigmoid(raw["opacity"]), torch.exp(raw["scaling"]),
+            torch.nn.functional.normalize(raw["rotation"]), torch.cat((raw["features_dc"], raw["features_rest"]), 1)]
+    torch.autograd.backward(acts, [torch.from_numpy(acc[k]) for k in
+                                   ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
+    return {n: raw[n].grad.numpy() for n in raw}, st_norm, st_cnt, st_rad
+
+
+def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fraction=0.125, want_means2D=True):
+    """All views of one iteration through FusedRasterizer.render_batch (the bench.py path) against the oracle.
+    seg1_fraction: 0.125 = two-round binning forced on, first forward (no open-tile prediction yet: the second round
+    repairs); "auto" = what bench.py builds (the deterministic rule of FusedRasterizer.fit_capacity, prediction settled by
+    its forward); 0.0 = one round.  want_means2D=False is bench.py's setting (no per-view screen-space gradient tensors:
+    the densification statistics consume them inside the chain-rule pass)."""
     from binocular3dgs_amd import synth
     from binocular3dgs_amd.debug import state_views
     from binocular3dgs_amd.fused import FusedRasterizer
@@ -194,13 +232,19 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
         if scam is not None:
             vlist.append((scam, slot, False, (gc2, None, None)))
             slot += 1
-    # two-round binning forced on (the automatic rule enables it from 6M instances per view): it must not change a result
-    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=True, seg1_fraction=0.125)
-    with torch.no_grad():                              # size the persistent binning buffers for this scene
-        fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
-        while fr.overflowed():
-            fr.grow()
+    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=want_means2D, seg1_fraction=seg1_fraction)
+    if seg1_fraction == "auto":
+        fr.fit_capacity([(c, s) for c, s, _, _ in vlist], bg)
+    else:
+        with torch.no_grad():                              # size the persistent binning buffers for this scene
+            fr.seg1_fraction, keep = 0.0, fr.seg1_fraction
             fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
+            while fr.overflowed():
+                fr.grow()
+                fr.render_batch([(c, s, False) for c, s, _, _ in vlist], bg)
+            fr.seg1_fraction = keep
+            fr.high_water.zero_()
+            fr.overflow_flag.zero_()
     for p in model.parameters():
         p.grad = torch.zeros_like(p)
     outs = fr.render_batch([(c, s, st_) for c, s, st_, _ in vlist], bg)
@@ -213,54 +257,36 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True):
     torch.autograd.backward(o_t, g_t)
     torch.cuda.synchronize()
     nr = fr.num_rendered()
-    assert max(nr) <= fr.capacity, "binning capacity overflow"
-    m = dict(P=P, W=W, H=H, views=len(vlist), N_binned=nr)
+    assert max(nr) <= fr.capacity and int(fr.overflow_flag.item()) == 0, "binning capacity overflow"
+    m = dict(P=P, W=W, H=H, views=len(vlist), N_binned=nr, seg1_fraction=fr.seg1_fraction)
+    per_view = [None] * len(vlist)
 
-    act = activated(model)
-    acc = {k: np.zeros(tuple(act[n].shape), np.float64) for k, n in
-           (("dL_dmeans3D", "means3D"), ("dL_dopacity", "opacities"), ("dL_dscales", "scales"),
-            ("dL_drotations", "rotations"), ("dL_dsh", "shs"))}
-    st_norm = np.zeros(P, np.float64)
-    st_cnt = np.zeros(P, np.float64)
-    st_rad = np.zeros(P, np.float64)
-    per_view = []
-    for k, ((cam, s, is_primary, (a, b, c)), o) in enumerate(zip(vlist, outs)):
-        st = tile_ref.forward(**oracle_kw(act, cam, bg, W, H, 1))
+    def per_view_cb(k, st, ref):
+        _, s, _, _ = vlist[k]
+        o = outs[k]
         pv = dict(N_oracle=int(st.N))
         radii = o["radii"]
         pv["radius_flips"] = int((radii.cpu().numpy() != st.radii).sum())
-        for name, key, ref in (("color", "render", st.color), ("depth", "rendered_depth", st.depth),
-                               ("alpha", "rendered_alpha", st.alpha)):
-            pv[name + "_max"], pv[name + "_frac"] = image_err(o[key].detach().cpu().numpy(), ref)
+        for name, key, refimg in (("color", "render", st.color), ("depth", "rendered_depth", st.depth),
+                                  ("alpha", "rendered_alpha", st.alpha)):
+            pv[name + "_max"], pv[name + "_frac"] = image_err(o[key].detach().cpu().numpy(), refimg)
         sl = fr.slots[s]
         # the slot's binning buffer is carved for `capacity` instances (that fixes where the tile-id array of the
         # two-word layout starts); the first N entries are the lists
         fv = state_views(P, W, H, sl.capacity, sl.geom, sl.binning, sl.img)
+        pv["N_seg2"] = int(fv["counts"][2])
         if check_lists and (k < 2 or k == len(vlist) - 1):
             pv["lists"] = _tight_list_metrics(P, W, H, st, fv, radii)
-        ref = tile_ref.backward(st, a.cpu().numpy(), None if b is None else b.cpu().numpy(),
-                                None if c is None else c.cpu().numpy())
-        for kk in acc:
-            acc[kk] += ref[kk].astype(np.float64).reshape(acc[kk].shape)
-        pv["dL_dmeans2D"] = rel_l2(sl.means2D_grad.cpu().numpy(), ref["dL_dmeans2D"])
-        if is_primary:
-            vis = st.radii > 0
-            st_norm[vis] += np.linalg.norm(ref["dL_dmeans2D"][vis, :2].astype(np.float64), axis=1)
-            st_cnt[vis] += 1
-            st_rad[vis] = np.maximum(st_rad[vis], st.radii[vis])
-        per_view.append(pv)
+        if sl.means2D_grad is not None:
+            pv["dL_dmeans2D"] = rel_l2(sl.means2D_grad.cpu().numpy(), ref["dL_dmeans2D"])
+        per_view[k] = pv
+
+    raw, st_norm, st_cnt, st_rad = oracle_raw_grads(model, [(c, prim, g) for c, _, prim, g in vlist], bg, W, H, per_view_cb)
     m["per_view"] = per_view
-    # chain rule of the activations (fp64 autograd on the CPU) applied to the oracle's summed gradients
-    raw = {n: getattr(model, "_" + n).detach().cpu().double().requires_grad_(True)
-           for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
-    acts = [raw["xyz"], torch.sigmoid(raw["opacity"]), torch.exp(raw["scaling"]),
-            torch.nn.functional.normalize(raw["rotation"]), torch.cat((raw["features_dc"], raw["features_rest"]), 1)]
-    torch.autograd.backward(acts, [torch.from_numpy(acc[k]) for k in
-                                   ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")])
     for n in raw:
         got = getattr(model, "_" + n).grad
         if got.numel():
-            m["grad_" + n] = rel_l2(got.cpu().numpy(), raw[n].grad.numpy())
+            m["grad_" + n] = rel_l2(got.cpu().numpy(), raw[n])
     m["stat_accum"] = rel_l2(model.xyz_gradient_accum.cpu().numpy().ravel(), st_norm)
     m["stat_denom_mismatch"] = int((model.denom.cpu().numpy().ravel() != st_cnt).sum())
     m["stat_max_radii_mismatch"] = int((model.max_radii2D.cpu().numpy().ravel() != st_rad).sum())

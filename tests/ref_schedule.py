@@ -197,6 +197,130 @@ class Trainer:
         m.max_radii2D, m.active_sh_degree = state["radii"].to(dev), state["sh"]
 
 
+class FusedTrainer:
+    """The same schedule on the build's OWN step (what bench.py times, plus the real loss): FusedRasterizer (raw
+    parameters, the input view and its shifted partner as one batch, shared depth sort, tight binning, in-kernel
+    activations), the fused loss block (b3gs_binocular_loss), multi-view chain rule with the densification statistics
+    folded in, one-launch Adam with the reference's decay order (opacity decay BEFORE the update, train.py:171-173 vs
+    :196-198), HIP densification.  Same step() / get_state() / mean_psnr() surface as Trainer, so it can lead a lockstep
+    run against the oracle-backed CPU trainer."""
+
+    def __init__(self, scene, iterations=300, densify_from_iter=60, densification_interval=40,
+                 densify_grad_threshold=0.0002, shift_cam_start=100, sh_interval=100, cam_trans_dist=0.4,
+                 opacity_decay=0.995, seed=5, seg1_fraction="auto"):
+        import binocular3dgs_amd.render as R
+        from binocular3dgs_amd.fused import FusedRasterizer
+        from binocular3dgs_amd.step import FusedAdam, ViewShardedStep
+        R.GaussianRasterizer = DispatchRasterizer
+        dev = "cuda"
+        self.__dict__.update(device=dev, iterations=iterations, densify_from_iter=densify_from_iter,
+                             densification_interval=densification_interval, thr=densify_grad_threshold,
+                             shift_cam_start=shift_cam_start, sh_interval=sh_interval, opacity_decay=opacity_decay)
+        i0 = scene["init"]
+        self.model = GaussianModel.from_tensors(i0["xyz"], i0["features_dc"], i0["features_rest"], i0["scaling"],
+                                                i0["rotation"], i0["opacity"], sh_degree=1, active_sh_degree=0, device=dev)
+        self.model.init_densification_stats()
+        W, H = scene["W"], scene["H"]
+        self.cams = synth.synth_cameras(W, H, yaws=synth.YAWS_6, device=dev)[:3]
+        self.gts = [g.to(dev) for g in scene["gts"]]
+        self.bg = scene["bg"].to(dev)
+        self.extent = scene["extent"]
+        # parameter order of the model: xyz, f_dc, f_rest, scaling, rotation, opacity
+        lrs = [LR["position_lr_init"] * self.extent, LR["feature_lr"], LR["feature_lr"] / 20.0, LR["scaling_lr"],
+               LR["rotation_lr"], LR["opacity_lr"]]
+        self.opt = FusedAdam(self.model.parameters(), lrs, eps=1e-15, opacity_decay=0.0, opacity_index=5, decay_first=True)
+        self.fused = FusedRasterizer(self.model, W, H, num_slots=2, want_means2D=False, seg1_fraction=seg1_fraction)
+        self.st = ViewShardedStep(self.model, [(self.cams[0], self.cams[0].shifted(0.1), 0.1)], self.bg,
+                                  optimizer=self.opt, fused=self.fused, overflow_check_every=1)
+        self.pipe = PipelineParams()
+        rng = np.random.default_rng(seed)                     # trans_dist sequence shared by all runs
+        self.shifts = (rng.random(iterations + 1) * cam_trans_dist) * rng.choice([-1.0, 1.0], iterations + 1)
+        self.last_newP = None
+        self._cur = {}
+
+    def mean_psnr(self):
+        with torch.no_grad():
+            return float(np.mean([float(psnr(render(c, self.model, self.pipe, self.bg)["render"].clamp(0, 1)[None],
+                                             g[None]).mean()) for c, g in zip(self.cams, self.gts)]))
+
+    def _loss(self, i, cam, pkg, spkg, t):
+        from binocular3dgs_amd.fused_loss import binocular_loss_fused
+        use = self._cur["it"] > self.shift_cam_start
+        total = binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], self._cur["gt"],
+                                     shifted_image=spkg["render"] if use else None, focal_x=cam.get_focal()[0],
+                                     trans_dist=t if use else None, slot=0, unit_grad=True)
+        self._cur["loss"] = total.detach()
+        return total
+
+    def step(self, it):
+        model, opt, st = self.model, self.opt, self.st
+        opt.lrs[0] = expon_lr(it, LR["position_lr_init"] * self.extent, LR["position_lr_final"] * self.extent,
+                              lr_delay_mult=LR["position_lr_delay_mult"], max_steps=self.iterations)
+        if it % self.sh_interval == 0:
+            model.oneupSHdegree()
+        k = (it - 1) % len(self.cams)
+        t = float(self.shifts[it])
+        v0, v1 = st.views
+        # (before the binocular phase the shifted view is rendered but receives no gradient: the reference does not
+        # render it at all, which leaves every result the same)
+        v0.cam, v0.t, v1.cam, v1.t = self.cams[k], t, self.cams[k].shifted(t), t
+        self._cur.update(it=it, gt=self.gts[k])
+        st.compute_grads(loss_fn=self._loss)
+        decay = self.opacity_decay if (self.opacity_decay and it > self.densify_from_iter) else 0.0
+        self.last_newP = None
+        if it > self.densify_from_iter and it % self.densification_interval == 0:
+            if decay > 0.0:
+                with torch.no_grad():   # the reference replaces every parameter here: optimizer.step() then updates nothing
+                    model._opacity.data.copy_(inverse_sigmoid(model.get_opacity * decay))
+            P = model.get_xyz.shape[0]
+            noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it)).to(self.device)
+            self.last_newP = st.densify_and_prune(self.thr, 0.005, self.extent, noise=noise)
+        elif it < self.iterations:
+            opt.opacity_decay = decay
+            st.reduce_and_update()
+        st.check_capacity()
+        return float(self._cur["loss"])
+
+    def get_state(self):
+        m, opt = self.model, self.opt
+        attr = dict(xyz="_xyz", f_dc="_features_dc", f_rest="_features_rest", opacity="_opacity", scaling="_scaling",
+                    rotation="_rotation")
+        order = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")          # FusedAdam's flat moments
+        offs, off = {}, 0
+        for n in order:
+            offs[n] = off
+            off += getattr(m, attr[n]).numel()
+        step = int(opt.step_count.item())
+        groups = []
+        for n in NAMES:
+            p = getattr(m, attr[n])
+            a, b = offs[n], offs[n] + p.numel()
+            groups.append(dict(p=p.detach().cpu().clone(),
+                               m=None if step == 0 else opt.exp_avg[a:b].view(p.shape).cpu().clone(),
+                               v=None if step == 0 else opt.exp_avg_sq[a:b].view(p.shape).cpu().clone(),
+                               step=None if step == 0 else float(step)))
+        return dict(groups=groups, accum=m.xyz_gradient_accum.cpu().clone(), denom=m.denom.cpu().clone(),
+                    radii=m.max_radii2D.cpu().clone(), sh=m.active_sh_degree)
+
+    def flat_params(self):
+        m = self.model
+        return torch.cat([getattr(m, a).detach().reshape(-1).cpu() for a in
+                          ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")])
+
+
+def train_fused(scene, iterations=300, eval_every=100, **kw):
+    """Free run of FusedTrainer; same history dict as train()."""
+    tr = FusedTrainer(scene, iterations=iterations, **kw)
+    hist = dict(psnr=[], P=[])
+    for it in range(1, iterations + 1):
+        tr.step(it)
+        if tr.last_newP is not None:
+            hist["P"].append((it, int(tr.last_newP)))
+        if it % eval_every == 0 or it == iterations:
+            hist["psnr"].append((it, tr.mean_psnr()))
+    return hist
+
+
 def train(scene, device, iterations=300, eval_every=100, **kw):
     """Free run.  Returns dict(psnr=[(iteration, mean train-view PSNR)], P=[(iteration, P after densify)])."""
     tr = Trainer(scene, device, iterations=iterations, **kw)

@@ -89,7 +89,7 @@ def test_argument_errors_are_reported_without_touching_a_device():
     assert L.b3gs_knn_mean_dist2(-1, None, None, None, None) == ERR_ARG
     assert L.b3gs_knn_mean_dist2(10, None, None, None, None) == ERR_ARG
     assert L.b3gs_knn_mean_dist2(0, None, None, None, None) == 0          # empty set: nothing to do
-    assert L.b3gs_adam_step(0, None, None, 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None, None) == ERR_ARG
+    assert L.b3gs_adam_step(0, None, None, 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None, None, None) == ERR_ARG
     assert L.b3gs_forward_raw_batch(0, None, None, 3, None) == ERR_ARG
     assert L.b3gs_forward_raw_batch(9, None, None, 3, None) == ERR_ARG
     assert L.b3gs_backward_raw_accumulate_range(0, None, None, None, 1, None, 0, 0, None) == ERR_ARG

@@ -38,18 +38,32 @@ def test_dropin_surface_vs_oracle(P, W, H, fov, views):
         assert m[k] <= 2e-4, f"{k}: rel L2 {m[k]:.3e}"
 
 
-@pytest.mark.parametrize("P,W,H,fov,views", SIZES)
-def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views):
+# the fused path's knobs: (seg1_fraction, want_means2D).  (0.125, True): two binning rounds forced, first forward (no
+# prediction yet, the second round repairs many tiles), per-view screen-space gradients; ("auto", False): EXACTLY what
+# bench.py builds at the headline -- the rule of FusedRasterizer.fit_capacity (two rounds at 1M, prediction settled), no
+# means2D tensors; (0.0, False): one binning round (the rule's choice below 2M instances per view)
+FUSED_CASES = [pytest.param(*sz.values, 0.125, True, id=sz.id + "-two_rounds_forced") for sz in SIZES] + \
+              [pytest.param(1_000_000, 800, 600, 60.0, 6, "auto", False, id="1M_800x600_6views-bench_config"),
+               pytest.param(1_000_000, 800, 600, 60.0, 6, 0.0, False, id="1M_800x600_6views-one_round")]
+
+
+@pytest.mark.parametrize("P,W,H,fov,views,seg1,m2d", FUSED_CASES)
+def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views, seg1, m2d):
     import fullsize
-    m = fullsize.fused_metrics(P, W, H, fov, views=views)
+    m = fullsize.fused_metrics(P, W, H, fov, views=views, seg1_fraction=seg1, want_means2D=m2d)
     assert m["views"] == views
+    if seg1 == "auto":
+        assert 0.0 < m["seg1_fraction"] <= 0.125, "the rule must pick two rounds at the headline workload"
+        assert all(pv["N_seg2"] == 0 for pv in m["per_view"]), "settled prediction: nothing left for the second round"
     flips = 0
     for k, pv in enumerate(m["per_view"]):
         assert pv["radius_flips"] <= max(2, P // 100_000), (k, pv["radius_flips"])
         flips += pv["radius_flips"]
         for name, scale in (("color", 1.0), ("depth", 10.0), ("alpha", 1.0)):
             assert pv[name + "_frac"] <= FLIP_FRAC and pv[name + "_max"] <= scale * FLIP_MAX, (k, name, pv)
-        assert pv["dL_dmeans2D"] <= 2e-4, (k, pv["dL_dmeans2D"])
+        assert ("dL_dmeans2D" in pv) == m2d
+        if m2d:
+            assert pv["dL_dmeans2D"] <= 2e-4, (k, pv["dL_dmeans2D"])
         if "lists" in pv:
             ls = pv["lists"]
             assert ls["subset"] and ls["order_preserved"], (k, ls)

@@ -49,9 +49,11 @@ def test_fused_equals_dropin(K):
     assert float((out["radii"] != ref_radii).float().mean()) < 1e-3
     # the stated contract (tests/test_gpu_parity.py): images within 2e-5 (1 + |x|), apart from pixels where the 1-ulp
     # activation difference flips a 1/255-rule decision (at most one minimal contribution, a handful of pixels)
-    for a, b in zip((out["render"], out["rendered_depth"], out["rendered_alpha"]), ref_img):
+    # (same bound as tests/test_gpu_fullsize_oracle.py: one minimal contribution is 1/255 of colour / alpha and z/255 of
+    # the un-normalised depth, z <= 10 in these scenes)
+    for (a, b), scale in zip(zip((out["render"], out["rendered_depth"], out["rendered_alpha"]), ref_img), (1.0, 10.0, 1.0)):
         err = ((a - b).abs() / (1 + b.abs())).detach()
-        assert int((err > 2e-5).sum()) <= 3 and float(err.max()) <= 10.0 / 255, (float(err.max()), int((err > 2e-5).sum()))
+        assert int((err > 2e-5).sum()) <= 3 and float(err.max()) <= scale / 255, (float(err.max()), int((err > 2e-5).sum()))
     names = ["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"]
     for n, p, r in zip(names, model.parameters(), ref):
         if r.numel() == 0:
@@ -434,7 +436,7 @@ def test_adam_reference_decay_order_empty_segment_and_error_text():
             assert float((p - q).abs().max()) < 5e-6 * max(1.0, float(p.abs().max()))
     seg = (_lib.B3gsAdamSegment * 1)()
     seg[0].count, seg[0].lr = 5, 1e-3          # non-empty segment with NULL pointers
-    rc = _lib.lib().b3gs_adam_step(1, seg, mine.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None, None)
+    rc = _lib.lib().b3gs_adam_step(1, seg, mine.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, None, None, None)
     assert rc == -1 and b"b3gs_adam_step" in _lib.lib().b3gs_last_error()
     io = _lib.B3gsDensifyIO()
     io.P, io.M = 4, 0
@@ -504,6 +506,67 @@ def test_step_detects_binning_overflow_and_grows():
     st.check_capacity()
 
 
+@pytest.mark.parametrize("opt_kind", ["fused", "sharded"])
+def test_overflowing_steps_are_dropped_on_the_device(opt_kind):
+    """A step rendered from truncated tile lists cannot corrupt the model: the binning
+    kernels raise a sticky device flag when N exceeds the capacity; from that step on the Adam launch (parameters,
+    moments, step counter) and the densification statistics skip their update on the device, with no host round trip.
+    When check_capacity() finally looks, the model is bit for bit in the state of the last complete step; after the
+    buffers have grown, repeating the steps gives what a run that never overflowed gives."""
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+    W, H = 160, 120
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    fn = lambda i, pkg, spkg: [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]  # noqa: E731
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 0.05]
+
+    def state(model, opt):
+        return [p.detach().clone() for p in model.parameters()] + [opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                opt.step_count.clone(), model.denom.clone(), model.xyz_gradient_accum.clone(), model.max_radii2D.clone()]
+
+    def build():
+        model, pairs, bg = _setup(P=6000, W=W, H=H)
+        model.init_densification_stats()
+        cls = FusedAdam if opt_kind == "fused" else ShardedAdam
+        opt = cls(model.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True)
+        fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+        st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, overflow_check_every=0)
+        return model, opt, fr, st
+
+    # reference: four complete steps
+    model, opt, fr, st = build()
+    for _ in range(4):
+        st.step(pair_grad_fn=fn)
+    want = state(model, opt)
+
+    model, opt, fr, st = build()
+    assert opt.skip_flag is fr.overflow_flag
+    for _ in range(2):
+        st.step(pair_grad_fn=fn)
+    good = state(model, opt)
+    fr.capacity = 1000                           # the scene outgrows its buffers
+    for i in range(len(fr.slots)):
+        fr.slots[i] = fr._new_slot(fr.slots[i].stream, i)
+    for _ in range(3):                           # nobody has looked yet: three steps on truncated lists
+        st.step(pair_grad_fn=fn)
+    torch.cuda.synchronize()
+    assert int(fr.overflow_flag.item()) == 1
+    for a, b in zip(state(model, opt), good):    # ... and none of them touched the model
+        assert torch.equal(a, b)
+    with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
+        st.check_capacity()
+    assert int(fr.overflow_flag.item()) == 0 and fr.capacity > 1000
+    for _ in range(2):                           # repeat from the last complete step
+        st.step(pair_grad_fn=fn)
+    st.check_capacity()
+    for a, b in zip(state(model, opt), want):
+        if a.dtype == torch.int32:
+            assert torch.equal(a, b)
+        else:
+            assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5   # fp32 atomics in the gradients
+
+
 @pytest.mark.parametrize("scene", ["dense", "thin"])
 def test_two_round_binning_equals_one_round(scene):
     """Termination-aware binning (B3gsForwardView.seg1_fraction): bin the nearest fraction of the depth order (plus, into the
@@ -551,6 +614,8 @@ def test_two_round_binning_equals_one_round(scene):
     def run(frac):
         fr = FusedRasterizer(model, W, H, num_slots=len(views), seg1_fraction=frac)
         fr.fit_capacity(views, bg)
+        for sl in fr.slots:       # (fit_capacity settles the prediction with a forward of its own: start from none)
+            sl.img.zero_()
         # first forward: no prediction yet, every unterminated tile is repaired by the second round; second forward:
         # those tiles are predicted open and get their complete list in round 1; third: the prediction of another view
         return one(fr, views), one(fr, views), one(fr, rot)
@@ -745,7 +810,7 @@ def test_sparse_row_and_row_mask_argument_errors():
     seg[0].param, seg[0].grad = p0.data_ptr(), p0.grad.data_ptr()
     seg[0].exp_avg, seg[0].exp_avg_sq = opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr()
     seg[0].count, seg[0].lr, seg[0].row_len, seg[0].first_row = p0.numel(), 1e-3, -3, 0
-    rc = _lib.lib().b3gs_adam_step(1, seg, opt.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, words.data_ptr(), None)
+    rc = _lib.lib().b3gs_adam_step(1, seg, opt.step_count.data_ptr(), 0.9, 0.999, 1e-15, 0.0, -1, 0, 1, words.data_ptr(), None, None)
     assert rc == -1 and b"row_len" in _lib.lib().b3gs_last_error()
 
 

@@ -350,9 +350,10 @@ def test_forward_capacity_entry_point_and_overflow():
 
 def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
     """GaussianRasterizer (the surface render() uses) pays the blocking read-back of num_rendered only for the first
-    render of a (P, W, H) shape; afterwards it runs b3gs_forward_capacity with twice the largest N seen and looks at N one
-    call late (rasterizer._LazyN).  Same images and gradients bit for bit / to atomics order; an N above the capacity is
-    reported at the next render, and the render after that is complete again."""
+    render of a (P, W, H) shape; afterwards a DIFFERENTIATED render runs b3gs_forward_capacity with twice the largest N
+    seen and its N is checked at the entry of its backward (rasterizer._LazyN).  Same images and gradients bit for bit / to
+    atomics order; an N above the capacity raises in backward() -- before any gradient exists, so optimizer.step() cannot
+    consume a truncated render -- and the next render is complete again.  Renders nobody differentiates stay exact."""
     from binocular3dgs_amd import _lib, rasterizer, synth
     from binocular3dgs_amd.render import PipelineParams, render
     W, H, P = 160, 112, 4000
@@ -364,55 +365,69 @@ def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
     assert lz.enabled
     key = (torch.cuda.current_device(), P, W, H)
     lz.capacity.pop(key, None)
+    lz.poll(force=True)
 
-    def run():
+    def run(backward=True):
         for p in model.parameters():
             p.grad = None
         pkg = render(cam, model, PipelineParams(), bg)
-        torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+        if backward:
+            torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
         torch.cuda.synchronize()
         return ([pkg[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha", "radii")],
-                [p.grad.clone() for p in model.parameters()] + [pkg["viewspace_points"].grad.clone()])
+                [p.grad.clone() for p in model.parameters()] + [pkg["viewspace_points"].grad.clone()] if backward else None)
 
     first = run()                                   # synchronous: learns N
     cap = lz.capacity[key]
-    lz.poll(force=True)
-    second = run()                                  # sync-free: capacity path
-    assert [k for k, *_ in lz.pending] == [key]     # its N is on the way to the host, nobody waited for it
+    assert lz.pending == []
+    pkg = render(cam, model, PipelineParams(), bg)  # sync-free: capacity path
+    assert [t[0] for t in lz.pending] == [key]      # its N is on the way to the host, nobody waited for it
+    torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+    assert lz.pending == []                         # ... until its backward looked at it
+    second = run()
     for a, b in zip(first[0], second[0]):
         assert torch.equal(a, b)
     for a, b in zip(first[1], second[1]):
         assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
-    lz.poll(force=True)                             # N of the second render: well inside the capacity
-    assert lz.capacity[key] == cap
-    # a scene that outgrew the buffer: reported one render late, capacity grown, next render complete
+    assert lz.capacity[key] == cap                  # N well inside the capacity: nothing grew
+    # a scene that outgrew the buffer: the backward of THAT render refuses, nothing reaches the parameters' .grad
     lz.capacity[key] = 256
-    run()                                           # truncated lists (nobody knows yet)
     with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
-        lz.poll(force=True)
-    assert lz.capacity[key] >= cap // 2 and lz.capacity[key] > 256
+        run()
+    assert all(p.grad is None for p in model.parameters())
+    assert lz.capacity[key] >= cap // 2 and lz.capacity[key] > 256 and lz.pending == []
     third = run()
     for a, b in zip(first[0], third[0]):
         assert torch.equal(a, b)
-    lz.poll(force=True)
+    # a truncated render whose backward never runs is caught at the next render instead
+    lz.capacity[key] = 256
+    run(backward=False)
+    with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
+        run(backward=False)
+    lz.pending.clear()
+    # renders without gradients (evaluation loops) take the exact forward: never truncated, nothing pending
+    lz.capacity[key] = 256
+    with torch.no_grad():
+        ev = render(cam, model, PipelineParams(), bg)
+    assert lz.pending == [] and torch.equal(ev["render"], first[0][0]) and lz.capacity[key] > 256
 
 
 def test_lazy_num_rendered_survives_more_renders_than_pinned_slots():
-    """More sync-free renders in a row than the ring of pinned read-back slots (64): the oldest are drained before a slot
-    is reused, every N is still checked."""
+    """More sync-free renders in a row than the ring of pinned read-back slots (64), none of them differentiated in the
+    end: the oldest are drained before a slot is reused, every N is still checked."""
     from binocular3dgs_amd import rasterizer, synth
     from binocular3dgs_amd.render import PipelineParams, render
     W, H, P = 64, 48, 500
-    model = synth.synth_model(P, seed=9, device="cuda", width=W, height=H, requires_grad=False)
+    model = synth.synth_model(P, seed=9, device="cuda", width=W, height=H)
     cam = synth.synth_view_set(W, H, device="cuda")[0][0]
     bg = torch.zeros(3, device="cuda")
     lz = rasterizer._lazy
-    lz.poll(force=True)
+    lz.pending.clear()
     with torch.no_grad():
         ref = render(cam, model, PipelineParams(), bg)["render"].clone()
-        for _ in range(lz.RING + 10):
-            out = render(cam, model, PipelineParams(), bg)["render"]
-    assert len(lz.pending) < lz.RING
+    for _ in range(lz.RING + 10):
+        out = render(cam, model, PipelineParams(), bg)["render"].detach()
+    assert 0 < len(lz.pending) < lz.RING
     assert torch.equal(out, ref)
     lz.poll(force=True)
     assert lz.pending == []

@@ -22,68 +22,9 @@ ITERS = 500
 KW = dict(densify_grad_threshold=0.001, densification_interval=50)   # threshold scaled to the 160x120 scene: P settles near 12k
 
 
-def _train_fused(scene, iterations, densify_from_iter=60, densification_interval=50, densify_grad_threshold=0.001,
-                 shift_cam_start=100, sh_interval=100, cam_trans_dist=0.4, opacity_decay=0.995, seed=5, eval_every=100):
+def _train_fused(scene, iterations, **kw):
     import ref_schedule as rs
-    from binocular3dgs_amd import synth
-    from binocular3dgs_amd.fused import FusedRasterizer
-    from binocular3dgs_amd.fused_loss import binocular_loss_fused
-    from binocular3dgs_amd.gaussian_model import GaussianModel, inverse_sigmoid
-    from binocular3dgs_amd.loss import expon_lr, psnr
-    from binocular3dgs_amd.render import PipelineParams, render
-    from binocular3dgs_amd.step import FusedAdam, ViewShardedStep
-    dev = "cuda"
-    i0 = scene["init"]
-    model = GaussianModel.from_tensors(i0["xyz"], i0["features_dc"], i0["features_rest"], i0["scaling"], i0["rotation"],
-                                       i0["opacity"], sh_degree=1, active_sh_degree=0, device=dev)
-    model.init_densification_stats()
-    W, H, extent = scene["W"], scene["H"], scene["extent"]
-    cams = synth.synth_cameras(W, H, yaws=synth.YAWS_6, device=dev)[:3]
-    gts = [g.to(dev) for g in scene["gts"]]
-    bg = scene["bg"].to(dev)
-    L = rs.LR
-    # parameter order of the model: xyz, f_dc, f_rest, scaling, rotation, opacity
-    lrs = [L["position_lr_init"] * extent, L["feature_lr"], L["feature_lr"] / 20.0, L["scaling_lr"], L["rotation_lr"], L["opacity_lr"]]
-    opt = FusedAdam(model.parameters(), lrs, eps=1e-15, opacity_decay=0.0, opacity_index=5, decay_first=True)
-    fr = FusedRasterizer(model, W, H, num_slots=2, want_means2D=False)
-    st = ViewShardedStep(model, [(cams[0], cams[0].shifted(0.1), 0.1)], bg, optimizer=opt, fused=fr)
-    rng = np.random.default_rng(seed)
-    shifts = (rng.random(iterations + 1) * cam_trans_dist) * rng.choice([-1.0, 1.0], iterations + 1)
-    hist = dict(psnr=[], P=[])
-    state = {}
-
-    def loss_fn(i, cam, pkg, spkg, t):
-        use = state["it"] > shift_cam_start
-        return binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], state["gt"],
-                                    shifted_image=spkg["render"] if use else None, focal_x=cam.get_focal()[0],
-                                    trans_dist=t if use else None, slot=0, unit_grad=True)
-
-    for it in range(1, iterations + 1):
-        opt.lrs[0] = expon_lr(it, L["position_lr_init"] * extent, L["position_lr_final"] * extent,
-                              lr_delay_mult=L["position_lr_delay_mult"], max_steps=iterations)
-        if it % sh_interval == 0:
-            model.oneupSHdegree()
-        k = (it - 1) % 3
-        t = float(shifts[it])
-        v0, v1 = st.views
-        v0.cam, v0.t, v1.cam, v1.t = cams[k], t, cams[k].shifted(t), t
-        state.update(it=it, gt=gts[k])
-        st.compute_grads(loss_fn=loss_fn)
-        decay = opacity_decay if it > densify_from_iter else 0.0
-        if it > densify_from_iter and it % densification_interval == 0:
-            with torch.no_grad():       # the reference replaces every parameter here: optimizer.step() then updates nothing
-                model._opacity.data = inverse_sigmoid(model.get_opacity * decay)
-            P = model.get_xyz.shape[0]
-            noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it)).to(dev)
-            hist["P"].append((it, int(st.densify_and_prune(densify_grad_threshold, 0.005, extent, noise=noise))))
-        elif it < iterations:
-            opt.opacity_decay = decay
-            st.reduce_and_update()
-        if it % eval_every == 0 or it == iterations:
-            with torch.no_grad():
-                hist["psnr"].append((it, float(np.mean([float(psnr(render(c, model, PipelineParams(), bg)["render"].clamp(0, 1)[None],
-                                                                       g[None]).mean()) for c, g in zip(cams, gts)]))))
-    return hist
+    return rs.train_fused(scene, iterations=iterations, **kw)
 
 
 def _flat(tr):
@@ -123,6 +64,48 @@ def test_reference_schedule_lockstep_hip_vs_oracle_backed_cpu():
             assert d < 0.01, (it, d)
     assert [i for i, _ in densified] == [100, 150, 200, 250] and densified[-1][1] > densified[0][1]
     print(f"lockstep: worst rel-L2 {worst_rel:.2e}, worst |dPSNR| {worst_psnr:.2e} dB, P after densifications {densified}")
+
+
+@pytest.mark.parametrize("seg1,n", [pytest.param("auto", 160, id="rule"), pytest.param(0.125, 260, id="two_rounds_forced")])
+def test_reference_schedule_lockstep_fused_step_vs_oracle_backed_cpu(seg1, n):
+    """The strict statement for the build's OWN step (row g1): FusedRasterizer pair batch + fused loss
+    block + one-launch Adam with the reference's decay order + HIP densification LEADS, the oracle-backed CPU trainer --
+    the reference loop statement by statement -- is handed its full state before every iteration and both step.  Same
+    bars as the drop-in lockstep: loss 1e-5 relative, identical Gaussian count after every densification, updated
+    parameters 1e-3 relative L2, PSNR 0.01 dB.  `two_rounds_forced`: two binning rounds with the open-tile prediction
+    under a camera that changes every iteration and slots that are re-created at every densification -- the second
+    round's persistent repair kernel takes its slow path again and again; `rule`: what FusedRasterizer picks by itself at
+    this size (one round)."""
+    import ref_schedule as rs
+    torch.set_num_threads(8)
+    scene = rs.make_scene()
+    hip = rs.FusedTrainer(scene, iterations=ITERS, seg1_fraction=seg1, **KW)
+    cpu = rs.Trainer(scene, "cpu", iterations=ITERS, **KW)
+    worst_rel, worst_psnr, densified, repaired = 0.0, 0.0, [], 0
+    for it in range(1, n + 1):
+        cpu.set_state(hip.get_state())
+        lh, lc = hip.step(it), cpu.step(it)
+        assert abs(lh - lc) <= 1e-5 * abs(lc) + 1e-7, (it, lh, lc)
+        assert (hip.last_newP is None) == (cpu.last_newP is None)
+        if hip.last_newP is not None:
+            assert int(hip.last_newP) == int(cpu.last_newP), (it, hip.last_newP, cpu.last_newP)
+            densified.append((it, int(hip.last_newP)))
+        repaired += sum(int(s.img[:64].view(torch.int32)[2]) > 0 for s in hip.fused.slots)
+        a, b = hip.flat_params(), _flat(cpu)
+        assert a.shape == b.shape
+        rel = float((a - b).norm() / b.norm())
+        worst_rel = max(worst_rel, rel)
+        assert rel <= 1e-3, (it, rel)
+        if it % 20 == 0:
+            d = abs(hip.mean_psnr() - cpu.mean_psnr())
+            worst_psnr = max(worst_psnr, d)
+            assert d < 0.01, (it, d)
+    want = [i for i in (100, 150, 200, 250) if i <= n]
+    assert [i for i, _ in densified] == want
+    if seg1 != "auto":
+        assert hip.fused.seg1_fraction == seg1 and repaired > 0, "the second binning round never had work: nothing was tested"
+    print(f"lockstep fused ({seg1}): worst rel-L2 {worst_rel:.2e}, worst |dPSNR| {worst_psnr:.2e} dB, P after "
+          f"densifications {densified}, forwards with a repaired view {repaired}")
 
 
 def test_reference_schedule_free_run_psnr():
