@@ -389,12 +389,20 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
       if (K1 >= P) K1 = 0;
     }
   }
+  // three-pass depth sort on 27-bit keys: only with the caller's overflow word to report a key outside the span to
+  bool key27 = getenv("B3GS_NO_KEY27") == nullptr;   // (A/B switch)
+  for (int k = 0; k < nviews; k++)
+    key27 = key27 && views[k].depth_key_bits == 27 && views[k].overflow_flag != nullptr && !views[k].view->prefiltered;
+  for (int k = 0; k < nviews; k++) {
+    jobs[k].key_bits = key27 ? 27 : 0;
+    pb.out[k].span_flag = key27 ? views[k].overflow_flag : nullptr;
+    bb.v[k].z_base = key27 ? 0x3E4CCCCDu : 0u;
+  }
   for (int k = 0; k < nviews; k++) {
     jobs[k].K1 = K1;
     if (!K1) continue;
     // the tiles the previous two-round forward into this image buffer left unterminated are predicted open now
     pb.out[k].pred_rows = jobs[k].im.pred_rows;
-    pb.out[k].pred_next = jobs[k].im.pred_next;
     bb.v[k].pred_rows = jobs[k].im.pred_rows;
     bb.v[k].pred_next = jobs[k].im.pred_next;
     const int d = views[k].depth_order_from;

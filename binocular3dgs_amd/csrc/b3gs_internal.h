@@ -36,6 +36,9 @@ struct GeomView {       // sized by P
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
   uint32_t* scan_tmp;   // [4096] block sums for scans
   float* bwd_rows;      // [P * B3GS_SCRATCH_ROW] drop-in backward: per-Gaussian sums of the blend backward (one row each)
+  unsigned long long* pflag;  // [ceil(P / 64)] two-round forward: bit i set = the tile rect of Gaussian i reaches a tile that
+                        //       is predicted open (written by the projection: the scan gathers the rects of the Gaussians
+                        //       behind segment 1 only where this bit is set)
 };
 
 struct BinView {        // sized by N (and P for the histogram)
@@ -91,7 +94,8 @@ static inline int b3gs_packed_idx_bits(int32_t P, int W, int H) {
 // radix-sort scratch: 1280 header words (global digit histograms, tickets) + one status word per
 // (pass <= 4, workgroup, digit) for the chained scan; also covers the 3-launch variant's 256*(nblk+1)
 // (+ 4096: the histogram rows are padded to a multiple of 16 columns, binning.hip::hist_stride)
-static inline size_t b3gs_sort_scratch_words(int64_t n) { return 1280 + 4096 + (size_t)4 * 256 * (b3gs_sort_blocks(n) + 1); }
+// (the 9-bit depth sort needs 512 rows of hist_stride(nblk) <= nblk + 15 words + 512 totals: 512 nblk + 8192, inside this)
+static inline size_t b3gs_sort_scratch_words(int64_t n) { return 1280 + 8192 + (size_t)4 * 256 * (b3gs_sort_blocks(n) + 1); }
 
 // carve: if base == nullptr only the size is computed
 template <typename T>
@@ -119,6 +123,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
   t.bwd_rows = b3gs_carve<float>(cur, p * B3GS_SCRATCH_ROW);
+  t.pflag = b3gs_carve<unsigned long long>(cur, (p + 63) / 64);
   if (v) *v = t;
   return (size_t)(cur - base);
 }
@@ -169,6 +174,36 @@ struct SceneX {
 
 #define B3GS_MAX_FUSED_VIEWS 8
 
+// A set of tiles as a bitmap: word (y, x / 64), bit x % 64 (ImgView::open_rows / pred_rows).
+struct OpenMap {
+  const unsigned long long* rows;
+  uint32_t row_words, grid_x, grid_y;
+};
+__host__ __device__ inline OpenMap open_map(const unsigned long long* rows, int W, int H) {
+  const int gx = (W + B3GS_TILE - 1) / B3GS_TILE, gy = (H + B3GS_TILE - 1) / B3GS_TILE;
+  return OpenMap{rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx, (uint32_t)gy};
+}
+#ifdef __HIPCC__
+// bits of row y inside columns [x0, x1) of 64-column block wb, shifted so that bit 0 is column max(x0, 64 wb)
+__device__ __forceinline__ unsigned long long open_bits(const OpenMap& om, uint32_t y, uint32_t wb, uint32_t x0, uint32_t x1,
+                                                        uint32_t* col0) {
+  const uint32_t lo = max(x0, wb * 64u), hi = min(x1, wb * 64u + 64u);
+  const unsigned long long m = om.rows[(size_t)y * om.row_words + wb] >> (lo & 63u);
+  *col0 = lo;
+  const uint32_t w = hi - lo;
+  return w >= 64u ? m : (m & ((1ull << w) - 1ull));
+}
+// number of open tiles inside the rect (packed u16: x0 | y0 << 16, x1 | y1 << 16)
+__device__ __forceinline__ uint32_t open_tiles(uint2 rc, const OpenMap& om) {
+  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+  if (x1 <= x0) return 0u;
+  uint32_t n = 0, c0;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) n += (uint32_t)__builtin_popcountll(open_bits(om, y, wb, x0, x1, &c0));
+  return n;
+}
+#endif
+
 // ---- error reporting shared by every translation unit (api.hip owns the thread-local message) -------
 // b3gs_fail: store the message b3gs_last_error() returns and hand back `code`;
 // b3gs_launch_status: B3GS_OK, or B3GS_ERR_HIP with "<what>: <hip error string>" when a launch / runtime call failed
@@ -195,8 +230,10 @@ struct PreOut {
   uint2* ranges;
   uint2* ranges2;
   unsigned long long* open_rows;
-  unsigned long long* pred_rows;   // two-round forward only (else null): pred_rows <- pred_next, pred_next <- 0
-  unsigned long long* pred_next;
+  int32_t* span_flag;              // non-null: raise bit 1 of this word when a visible depth key lies outside the 27-bit span
+  const unsigned long long* pred_rows;   // two-round forward only (else null): the tiles predicted open for THIS forward
+                                   //   (rotated from pred_next by the previous forward's last kernel, render.hip)
+  unsigned long long* pflag;       //   ... and where the per-Gaussian "reaches a predicted tile" bits go (GeomView::pflag)
   int32_t ntiles, nrowwords;
 };
 struct PreBatch {
@@ -243,6 +280,9 @@ struct BinJob {
   // ABI 6 (optional): high_water <- max(high_water, N); overflow_flag <- 1 when N > n_bound (B3gsForwardView)
   int32_t* high_water = nullptr;
   int32_t* overflow_flag = nullptr;
+  // 27: every visible depth key lies within 2^27 of the float bits of B3GS_NEAR (checked by the projection, which raises
+  // bit 1 of overflow_flag otherwise): three 9-bit passes instead of four 8-bit ones.  0 / 32: the full 32-bit sort.
+  int32_t key_bits = 0;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,
@@ -270,6 +310,7 @@ struct BlendView {
   const unsigned long long* pred_rows;   // forward, round 0: the tiles predicted open (complete list in segment 1)
   unsigned long long* pred_next;         //   ... and the prediction for the next forward (every unterminated tile, and the
   const uint32_t* z_clear; //   predicted ones that needed more than the depth key *z_clear = rank 3/4 K1 of the order)
+  uint32_t z_base;         //   ... which is stored minus this base when the depth sort ran on 27-bit keys (binning.hip)
   int32_t row_words;       //   64-bit words per tile row of the bitmap
   int32_t round;           // forward: 0 = first pass over all tiles (segment 1); 1 = second pass, only tiles with a segment 2;
                            //          2 = all tiles over segment 1 + segment 2 (re-blend of a finished forward's state)

@@ -83,15 +83,6 @@ struct SortBatch {
   SortJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
-// A set of tiles as a bitmap: word (y, x / 64), bit x % 64 (ImgView::open_rows / pred_rows).
-struct OpenMap {
-  const unsigned long long* rows;
-  uint32_t row_words, grid_x, grid_y;
-};
-__host__ __device__ inline OpenMap open_map(const unsigned long long* rows, int W, int H) {
-  const int gx = (W + B3GS_TILE - 1) / B3GS_TILE, gy = (H + B3GS_TILE - 1) / B3GS_TILE;
-  return OpenMap{rows, (uint32_t)((gx + 63) / 64), (uint32_t)gx, (uint32_t)gy};
-}
 struct ScanJob {
   const uint32_t* order;    // depth order (own or the donor view's)
   const uint2* rect;        // tile rectangles by Gaussian (element i at rect[i * rect_stride])
@@ -110,6 +101,7 @@ struct ScanJob {
   int32_t* high_water;      // optional: max(N) over the forwards since the host last looked
   int32_t* overflow_flag;   // optional: set when N exceeds n_bound (the lists of this view are truncated)
   uint32_t n_bound;
+  const unsigned long long* pflag;   // two-round: bit g set = Gaussian g's rect reaches a predicted-open tile (projection)
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
@@ -156,24 +148,6 @@ struct RangeBatch {
   RangeJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
-// bits of row y inside columns [x0, x1) of 64-column block wb, shifted so that bit 0 is column max(x0, 64 wb)
-__device__ __forceinline__ unsigned long long open_bits(const OpenMap& om, uint32_t y, uint32_t wb, uint32_t x0, uint32_t x1,
-                                                        uint32_t* col0) {
-  const uint32_t lo = max(x0, wb * 64u), hi = min(x1, wb * 64u + 64u);
-  const unsigned long long m = om.rows[(size_t)y * om.row_words + wb] >> (lo & 63u);
-  *col0 = lo;
-  const uint32_t w = hi - lo;
-  return w >= 64u ? m : (m & ((1ull << w) - 1ull));
-}
-// number of open tiles inside the rect
-__device__ __forceinline__ uint32_t open_tiles(uint2 rc, const OpenMap& om) {
-  const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-  if (x1 <= x0) return 0u;
-  uint32_t n = 0, c0;
-  for (uint32_t y = y0; y < y1; y++)
-    for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) n += (uint32_t)__builtin_popcountll(open_bits(om, y, wb, x0, x1, &c0));
-  return n;
-}
 // k-th open tile of the rect in row-major order (k < open_tiles(rc))
 __device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const OpenMap& om) {
   const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
@@ -211,6 +185,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // chunk sums AND the sums of every 256-Gaussian sub-block (iteration r of the strided loop = sub-block r): the emission
 // kernel scans inside its own sub-block, so no per-Gaussian offset array is written or read.
 constexpr int SCAN_MAX_SUBS = 64;
+// Sub-blocks of a chunk handled per step of scan_chunk_sums: the index loads, the flag / rect gathers that depend on them
+// and the stores of that many items per thread are in flight together.  The kernel is one dependent chain of memory round
+// trips per step with ~3 workgroups per CU: measured on MI355X: 4, 8 and 16 within 1 % (the rect gathers of the flagged half of the Gaussians bound the kernel).
+#ifndef B3GS_SCAN_BATCH
+#define B3GS_SCAN_BATCH 8
+#endif
+constexpr int SCAN_BATCH = B3GS_SCAN_BATCH;
 constexpr int SCAN_PRED_WORDS = 512;   // LDS copy of a tile bitmap (4 KB): up to 512 tile rows of <= 64 tiles, 256 of <= 128, ...   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
@@ -240,40 +221,54 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   }
   // tiles_touched == area of the rectangle (preprocess keeps them consistent)
   // (sub-blocks in batches of four: the four index loads, then the four dependent rect gathers, are in flight together)
+  // Behind segment 1 a Gaussian only matters when its rect reaches a predicted-open tile: the projection left that as
+  // one bit per Gaussian (125 KB per view: L2-resident), so the random 16-byte rect gather -- one 128-byte line each
+  // -- is paid for the flagged ones only (a few per cent).
   if (job.partner >= 0) {
     const ScanJob& pj = sb.j[job.partner];
     const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
+    const unsigned long long* __restrict__ fa_map = job.pflag;
+    const unsigned long long* __restrict__ fb_map = pj.pflag;
     uint2* __restrict__ sa = job.srect;
     uint2* __restrict__ sb2 = pj.srect;
-    for (int r0 = 0; r0 < subs; r0 += 4) {   // subs is a multiple of 16
-      uint32_t oi[4];
-      uint4 rr[4];
+    for (int r0 = 0; r0 < subs; r0 += SCAN_BATCH) {   // subs is a multiple of 16
+      uint32_t oi[SCAN_BATCH];
+      uint4 rr[SCAN_BATCH];
+      bool fa[SCAN_BATCH], fb[SCAN_BATCH];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
         oi[k] = i < end ? order[i] : 0u;
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-        rr[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (i < end) rr[k] = rect2[oi[k]];   // the random access of the binning: one line for both views of the pair
+        fa[k] = fb[k] = i < end;
+        if (i < end && i >= sb.K1) {
+          fa[k] = (fa_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
+          fb[k] = (fb_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
+        rr[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (fa[k] || fb[k]) rr[k] = rect2[oi[k]];   // the random access of the binning: one line for both views of the pair
+      }
+#pragma unroll
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int r = r0 + k;
         const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
         uint32_t ta = 0, tb = 0;
         if (i < end) {
           const uint2 ra = make_uint2(rr[k].x, rr[k].y), rb = make_uint2(rr[k].z, rr[k].w);
-          sa[i] = ra;
-          sb2[i] = rb;
           if (i < sb.K1) {
+            sa[i] = ra;
+            sb2[i] = rb;
             ta = rect_area(ra);
             tb = rect_area(rb);
           } else {   // behind segment 1: only the tiles predicted open
-            ta = open_tiles(ra, pa);
-            tb = open_tiles(rb, pb2);
+            if (fa[k]) { ta = open_tiles(ra, pa); sa[i] = ra; }
+            if (fb[k]) { tb = open_tiles(rb, pb2); sb2[i] = rb; }
             job.scount[i] = ta;
             pj.scount[i] = tb;
           }
@@ -287,32 +282,36 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   } else {
     const uint2* __restrict__ rect = job.rect;
     const size_t stride = (size_t)job.rect_stride;
+    const unsigned long long* __restrict__ f_map = job.pflag;
     uint2* __restrict__ srect = job.srect;
-    for (int r0 = 0; r0 < subs; r0 += 4) {
-      uint32_t oi[4];
-      uint2 rr[4];
+    for (int r0 = 0; r0 < subs; r0 += SCAN_BATCH) {
+      uint32_t oi[SCAN_BATCH];
+      uint2 rr[SCAN_BATCH];
+      bool fl[SCAN_BATCH];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
         oi[k] = i < end ? order[i] : 0u;
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+        fl[k] = i < end;
+        if (i < end && i >= sb.K1) fl[k] = (f_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
         rr[k] = make_uint2(0u, 0u);
-        if (i < end) rr[k] = rect[oi[k] * stride];
+        if (fl[k]) rr[k] = rect[oi[k] * stride];
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < SCAN_BATCH; k++) {
         const int r = r0 + k;
         const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
         uint32_t t = 0;
         if (i < end) {
-          srect[i] = rr[k];
           if (i < sb.K1) {
+            srect[i] = rr[k];
             t = rect_area(rr[k]);
           } else {
-            t = open_tiles(rr[k], pa);
+            if (fl[k]) { t = open_tiles(rr[k], pa); srect[i] = rr[k]; }
             job.scount[i] = t;
           }
         }
@@ -581,6 +580,193 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb,
   radix_scatter_body<HAS_VAL, BITS>(sb, pass_shift, blockIdx.x, blockIdx.y, sh);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Depth sort in THREE passes of 9-bit digits (B3gsForwardView::depth_key_bits = 27).  A visible Gaussian has view z >
+// 0.2 (B3GS_NEAR), so its key -- the float bits of z -- is at least KEY27_BASE = bits(0.2f); keys of z up to ~13107
+// lie within 2^27 of it.  The first pass maps  key -> key - KEY27_BASE  (culled keys 0xFFFFFFFF -> 2^27 - 1, the
+// largest value) on the fly: order-preserving, ties keep their index order, so the resulting permutation is the one
+// the four 8-bit passes over all 32 bits produce.  The assumption is CHECKED, not trusted: the projection raises bit 1
+// of the caller's overflow word when a visible key falls outside the span (preprocess.hip), which drops that step on
+// the device like a capacity overflow and makes the host fall back to the full 32-bit sort.
+// Same structure as the 8-bit kernels above with 512 digits (thread t owns digits t and t + 256).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t KEY27_BASE = 0x3E4CCCCDu;          // float bits of B3GS_NEAR
+constexpr uint32_t KEY27_SPAN = 1u << 27;
+__device__ __forceinline__ uint32_t key27(uint32_t k) {
+  if (k == 0xFFFFFFFFu) return KEY27_SPAN - 1u;       // culled: sinks to the end
+  const uint32_t d = k > KEY27_BASE ? k - KEY27_BASE : 0u;
+  return d < KEY27_SPAN - 2u ? d : KEY27_SPAN - 2u;   // (out-of-span keys are flagged by the projection)
+}
+
+__global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix9_hist(SortBatch sb, int shift, int xform) {
+  __shared__ uint32_t h[HIST_TILES][512];
+  const SortJob& job = sb.j[blockIdx.y];
+  const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
+  const uint32_t blk0 = blockIdx.x * HIST_TILES;
+  if (blk0 >= job.nblk) return;
+  const uint32_t* __restrict__ keys = job.kin;
+  const uint32_t n = job.n_cap;
+  if ((uint64_t)blk0 * B3GS_SORT_TILE >= n) return;
+  h[sub][t] = 0;
+  h[sub][t + 256] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)(blk0 + sub) * B3GS_SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+    const uint64_t i = base + k * B3GS_SORT_THREADS + t;
+    if (i < n) {
+      uint32_t kk = keys[i];
+      if (xform) kk = key27(kk);
+      atomicAdd(&h[sub][(kk >> shift) & 0x1FF], 1u);
+    }
+  }
+  __syncthreads();
+  if (sub == 0) {
+    const uint32_t hs = hist_stride(job.nblk);
+    *reinterpret_cast<uint4*>(job.hist + (size_t)t * hs + blk0) = make_uint4(h[0][t], h[1][t], h[2][t], h[3][t]);
+    *reinterpret_cast<uint4*>(job.hist + (size_t)(t + 256) * hs + blk0) =
+        make_uint4(h[0][t + 256], h[1][t + 256], h[2][t + 256], h[3][t + 256]);
+  }
+}
+
+__global__ void __launch_bounds__(256) radix9_rowscan(SortBatch sb) {
+  __shared__ uint32_t tmp[8];
+  const SortJob& job = sb.j[blockIdx.y];
+  const uint32_t nblk = job.nblk;
+  const uint32_t used = min(nblk, (job.n_cap + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);
+  uint32_t* row = job.hist + (size_t)blockIdx.x * hist_stride(nblk);
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < used; b0 += 256) {
+    uint32_t i = b0 + threadIdx.x;
+    uint32_t v = i < used ? row[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_excl_scan_256(v, tmp, &tot);
+    if (i < used) row[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) job.hist[(size_t)512 * hist_stride(nblk) + blockIdx.x] = carry;  // totals
+}
+
+__global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb, int shift, int xform) {
+  __shared__ uint32_t wave_cnt[4][512];
+  __shared__ uint32_t blk_start[512];
+  __shared__ uint32_t gbase[512];
+  __shared__ uint32_t tmp[8];
+  __shared__ uint32_t s_key[B3GS_SORT_TILE];
+  __shared__ uint32_t s_val[B3GS_SORT_TILE];
+  const SortJob& job = sb.j[blockIdx.y];
+  if (blockIdx.x >= job.nblk) return;
+  const uint32_t* __restrict__ keys_in = job.kin;
+  const uint32_t* __restrict__ vals_in = job.vin;
+  uint32_t* __restrict__ keys_out = job.kout;
+  uint32_t* __restrict__ vals_out = job.vout;
+  const uint32_t nblk = job.nblk;
+  const uint32_t* __restrict__ hist = job.hist;
+  const uint32_t hstride = hist_stride(nblk);
+  const uint32_t* __restrict__ totals = job.hist + (size_t)512 * hstride;
+  const uint32_t n = job.n_cap;
+  const uint32_t tile_base = blockIdx.x * B3GS_SORT_TILE;
+  if (tile_base >= n) return;
+  const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
+  const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+  const u64 lt = lanemask_lt();
+#pragma unroll
+  for (int k = 0; k < 4; k++) { wave_cnt[k][threadIdx.x] = 0; wave_cnt[k][threadIdx.x + 256] = 0; }
+  __syncthreads();
+  uint32_t key[B3GS_SORT_ITEMS], val[B3GS_SORT_ITEMS], rank[B3GS_SORT_ITEMS];
+#pragma unroll
+  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
+    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+    const bool valid = li < tile_n;
+    const uint32_t gi = tile_base + li;
+    uint32_t kk = valid ? keys_in[gi] : 0xFFFFFFFFu;
+    if (xform && valid) kk = key27(kk);
+    key[r] = kk;
+    val[r] = valid ? (vals_in ? vals_in[gi] : gi) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
+    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+    const bool valid = li < tile_n;
+    const uint32_t d = (key[r] >> shift) & 0x1FF;
+    u64 m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 9; b++) {
+      const bool bit = (d >> b) & 1u;
+      const u64 bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const uint32_t before = (uint32_t)__popcll(m & lt);
+    const uint32_t cnt = wave_cnt[w][d];
+    rank[r] = cnt + before;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0) wave_cnt[w][d] = cnt + (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {   // per digit (thread t owns digits t and t + 256): prefix over the 4 waves, workgroup digit start, global base
+    uint32_t c[2][4], tot[2], dt[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t d = threadIdx.x + 256u * h;
+#pragma unroll
+      for (int k = 0; k < 4; k++) c[h][k] = wave_cnt[k][d];
+      tot[h] = (c[h][0] + c[h][1]) + (c[h][2] + c[h][3]);
+      dt[h] = totals[d];
+    }
+    uint32_t lo_tot, hi_tot, lo_dtot, hi_dtot;
+    const uint32_t s0 = block_excl_scan_256(tot[0], tmp, &lo_tot);
+    const uint32_t s1 = block_excl_scan_256(tot[1], tmp, &hi_tot) + lo_tot;
+    const uint32_t g0 = block_excl_scan_256(dt[0], tmp, &lo_dtot);
+    const uint32_t g1 = block_excl_scan_256(dt[1], tmp, &hi_dtot) + lo_dtot;
+    const uint32_t start[2] = {s0, s1}, dbase[2] = {g0, g1};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const uint32_t d = threadIdx.x + 256u * h;
+      wave_cnt[0][d] = start[h];
+      wave_cnt[1][d] = start[h] + c[h][0];
+      wave_cnt[2][d] = start[h] + c[h][0] + c[h][1];
+      wave_cnt[3][d] = start[h] + c[h][0] + c[h][1] + c[h][2];
+      blk_start[d] = start[h];
+      gbase[d] = dbase[h] + hist[(size_t)d * hstride + blockIdx.x];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
+    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+    if (li < tile_n) {
+      const uint32_t d = (key[r] >> shift) & 0x1FF;
+      const uint32_t p = wave_cnt[w][d] + rank[r];
+      s_key[p] = key[r];
+      s_val[p] = val[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+    const uint32_t p = k * B3GS_SORT_THREADS + threadIdx.x;
+    if (p < tile_n) {
+      const uint32_t kk = s_key[p];
+      const uint32_t d = (kk >> shift) & 0x1FF;
+      const uint32_t dst = gbase[d] + (p - blk_start[d]);
+      keys_out[dst] = kk;
+      vals_out[dst] = s_val[p];
+    }
+  }
+}
+
+// one 9-bit pass over all jobs (depth keys only: every job has values, n = n_cap = P)
+void radix9_pass(SortBatch& sb, int shift, bool xform, hipStream_t s) {
+  uint32_t max_blk = 0;
+  for (int k = 0; k < sb.n; k++) max_blk = sb.j[k].nblk > max_blk ? sb.j[k].nblk : max_blk;
+  if (sb.n <= 0 || max_blk == 0) return;
+  hipLaunchKernelGGL(radix9_hist, dim3((max_blk + HIST_TILES - 1) / HIST_TILES, sb.n), dim3(HIST_TILES * B3GS_SORT_THREADS), 0, s,
+                     sb, shift, xform ? 1 : 0);
+  hipLaunchKernelGGL(radix9_rowscan, dim3(512, sb.n), dim3(256), 0, s, sb);
+  hipLaunchKernelGGL(radix9_scatter, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift, xform ? 1 : 0);
+}
+
 // one pass over all jobs; swaps every job's in/out buffers afterwards (vin becomes non-null)
 template <int BITS>
 void launch_scatter(const SortBatch& sb, bool any_val, uint32_t max_blk, int shift, hipStream_t s) {
@@ -736,7 +922,10 @@ __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
 // tiles that segment 1 did not finish
 // ---------------------------------------------------------------------------------------------
 struct Scan2Job {
-  const uint2* srect;       // rects in depth order (written for all P Gaussians by the first scan)
+  const uint32_t* order;    // depth order and the rects by Gaussian: the first scan stored the rects of the Gaussians behind
+  const uint2* rect;        //   segment 1 only where they reach a predicted tile, so this (rare) round gathers them itself
+  int32_t rect_stride;
+  uint2* srect;             // rects in depth order: completed here for [K1, P) (the emission reads them)
   uint32_t* scount;
   uint32_t* soffs;
   uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
@@ -762,20 +951,30 @@ __device__ __forceinline__ void scan2_chunk_sums_body(const Scan2Batch& sb, uint
   const int64_t begin = (int64_t)sb.K1 + (int64_t)bx * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   uint32_t sum = 0;
-  const uint2* __restrict__ srect = job.srect;
+  const uint32_t* __restrict__ order = job.order;
+  const uint2* __restrict__ rect = job.rect;
+  const size_t stride = (size_t)job.rect_stride;
+  uint2* __restrict__ srect = job.srect;
   uint32_t* __restrict__ scount = job.scount;
-  for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * SCAN_THREADS) {   // four rect loads in flight per thread
+  for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * SCAN_THREADS) {   // four rect gathers in flight per thread
+    uint32_t oi[4];
     uint2 rc[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
-      rc[k] = i < end ? srect[i] : make_uint2(0u, 0u);
+      oi[k] = i < end ? order[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
+      rc[k] = i < end ? rect[oi[k] * stride] : make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
       if (i < end) {
         const uint32_t t = open_tiles(rc[k], job.open);
+        srect[i] = rc[k];
         scount[i] = t;
         sum += t;
       }
@@ -1065,28 +1264,35 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     }
     return;
   }
-  // ---- 1. depth order: 4 passes depth_key -> skey[1] -> skey[0] -> skey[1] -> skey[0] for every view that
-  //         does not borrow another view's order; result in sval[0]
+  // ---- 1. depth order for every view that does not borrow another view's order; result in sval[0] / skey[0]:
+  //         4 passes of 8 bits  depth_key -> [1] -> [0] -> [1] -> [0], or -- when every job of the batch vouches for
+  //         the 27-bit key span (BinJob::key_bits == 27) -- 3 passes of 9 bits  depth_key -> [0] -> [1] -> [0]
   SortBatch db;
   db.n = 0;
   const uint32_t pblk = b3gs_sort_blocks((int64_t)P);
+  bool span27 = true;
+  for (int v = 0; v < nviews; v++) span27 = span27 && jobs[v].key_bits == 27;
+  const int npass = span27 ? 3 : 4;
+  const int first_dst = span27 ? 0 : 1;
   for (int v = 0; v < nviews; v++) {
     if (jobs[v].order_from != -1) continue;
     const GeomView& g = jobs[v].g;
-    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[1], g.sval[1], nullptr, (uint32_t)P, pblk, 0, g.hist, nullptr, nullptr};
+    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[first_dst], g.sval[first_dst], nullptr, (uint32_t)P, pblk, 0, g.hist,
+                           nullptr, nullptr};
   }
-  for (int pass = 0; pass < 4; pass++) {
-    radix_pass(db, 8 * pass, s);
+  for (int pass = 0; pass < npass; pass++) {
+    if (span27) radix9_pass(db, 9 * pass, pass == 0, s);
+    else radix_pass(db, 8 * pass, s);
     int k = 0;
     for (int v = 0; v < nviews; v++) {
       if (jobs[v].order_from != -1) continue;
       const GeomView& g = jobs[v].g;
-      const int dst = pass & 1;  // destination of the NEXT pass: [0], [1], [0]
+      const int src = (first_dst + pass) & 1;   // where this pass wrote: the next one reads it and writes the other
       SortJob& j = db.j[k++];
-      j.kin = g.skey[dst ^ 1];
-      j.vin = g.sval[dst ^ 1];
-      j.kout = g.skey[dst];
-      j.vout = g.sval[dst];
+      j.kin = g.skey[src];
+      j.vin = g.sval[src];
+      j.kout = g.skey[src ^ 1];
+      j.vout = g.sval[src ^ 1];
     }
   }
 
@@ -1111,7 +1317,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
                       jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
                       open_map(jb.im.pred_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
-                      (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0)};
+                      (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0), jb.g.pflag};
   }
   // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
   // into d's gather
@@ -1223,7 +1429,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   sc.nchunks = (total_tiles + sc.tiles_per_chunk - 1) / sc.tiles_per_chunk;
   for (int v = 0; v < nviews; v++) {
     const BinJob& jb = jobs[v];
-    sc.j[v] = Scan2Job{jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp, jb.g.header, jb.im.header, jb.n_out,
+    sc.j[v] = Scan2Job{depth_order_of(jobs, v), jb.rect ? jb.rect : jb.g.rect, jb.rect ? jb.rect_stride : 1,
+                       jb.g.srect, jb.g.scount, jb.g.soffs, jb.g.scan_tmp, jb.g.header, jb.im.header, jb.n_out,
                        open_map(jb.im.open_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
                        (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0)};
   }

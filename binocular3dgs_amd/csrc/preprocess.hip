@@ -187,6 +187,7 @@ __device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, floa
   return r;
 }
 
+constexpr int PRE_PRED_WORDS = 128;   // LDS copy of one view's predicted-open bitmap (8 KB for 8 views)
 template <bool RAW>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,13 +197,16 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
       pb.out[v].ranges2[i] = make_uint2(0xFFFFFFFFu, 0u);
     }
   for (int v = 0; v < pb.n; v++)
-    if (i < pb.out[v].nrowwords) {
-      pb.out[v].open_rows[i] = 0ull;
-      if (pb.out[v].pred_rows) {   // two-round forward: the tiles the previous forward left unterminated are predicted open
-        pb.out[v].pred_rows[i] = pb.out[v].pred_next[i];
-        pb.out[v].pred_next[i] = 0ull;
-      }
-    }
+    if (i < pb.out[v].nrowwords) pb.out[v].open_rows[i] = 0ull;
+  // two-round forward: the bitmaps of the tiles predicted open (304 bytes per view at 800x600) are read once per
+  // Gaussian and view below -- staged in LDS when they fit
+  __shared__ unsigned long long s_pred[B3GS_MAX_FUSED_VIEWS][PRE_PRED_WORDS];
+  if (pb.out[0].pred_rows) {
+    for (int v = 0; v < pb.n; v++)
+      if (pb.out[v].nrowwords <= PRE_PRED_WORDS && (int)threadIdx.x < pb.out[v].nrowwords)
+        s_pred[v][threadIdx.x] = pb.out[v].pred_rows[threadIdx.x];
+    __syncthreads();
+  }
   if (i >= pb.sc[0].P) return;
   // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
   // scale modifier), activated opacity
@@ -319,6 +323,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
   g.radii[i] = radius_out;
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
+  // the three-pass depth sort assumes every visible key within 2^27 of the float bits of the near plane (binning.hip):
+  // say so when one is not (z > ~13107, or a prefiltered Gaussian in front of the near plane)
+  if (g.span_flag && dkey != 0xFFFFFFFFu && (dkey <= 0x3E4CCCCDu || dkey - 0x3E4CCCCDu >= (1u << 27) - 2u))
+    atomicOr(g.span_flag, 2);
+  if (g.pred_rows) {
+    // two-round forward: does this Gaussian reach a tile that is predicted open?  One bit per Gaussian (a wave's 64
+    // consecutive Gaussians = one word): behind segment 1 the scan gathers a rect only where the bit is set
+    const bool hit = touched != 0u &&
+                     open_tiles(rect, open_map(g.nrowwords <= PRE_PRED_WORDS ? s_pred[v] : g.pred_rows, sc.W, sc.H)) != 0u;
+    const unsigned long long word = __ballot(hit);
+    if ((threadIdx.x & 63u) == 0u) g.pflag[(size_t)i >> 6] = word;
+  }
   if (g.rect_role == 1) held_rect = rect;
   else if (g.rect_role == 2) reinterpret_cast<uint4*>(g.rect - 1)[i] = make_uint4(held_rect.x, held_rect.y, rect.x, rect.y);
   else g.rect[(size_t)i * g.rect_stride] = rect;
@@ -885,8 +901,9 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.ranges = im.ranges;
   o.ranges2 = im.ranges2;
   o.open_rows = im.open_rows;
+  o.span_flag = nullptr;   // set by b3gs_forward_raw_batch when the 27-bit depth sort is requested
   o.pred_rows = nullptr;   // set by the two-round forward (b3gs_forward_raw_batch)
-  o.pred_next = nullptr;
+  o.pflag = g.pflag;
   o.nrowwords = ((sc.H + B3GS_TILE - 1) / B3GS_TILE) * (((sc.W + B3GS_TILE - 1) / B3GS_TILE + 63) / 64);
   o.ntiles = ((sc.W + B3GS_TILE - 1) / B3GS_TILE) * ((sc.H + B3GS_TILE - 1) / B3GS_TILE);
   return o;

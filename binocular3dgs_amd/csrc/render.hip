@@ -276,7 +276,7 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
           const uint32_t wq = work - 1u;
           const uint32_t lw = wq < tl.len1 ? tl.list1[tl.first1 + wq] : tl.list2[tl.first2 + (wq - tl.len1)];
           const float zdeep = reinterpret_cast<const float*>(rec + 4 * (size_t)(lw & bv.idx_mask) + 2)[1];
-          if (!(__float_as_uint(zdeep) < *bv.z_clear)) atomicOr(&bv.pred_next[word], bit);
+          if (!(__float_as_uint(zdeep) - bv.z_base < *bv.z_clear)) atomicOr(&bv.pred_next[word], bit);
         } else if (!predicted && bv.pred_next && 4u * work > 3u * tl.len1) {
           // terminated, but only in the last quarter of its segment-1 prefix: one optimiser step can push it over the
           // end (measured at the headline: a tile at that margin was left open every other iteration, and every such
@@ -328,6 +328,22 @@ __global__ void __launch_bounds__(256) render_fwd_repair_kernel(BlendBatch batch
 #pragma unroll
   for (int k = 0; k < B3GS_MAX_FUSED_VIEWS; k++)
     if (k < batch.n) any = any || *batch.v[k].open_count != 0u;
+  // This is the last kernel of a two-round forward: the prediction the first blend pass collected (pred_next) becomes
+  // the prediction of the NEXT forward into these image buffers.  Nothing below reads either bitmap (the second pass
+  // does not predict), and the next forward's projection needs pred_rows complete before its first workgroup starts.
+  if (blockIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < B3GS_MAX_FUSED_VIEWS; k++)
+      if (k < batch.n && batch.v[k].pred_next) {
+        const BlendView& v = batch.v[k];
+        unsigned long long* pr = const_cast<unsigned long long*>(v.pred_rows);
+        const int nwords = v.row_words * (v.ntiles / v.grid_x);
+        for (int i = (int)threadIdx.x; i < nwords; i += 256) {
+          pr[i] = v.pred_next[i];
+          v.pred_next[i] = 0ull;
+        }
+      }
+  }
   if (!any) return;
   for (int bid = (int)blockIdx.x; bid < total; bid += (int)gridDim.x) {
     render_fwd_tile<CHUNK, false>(select_view(batch, bid), bid, 0u, sh, s_work, nullptr);
@@ -796,6 +812,7 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   v.pred_rows = nullptr;
   v.pred_next = nullptr;
   v.z_clear = nullptr;
+  v.z_base = 0u;
   v.open_count = im.header + 3;
   v.row_words = (v.grid_x + 63) / 64;
   v.round = 0;

@@ -129,6 +129,10 @@ class FusedRasterizer:
         # the optimiser and the densification statistics skip every step while it is set (B3gsForwardView::overflow_flag,
         # b3gs_adam_step(skip_if_nonzero)), so check_overflow() finds the state of the last complete step
         self.overflow_flag = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        # depth sort on 27-bit keys (three 9-bit passes instead of four 8-bit ones): valid while every visible Gaussian
+        # has view z < ~13107; the projection checks it and raises bit 1 of overflow_flag otherwise -> check_overflow()
+        # falls back to the full 32-bit sort for good
+        self.depth_key_bits = 27
         self.slots: List[_Slot] = [self._new_slot(torch.cuda.Stream(self.dev), k) for k in range(num_slots)]
         self._deferred = None   # [(spec, B3gsScene)] while a deferred-accumulate section is open
         self._params = _lib.B3gsRawParams()
@@ -216,6 +220,7 @@ class FusedRasterizer:
                     arr[k].seg1_fraction = self.seg1_fraction
                     arr[k].high_water = self.high_water[sp["slot"]:sp["slot"] + 1].data_ptr()
                     arr[k].overflow_flag = self.overflow_flag.data_ptr()
+                    arr[k].depth_key_bits = self.depth_key_bits
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
@@ -386,13 +391,16 @@ class FusedRasterizer:
         the last complete step and the caller simply repeats from there.  (The reference sizes the binning buffer from
         N on every render: one blocking read-back per view.)"""
         hw = int(self.high_water.max().item())
-        flagged = bool(int(self.overflow_flag.item()))
+        flag = int(self.overflow_flag.item())
         self.high_water.zero_()
         self._check_repair_status()
-        if hw <= self.capacity and not flagged:
+        if hw <= self.capacity and not flag:
             return 0
         self.overflow_flag.zero_()
-        self.grow(need=hw)
+        if flag & 2:                    # a depth key outside the 27-bit span: sort all 32 bits from now on
+            self.depth_key_bits = 0
+        if hw > self.capacity or (flag & 1):
+            self.grow(need=hw)
         return max(hw, 1)
 
     def _check_repair_status(self):

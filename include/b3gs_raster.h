@@ -186,6 +186,11 @@ typedef struct B3gsForwardView {
    * the flag, grown the buffers and cleared it: the steps since the last check can really be repeated. */
   int32_t* high_water;
   int32_t* overflow_flag;
+  /* 27: the caller vouches that every visible Gaussian's depth key (float bits of view z > 0.2) lies within 2^27 of the
+   * bits of 0.2f, i.e. z < ~13107: the depth sort then runs three 9-bit passes instead of four 8-bit ones (same
+   * permutation).  The library CHECKS it: a key outside the span raises bit 1 of *overflow_flag (required non-NULL for
+   * this mode), which drops the step like a capacity overflow; the caller then falls back to 0.  0 (or 32): full sort. */
+  int32_t depth_key_bits;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);

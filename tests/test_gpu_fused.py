@@ -641,6 +641,74 @@ def test_two_round_binning_equals_one_round(scene):
                     assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
 
 
+def _lists(fr, P, W, H, slots):
+    from binocular3dgs_amd.debug import state_views
+    out = []
+    for s in slots:
+        sl = fr.slots[s]
+        v = state_views(P, W, H, fr.capacity, sl.geom, sl.binning, sl.img)
+        n = int(v["counts"][0])
+        out.append((n, v["point_list"][:n].clone(), v["ranges"].clone()))
+    return out
+
+
+@pytest.mark.parametrize("P,W,H", [(30000, 208, 144), (3, 16, 16), (4097, 64, 48)])
+def test_three_pass_depth_sort_equals_four_pass(P, W, H):
+    """B3gsForwardView::depth_key_bits = 27: three 9-bit radix passes over (key - bits(0.2f)) give the permutation of the
+    four 8-bit passes over all 32 key bits -- tile lists, ranges and images bit for bit, culled Gaussians (behind the
+    near plane) included, ties (equal depths) in index order."""
+    from binocular3dgs_amd.fused import FusedRasterizer
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    with torch.no_grad():
+        model._xyz[: P // 7, 2] -= 12.0                    # a good part behind the camera: culled keys sink to the end
+        model._xyz[P // 2: P // 2 + P // 9] = model._xyz[P // 2: P // 2 + 1]   # identical positions: equal keys
+    views = [(pairs[0][0], 0, True), (pairs[0][1], 1, False), (pairs[1][0], 2, True)]
+    res = []
+    for bits in (27, 0):
+        fr = FusedRasterizer(model, W, H, num_slots=3, seg1_fraction=0.0)
+        fr.depth_key_bits = bits
+        with torch.no_grad():
+            outs = fr.render_batch(views, bg)
+        torch.cuda.synchronize()
+        assert int(fr.overflow_flag.item()) == 0
+        res.append(([o["render"].clone() for o in outs], _lists(fr, P, W, H, (0, 1, 2))))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for (na, la, ra), (nb, lb, rb) in zip(res[0][1], res[1][1]):
+        assert na == nb and torch.equal(la, lb) and torch.equal(ra, rb)
+
+
+def test_depth_key_outside_the_27_bit_span_is_detected_and_falls_back():
+    """A visible Gaussian farther than z ~ 13107 does not fit the 27-bit key span: the projection raises bit 1 of the
+    overflow word (the step is dropped on the device like a capacity overflow), check_overflow() switches the rasterizer
+    to the full 32-bit sort, and the repeated render equals a rasterizer that sorted 32 bits from the start."""
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H, P = 160, 120, 5000
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    cam = pairs[0][0]
+    with torch.no_grad():
+        # push a few Gaussians 20000 units out along the viewing direction (camera space +z), scaled up to stay visible
+        R = cam.world_view_transform[:3, :3]               # row-vector convention: x_cam = x_world @ R + t
+        fwd = R[:, 2]
+        model._xyz[:8] = cam.camera_center + 20000.0 * fwd + 50.0 * torch.randn(8, 3, device="cuda")
+        model._scaling[:8] += 9.0
+    views = [(cam, 0, True)]
+    ref = FusedRasterizer(model, W, H, num_slots=1, seg1_fraction=0.0)
+    ref.depth_key_bits = 0
+    with torch.no_grad():
+        want = ref.render_batch(views, bg)[0]["render"].clone()
+    fr = FusedRasterizer(model, W, H, num_slots=1, seg1_fraction=0.0)
+    assert fr.depth_key_bits == 27
+    with torch.no_grad():
+        fr.render_batch(views, bg)
+    torch.cuda.synchronize()
+    assert int(fr.overflow_flag.item()) & 2
+    assert fr.check_overflow() and fr.depth_key_bits == 0 and int(fr.overflow_flag.item()) == 0
+    with torch.no_grad():
+        got = fr.render_batch(views, bg)[0]["render"]
+    assert torch.equal(got, want) and not fr.check_overflow()
+
+
 @pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16)])
 def test_two_round_binning_edge_sizes(P, W, H):
     """Two-round binning at the edges: a single tile (no tile-sort pass: the ranges of segment 2 come from tile_ranges
