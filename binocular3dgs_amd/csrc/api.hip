@@ -371,7 +371,8 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     jobs[k].rect = pb.out[k].rect;
     jobs[k].rect_stride = pb.out[k].rect_stride;
   }
-  bb.order_buf = jobs[0].im.order;   // the forward follows the longest-tile-first order of the previous backward, if any
+  // the forward follows the longest-tile-first order of the previous backward, if the image buffer can hold one
+  bb.order_buf = views[0].fresh_image ? nullptr : jobs[0].im.order;
   pb.raw = *params;
   // two-round binning: the same K1 for every view of the batch; needs packed instance words and one tile-sort depth
   const int32_t P = views[0].view->P;
@@ -379,7 +380,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   {
     float frac = views[0].seg1_fraction;
     if (const char* e = getenv("B3GS_SEG1_FRAC")) frac = (float)atof(e);
-    if (frac > 0.0f && frac < 1.0f && P > 1) {
+    if (frac > 0.0f && frac < 1.0f && P > 1 && !views[0].fresh_image) {
       K1 = (int32_t)((double)frac * (double)P + 0.999999);
       K1 = K1 < 1 ? 1 : K1;
       for (int k = 0; k < nviews && K1; k++) {

@@ -44,6 +44,10 @@ class GaussianModel:
         self._scaling, self._rotation, self._opacity = e, e, e
         self.optimizer = None            # scene/gaussian_model.py:56-58
         self.spatial_lr_scale = 0
+        # scene/gaussian_model.py:33-43 (setup_functions): render() recognises a raw-parameter model by these
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
 
     @classmethod
     def from_tensors(cls, xyz, features_dc, features_rest, scaling, rotation, opacity, sh_degree=1,
@@ -97,11 +101,11 @@ class GaussianModel:
 
     @property
     def get_scaling(self):
-        return torch.exp(self._scaling)
+        return self.scaling_activation(self._scaling)
 
     @property
     def get_rotation(self):
-        return torch.nn.functional.normalize(self._rotation)
+        return self.rotation_activation(self._rotation)
 
     @property
     def get_xyz(self):
@@ -113,7 +117,7 @@ class GaussianModel:
 
     @property
     def get_opacity(self):
-        return torch.sigmoid(self._opacity)
+        return self.opacity_activation(self._opacity)
 
     def get_covariance(self, scaling_modifier=1):
         return covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)

@@ -130,6 +130,7 @@ class _LazyN:
         self.pinned = None
         self.slot = 0
         self.enabled = os.environ.get("B3GS_DROPIN_SYNC", "0") != "1"
+        self.key_bits = 27     # fused render() node: depth sort on 27-bit keys until a render reports a key outside the span
 
     def note(self, key, n):
         self.capacity[key] = max(self.capacity.get(key, 0), int(n * self.HEADROOM), 1 << 16)
@@ -142,9 +143,15 @@ class _LazyN:
         n = int(host[0])
         if n > cap * self.REGROW_AT:
             self.note(key, n)
+        if host.numel() > 1 and int(host[1]) & 2:     # fused render() node: a depth key outside the 27-bit span
+            self.key_bits = 0
+            return (n, cap, "a depth key outside the 27-bit span of the three-pass sort (z > ~13107); the full 32-bit "
+                            "sort is used from now on")
         return (n, cap) if n > cap else None
 
-    def _error(self, key, n, cap, when):
+    def _error(self, key, n, cap, when, why=None):
+        if why is not None:
+            return _lib.B3gsError(f"B3GS_ERR_CAPACITY: {when} render of shape {key[1:]} had {why} -- repeat the step")
         return _lib.B3gsError(f"B3GS_ERR_CAPACITY: {when} render of shape {key[1:]} produced {n} tile instances, its "
                               f"binning buffer held {cap} (truncated lists); the capacity is now {self.capacity[key]} "
                               f"-- repeat the step")
@@ -162,7 +169,7 @@ class _LazyN:
                 over = (tok[0],) + r
         self.pending = keep
         if over is not None:
-            raise self._error(over[0], over[1], over[2], "an earlier")
+            raise self._error(over[0], over[1], over[2], "an earlier", *over[3:])
 
     def confirm(self, tok):
         """Backward entry: this render's N must have fitted its buffer."""
@@ -171,14 +178,14 @@ class _LazyN:
         r = self._resolve(tok)
         self.pending = [t for t in self.pending if t is not tok]
         if r is not None:
-            raise self._error(tok[0], r[0], r[1], "this")
+            raise self._error(tok[0], r[0], r[1], "this", *r[2:])
 
     def track(self, key, cap, n_dev):
         if self.pinned is None:
-            self.pinned = torch.zeros((self.RING,), dtype=torch.int32).pin_memory()
+            self.pinned = torch.zeros((self.RING, 2), dtype=torch.int32).pin_memory()
         if len(self.pending) >= self.RING - 1:
             self.poll(force=True)
-        host = self.pinned[self.slot:self.slot + 1]
+        host = self.pinned[self.slot, :n_dev.numel()]     # n_dev: [N] or [N, overflow word]
         self.slot = (self.slot + 1) % self.RING
         host.copy_(n_dev, non_blocking=True)
         ev = torch.cuda.Event()
@@ -379,6 +386,187 @@ class _RasterizeGaussians(torch.autograd.Function):
                 pick(grad_colors_precomp, colors_precomp.numel() != 0, 3), pick(grad_opacities, True, 4),
                 pick(grad_scales, scales.numel() != 0, 5), pick(grad_rotations, rotations.numel() != 0, 6),
                 pick(grad_cov3Ds_precomp, cov3Ds_precomp.numel() != 0, 7), None, None)[:ctx.n_inputs]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# render() handed a GaussianModel: one autograd node on the RAW parameters
+# ---------------------------------------------------------------------------------------------------------------
+_INPLACE_GRADS = os.environ.get("B3GS_DROPIN_INPLACE_GRADS", "1") != "0"
+_raw_scratch = {}     # (device index, P) -> zeroed [P * 10] floats, left clean by every backward (b3gs_backward_raw_accumulate)
+
+
+def raw_model_ok(pc) -> bool:
+    """True when `pc` stores the reference's six raw parameter tensors and activates them the reference's way
+    (scene/gaussian_model.py:33-43: exp / sigmoid / normalize; get_features = cat(_features_dc, _features_rest)) -- then
+    render() can hand the RAW tensors to the library, which evaluates the activations and their backward in-kernel."""
+    try:
+        return (pc.scaling_activation is torch.exp and pc.opacity_activation is torch.sigmoid and
+                pc.rotation_activation is torch.nn.functional.normalize and
+                all(torch.is_tensor(getattr(pc, a)) and getattr(pc, a).is_cuda and getattr(pc, a).dtype == torch.float32
+                    and getattr(pc, a).is_contiguous()
+                    for a in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")))
+    except AttributeError:
+        return False
+
+
+_word_ring = {}       # device index -> [zeroed int32 ring, next pair]
+
+
+def _zero_words(dev):
+    """Two zeroed int32 words on `dev` without a fill kernel per render: pairs of a ring that is zeroed once per lap (a
+    pair handed out is read by the host long before the ring comes round: 4096 renders later)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _word_ring.get(idx)
+    if ent is None or ent[1] >= ent[0].shape[0]:
+        ent = _word_ring[idx] = [torch.zeros((4096, 2), dtype=torch.int32, device=dev), 0]
+    w = ent[0][ent[1]]
+    ent[1] += 1
+    return w
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    """gaussian_renderer/__init__.py:53-93 as ONE node: the accessors (get_scaling / get_rotation / get_opacity /
+    get_features: ~30 PyTorch kernels with their autograd per render) run inside the projection and chain-rule kernels
+    (b3gs_forward_raw_batch / b3gs_backward_raw_accumulate), the depth sort takes three passes, and the Gaussians are
+    binned into the tiles their alpha >= 1/255 footprint reaches (same images; `_C.rasterize_gaussians` keeps the
+    reference's binning rule and bit-exact lists).  Gradients are RETURNED to autograd (they land in `.grad` of the six
+    parameters and of the `means2D` dummy exactly like the reference's), not written behind its back."""
+
+    @staticmethod
+    def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, means2D, cfg):
+        L = _lib.lib()
+        dev, P = xyz.device, xyz.shape[0]
+        W, H = cfg["W"], cfg["H"]
+        K = f_dc.shape[1] + f_rest.shape[1]
+        sc = _lib.B3gsScene(P, int(cfg["sh_degree"]), int(K), W, H, float(cfg["tanfovx"]), float(cfg["tanfovy"]),
+                            float(cfg["scale_modifier"]), 0, int(bool(cfg["debug"])), cfg["bg"].data_ptr(), None, None, None,
+                            None, None, None, None, cfg["viewmatrix"].data_ptr(), cfg["projmatrix"].data_ptr(),
+                            cfg["campos"].data_ptr())
+        rp = _lib.B3gsRawParams()
+        rp.xyz, rp.features_dc = xyz.data_ptr(), f_dc.data_ptr()
+        rp.features_rest = f_rest.data_ptr() if f_rest.numel() else None
+        rp.scaling, rp.rotation, rp.opacity = scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr()
+        u8 = dict(dtype=torch.uint8, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        key = ("raw", dev.index if dev.index is not None else torch.cuda.current_device(), P, W, H)
+        lazy = bool(cfg["differentiated"]) and _lazy.enabled and not cfg["debug"]
+        if lazy:
+            _lazy.poll()
+        geom = torch.empty((L.b3gs_geometry_bytes(P),), **u8)
+        # recycled allocator memory: B3gsForwardView::fresh_image tells the library to read nothing from it (the batched
+        # forward otherwise trusts a tile-order array it finds behind a signature in a PERSISTENT image buffer)
+        img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
+        color, depth, alpha = torch.empty((3, H, W), **f32), torch.empty((1, H, W), **f32), torch.empty((1, H, W), **f32)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        cap = _lazy.capacity.get(key) or max(1 << 20, 12 * P)
+        while True:
+            binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+            words = _zero_words(dev)                                       # [N, overflow word], zero
+            fv = (_lib.B3gsForwardView * 1)()
+            fv[0].view = C.pointer(sc)
+            fv[0].geometry, fv[0].binning, fv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
+            fv[0].binning_capacity = cap
+            fv[0].out_color, fv[0].out_depth, fv[0].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
+            fv[0].radii, fv[0].device_num_rendered = radii.data_ptr(), words.data_ptr()
+            fv[0].depth_order_from, fv[0].seg1_fraction = -1, 0.0
+            fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
+            fv[0].depth_key_bits = _lazy.key_bits
+            fv[0].fresh_image = 1
+            with torch.cuda.device(dev):
+                _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
+            if lazy and key in _lazy.capacity:
+                ctx.lazy_token = _lazy.track(key, cap, words)
+                break
+            n, flag = (int(v) for v in words.tolist())                    # exact render: one read-back
+            _lazy.note(key, n)
+            if flag & 2:
+                _lazy.key_bits = 0
+            ctx.lazy_token = None
+            if n <= cap and not (flag & 2):
+                break
+            cap = max(cap, _lazy.capacity[key])                           # repeat with what it needs
+        ctx.cfg, ctx.sc, ctx.rp = cfg, sc, rp
+        ctx.save_for_backward(xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img)
+        ctx.cap = cap
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        _lazy.confirm(ctx.lazy_token)     # truncated lists / key span: raises before any gradient exists
+        L = _lib.lib()
+        xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img = ctx.saved_tensors
+        cfg, sc, dev, P = ctx.cfg, ctx.sc, xyz.device, xyz.shape[0]
+        W, H = cfg["W"], cfg["H"]
+        f32 = dict(dtype=torch.float32, device=dev)
+        if grad_color is None:
+            grad_color = torch.zeros((3, H, W), **f32)
+        gc = _dev_f32(grad_color, "dL_dout_color")
+        gd = None if grad_depth is None else _dev_f32(grad_depth, "dL_dout_depth")
+        ga = None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha")
+        skey = (dev.index if dev.index is not None else torch.cuda.current_device(), P)
+        scratch = _raw_scratch.get(skey)
+        if scratch is None:
+            if len(_raw_scratch) > 4:
+                _raw_scratch.clear()
+            scratch = _raw_scratch[skey] = torch.zeros((max(L.b3gs_backward_scratch_floats(P), 1),), **f32)
+        bv = (_lib.B3gsBlendView * 1)()
+        bv[0].view = C.pointer(sc)
+        bv[0].geometry, bv[0].binning, bv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
+        bv[0].dL_dcolor = gc.data_ptr()
+        bv[0].dL_ddepth = None if gd is None else gd.data_ptr()
+        bv[0].dL_dalpha = None if ga is None else ga.data_ptr()
+        bv[0].scratch, bv[0].binning_capacity = scratch.data_ptr(), ctx.cap
+        # Where the six gradients go.  Default: fresh tensors, RETURNED to autograd (AccumulateGrad keeps the first one a
+        # parameter receives and adds the later ones: one more pass over 92 B per Gaussian per render).  When every
+        # parameter is a plain leaf that already holds a dense fp32 `.grad` of its own shape and nothing hooks into its
+        # gradient, the chain-rule kernel adds into `.grad` directly (`+=`, what AccumulateGrad would do) and the node
+        # returns None for them -- same values, one pass less.  B3GS_DROPIN_INPLACE_GRADS=0 disables it.
+        params = (xyz, f_dc, f_rest, scaling, rotation, opacity)
+        inplace = _INPLACE_GRADS and all(
+            (not ctx.needs_input_grad[i]) or
+            (t.is_leaf and t.grad is not None and t.grad.dtype == torch.float32 and t.grad.shape == t.shape and
+             t.grad.is_contiguous() and t.grad.device == t.device and not t._backward_hooks and
+             not getattr(t, "_post_accumulate_grad_hooks", None))
+            for i, t in enumerate(params)) and all(ctx.needs_input_grad[:6])
+        grads = [t.grad if inplace else torch.empty_like(t) for t in params]
+        g_m2d = torch.empty((P, 3), **f32)
+        gr = _lib.B3gsRawGrads()
+        gr.xyz, gr.features_dc = grads[0].data_ptr(), grads[1].data_ptr()
+        gr.features_rest = grads[2].data_ptr() if grads[2].numel() else None
+        gr.scaling, gr.rotation, gr.opacity = grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr()
+        gr.touched_rows = None
+        av = (_lib.B3gsFusedView * 1)()
+        av[0].view = C.pointer(sc)
+        av[0].radii, av[0].geometry, av[0].scratch = radii.data_ptr(), geom.data_ptr(), scratch.data_ptr()
+        av[0].dL_dmeans2D, av[0].densify_stats = g_m2d.data_ptr(), 0
+        with torch.cuda.device(dev):
+            s = _stream(dev)
+            _lib.check(L.b3gs_blend_backward_batch(1, bv, s), "b3gs_blend_backward_batch")
+            # overwrite mode: every row of every gradient tensor is stored (zeros for Gaussians without a contribution);
+            # accumulate mode (in place): only the rows that received something are touched
+            _lib.check(L.b3gs_backward_raw_accumulate(1, av, C.byref(ctx.rp), C.byref(gr), 0 if inplace else 1, None, s),
+                       "b3gs_backward_raw_accumulate")
+        needs = ctx.needs_input_grad
+        out = [None if (inplace or not needs[i]) else g for i, g in enumerate(grads)]
+        return (*out, g_m2d if needs[6] else None, None)
+
+
+def rasterize_raw(pc, means2D, raster_settings):
+    """render()'s fast path: `pc` = a model raw_model_ok() accepts.  -> (color, radii, depth, alpha)."""
+    rs = raster_settings
+    dev = pc._xyz.device
+    t = [_dev_f32(x, n).reshape(-1) for x, n in ((rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"), (rs.projmatrix, "projmatrix"),
+                                                 (rs.campos, "campos"))]
+    if t[0].numel() != 3 or t[1].numel() != 16 or t[2].numel() != 16 or t[3].numel() != 3:
+        raise ValueError("bg/campos must have 3 and viewmatrix/projmatrix 16 elements")
+    params = (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)
+    cfg = dict(W=int(rs.image_width), H=int(rs.image_height), tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, bg=t[0],
+               scale_modifier=rs.scale_modifier, viewmatrix=t[1], projmatrix=t[2], campos=t[3], sh_degree=rs.sh_degree,
+               debug=rs.debug,
+               differentiated=torch.is_grad_enabled() and any(p.requires_grad for p in params + (means2D,)))
+    del dev
+    return _RasterizeRaw.apply(*params, means2D, cfg)
 
 
 class GaussianRasterizer(nn.Module):

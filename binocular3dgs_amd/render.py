@@ -6,10 +6,14 @@ Same signature, same flag routing (`pipe.convert_SHs_python`, `pipe.compute_cov3
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_raw, raw_model_ok
+
+_HipRasterizer = GaussianRasterizer                            # (tests swap `GaussianRasterizer` for recording stubs)
+_FUSED_NODE = os.environ.get("B3GS_DROPIN_FUSED", "1") != "0"  # render() of a raw-parameter model as ONE autograd node
 
 _C0 = 0.28209479177387814
 _C1 = 0.4886025119029199
@@ -50,15 +54,57 @@ class PipelineParams:
         self.debug = debug
 
 
+class _LazyVisibility(dict):
+    """render()'s dict whose `visibility_filter` (= radii > 0, gaussian_renderer/__init__.py:99) is computed on first
+    access (one elementwise kernel per render that the training loop reads for the input view only).  The key is present
+    from the start (iteration, `in`, len() see the reference's six keys); every way of reading it materialises it."""
+
+    def __init__(self, d):
+        super().__init__(d)
+        super().__setitem__("visibility_filter", None)
+
+    def _fill(self):
+        if super().__getitem__("visibility_filter") is None:
+            super().__setitem__("visibility_filter", super().__getitem__("radii") > 0)
+
+    def __getitem__(self, key):
+        if key == "visibility_filter":
+            self._fill()
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        if key == "visibility_filter":
+            self._fill()
+        return super().get(key, default)
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene; `bg_color` must live on the GPU (as in the reference)."""
     xyz = pc.get_xyz
-    # zero tensor whose .grad receives the screen-space mean gradients (densification statistic)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # A model that keeps the reference's raw parameters and activations, default pipeline flags: one autograd node on the
+    # raw tensors (activations in-kernel, rasterizer.rasterize_raw) instead of ~30 PyTorch kernels around the rasterizer
+    # call.  B3GS_DROPIN_FUSED=0 keeps the statement-by-statement path below.
+    fused_node = (_FUSED_NODE and override_color is None and not pipe.compute_cov3D_python and not pipe.convert_SHs_python
+                  and GaussianRasterizer is _HipRasterizer and xyz.shape[0] > 0 and raw_model_ok(pc))
+    if fused_node:
+        # (a leaf instead of the reference's `zeros + 0`: its .grad then IS the node's screen-space gradient tensor,
+        # where retain_grad() on a non-leaf clones it -- 12 B per Gaussian per render)
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+    else:
+        # zero tensor whose .grad receives the screen-space mean gradients (densification statistic)
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height),
@@ -75,6 +121,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         debug=pipe.debug,
     )
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    if fused_node:
+        rendered_image, radii, depth, alpha = rasterize_raw(pc, screenspace_points, raster_settings)
+        # (`visibility_filter` = radii > 0 is materialised when somebody reads it)
+        return _LazyVisibility({"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii,
+                                "rendered_depth": depth, "rendered_alpha": alpha})
 
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:

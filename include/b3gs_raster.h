@@ -191,6 +191,11 @@ typedef struct B3gsForwardView {
    * permutation).  The library CHECKS it: a key outside the span raises bit 1 of *overflow_flag (required non-NULL for
    * this mode), which drops the step like a capacity overflow; the caller then falls back to 0.  0 (or 32): full sort. */
   int32_t depth_key_bits;
+  /* != 0: `image` is a fresh allocation with undefined content (not the buffer of an earlier forward): nothing is read
+   * from it -- neither the tile order the previous backward of a persistent buffer leaves for the next forward nor the
+   * open-tile prediction (two-round binning is then off).  A caller that re-uses image buffers across forwards zeroes a
+   * new one ONCE and passes 0.  All views of a batch use views[0]'s value. */
+  int32_t fresh_image;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);

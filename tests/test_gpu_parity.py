@@ -348,7 +348,7 @@ def test_forward_capacity_entry_point_and_overflow():
             assert int(n.item()) > cap and torch.isfinite(color).all()   # truncated lists: caller must grow and repeat
 
 
-def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
+def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape(monkeypatch):
     """GaussianRasterizer (the surface render() uses) pays the blocking read-back of num_rendered only for the first
     render of a (P, W, H) shape; afterwards a DIFFERENTIATED render runs b3gs_forward_capacity with twice the largest N
     seen and its N is checked at the entry of its backward (rasterizer._LazyN).  Same images and gradients bit for bit / to
@@ -365,7 +365,9 @@ def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
     assert lz.enabled
     key = (torch.cuda.current_device(), P, W, H)
     lz.capacity.pop(key, None)
-    lz.poll(force=True)
+    lz.pending.clear()
+    import binocular3dgs_amd.render as R
+    monkeypatch.setattr(R, "_FUSED_NODE", False)     # this test is about the reference-shaped GaussianRasterizer surface
 
     def run(backward=True):
         for p in model.parameters():
@@ -412,7 +414,7 @@ def test_autograd_surface_runs_sync_free_after_the_first_render_of_a_shape():
     assert lz.pending == [] and torch.equal(ev["render"], first[0][0]) and lz.capacity[key] > 256
 
 
-def test_lazy_num_rendered_survives_more_renders_than_pinned_slots():
+def test_lazy_num_rendered_survives_more_renders_than_pinned_slots(monkeypatch):
     """More sync-free renders in a row than the ring of pinned read-back slots (64), none of them differentiated in the
     end: the oldest are drained before a slot is reused, every N is still checked."""
     from binocular3dgs_amd import rasterizer, synth
@@ -423,6 +425,8 @@ def test_lazy_num_rendered_survives_more_renders_than_pinned_slots():
     bg = torch.zeros(3, device="cuda")
     lz = rasterizer._lazy
     lz.pending.clear()
+    import binocular3dgs_amd.render as R
+    monkeypatch.setattr(R, "_FUSED_NODE", False)
     with torch.no_grad():
         ref = render(cam, model, PipelineParams(), bg)["render"].clone()
     for _ in range(lz.RING + 10):
@@ -431,3 +435,109 @@ def test_lazy_num_rendered_survives_more_renders_than_pinned_slots():
     assert torch.equal(out, ref)
     lz.poll(force=True)
     assert lz.pending == []
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_render_of_a_raw_parameter_model_is_one_fused_node(K):
+    """render() handed a model with the reference's raw parameters and activations (scene/gaussian_model.py:33-43) goes
+    through ONE autograd node on the raw tensors (rasterizer.rasterize_raw: activations and their backward in-kernel,
+    three-pass depth sort, tight binning) instead of the accessor kernels + GaussianRasterizer.  Same dict, images to the
+    stated band (activation rounding may flip a 1/255 decision on a handful of pixels), gradients of the six parameters
+    and of `viewspace_points` to 2e-4, accumulation over two renders through autograd, exact renders under no_grad."""
+    import binocular3dgs_amd.render as R
+    from binocular3dgs_amd import rasterizer, synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H, P = 200, 144, 6000
+    model = synth.synth_model(P, seed=7, device="cuda", width=W, height=H, K=K)
+    pairs = synth.synth_view_set(W, H, device="cuda")
+    cam, scam = pairs[0][0], pairs[0][1]
+    bg = torch.tensor([0.1, 0.0, 0.2], device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=2, device="cuda")
+    assert rasterizer.raw_model_ok(model) and R._FUSED_NODE
+
+    def run(fused):
+        R._FUSED_NODE = fused
+        try:
+            for p in model.parameters():
+                p.grad = None
+            a = render(cam, model, PipelineParams(), bg)
+            b = render(scam, model, PipelineParams(), bg)
+            torch.autograd.backward([a["render"], a["rendered_depth"], a["rendered_alpha"], b["render"]], [gc, gd, ga, gc])
+            torch.cuda.synchronize()
+            return a, b, [p.grad.clone() for p in model.parameters()]
+        finally:
+            R._FUSED_NODE = True
+
+    ra, rb, rg = run(False)
+    fa, fb, fg = run(True)
+    assert set(fa.keys()) == set(ra.keys())
+    # parameters that already hold a dense .grad (a second backward into them, a gradient slab): the node adds into it
+    # in place instead of handing autograd a tensor to add -- same sums
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    a = render(cam, model, PipelineParams(), bg)
+    keep = [p.grad for p in model.parameters()]
+    torch.autograd.backward([a["render"], a["rendered_depth"], a["rendered_alpha"]], [gc, gd, ga])
+    b = render(scam, model, PipelineParams(), bg)
+    torch.autograd.backward([b["render"]], [gc])
+    torch.cuda.synchronize()
+    for n, p, k, r in zip(["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"], model.parameters(), keep, rg):
+        assert p.grad is k                                # still the caller's tensor
+        if r.numel():
+            assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 2e-4, n
+    for got, ref in ((fa, ra), (fb, rb)):
+        assert float((got["radii"] != ref["radii"]).float().mean()) < 1e-3
+        assert got["visibility_filter"].dtype == torch.bool and got["radii"].dtype == torch.int32
+        for (k, scale) in (("render", 1.0), ("rendered_depth", 10.0), ("rendered_alpha", 1.0)):
+            err = ((got[k] - ref[k]).abs() / (1 + ref[k].abs())).detach()
+            assert got[k].shape == ref[k].shape
+            assert int((err > 2e-5).sum()) <= 3 and float(err.max()) <= scale / 255, (k, float(err.max()))
+    for n, g, r in zip(["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"], fg, rg):
+        if r.numel():
+            assert g.shape == r.shape and rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 2e-4, n
+    assert rel_l2(fa["viewspace_points"].grad.cpu().numpy(), ra["viewspace_points"].grad.cpu().numpy()) < 2e-4
+    assert fb["viewspace_points"].grad is not None
+    # evaluation renders: exact (synchronous) forward, nothing pending, same image as the differentiated render
+    lz = rasterizer._lazy
+    lz.pending.clear()
+    with torch.no_grad():
+        ev = render(cam, model, PipelineParams(), bg)
+    assert lz.pending == [] and torch.equal(ev["render"], fa["render"])
+    # a pipeline flag the node does not cover falls back to the statement-by-statement path
+    with torch.no_grad():
+        py = render(cam, model, PipelineParams(compute_cov3D_python=True), bg)
+    assert float(((py["render"] - ev["render"]).abs() / (1 + ev["render"].abs())).max()) <= 1.0 / 255
+
+
+def test_fused_render_node_refuses_truncated_lists_in_backward():
+    """The node's sync-free forward follows the same protocol as the reference-shaped surface: N is checked at the entry
+    of backward(); a buffer that was too small raises there, before any gradient exists."""
+    from binocular3dgs_amd import _lib, rasterizer, synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H, P = 160, 112, 4000
+    model = synth.synth_model(P, seed=5, device="cuda", width=W, height=H)
+    cam = synth.synth_view_set(W, H, device="cuda")[0][0]
+    bg = torch.zeros(3, device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=2, device="cuda")
+    lz = rasterizer._lazy
+    lz.pending.clear()
+    key = ("raw", torch.cuda.current_device(), P, W, H)
+    lz.capacity.pop(key, None)
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        pkg = render(cam, model, PipelineParams(), bg)
+        torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+        torch.cuda.synchronize()
+        return pkg["render"].detach().clone()
+
+    first = run()                                   # exact render: learns N
+    assert key in lz.capacity
+    second = run()                                  # sync-free
+    assert torch.equal(first, second) and lz.pending == []
+    lz.capacity[key] = 256
+    with pytest.raises(_lib.B3gsError, match="B3GS_ERR_CAPACITY"):
+        run()
+    assert all(p.grad is None for p in model.parameters()) and lz.capacity[key] > 256
+    assert torch.equal(run(), first)
