@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--dp-path", action="store_true",
                     help="single-GPU check of the N>1 code path: 1-rank RCCL group, graph + eager collectives")
     ap.add_argument("--graph", type=int, default=1, help="capture one whole iteration in a HIP graph (fused path only)")
+    ap.add_argument("--dp-graph", type=int, default=0,
+                    help="N > 1: capture the RCCL reduce-scatter / all-gather and the Adam launch in the iteration's HIP graph "
+                         "too (default: graph for the rendering part, eager exchange)")
     return ap.parse_args()
 
 
@@ -203,6 +206,7 @@ class Job:
                 self.step_kw = dict(loss_fn=loss_fn)
         self.loss = loss
         self.use_graph = bool(graph) and fused is not None
+        self.dp_graph = False
         self.run = self.eager_step
         self._snap = None
 
@@ -257,16 +261,36 @@ class Job:
                 for st_ in opt.state.values():
                     if "step" in st_ and not st_["step"].is_cuda:
                         st_["step"] = st_["step"].to(self.dev)
-            body = (lambda: st.compute_grads(**self.step_kw)) if self.dp else self.eager_step
+            # data parallel: by default the rendering part of the iteration is one hipGraph and the RCCL collectives of
+            # the gradient slab + the (single-kernel) Adam are issued eagerly after each replay; --dp-graph captures the
+            # collectives as well (RCCL launches are capturable): one replay per iteration, no host gap before the exchange
+            whole = self.dp and bool(getattr(args, "dp_graph", 0))
+            body = (lambda: st.compute_grads(**self.step_kw)) if (self.dp and not whole) else self.eager_step
             sg = torch.cuda.Stream()
             sg.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(sg):
                 body()
             torch.cuda.current_stream().wait_stream(sg)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                body()
-            if self.dp:
+            try:
+                with torch.cuda.graph(graph):
+                    body()
+            except Exception as exc:
+                if not whole:
+                    raise
+                # the collectives would not capture in this environment: fall back to graph + eager exchange
+                if self.rank == 0:
+                    print(f"[bench] capturing the RCCL collectives failed ({exc!r}); eager exchange", file=sys.stderr)
+                whole = False
+                torch.cuda.synchronize(self.dev)
+                body = lambda: st.compute_grads(**self.step_kw)   # noqa: E731
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+            self.dp_graph = whole
+            if self.dp and whole:
+                self.run = graph.replay
+            elif self.dp:
                 # data parallel: the rendering part of the iteration is one hipGraph; the RCCL collectives of the
                 # gradient slab and the (single-kernel) Adam are issued eagerly after each replay
                 def run():
@@ -371,6 +395,9 @@ def main():
     ms, inst_per_launch = ({k: 0.0 for k in ("preprocess", "sort", "render_fwd", "render_bwd", "preprocess_bwd")}, None)
     if job.local_views:
         ms, inst_per_launch = job.kernel_times(min(args.steps, 20))
+    exchange = None
+    if dp:
+        exchange = measure_exchange(job, min(args.steps, 10))
 
     # workload statistics of this rank's primary view 0 through the reference-shaped C ABI surface (V, the reference-rule N)
     from binocular3dgs_amd import _C
@@ -442,6 +469,7 @@ def main():
                        "parallelism": f"dp{world} (views sharded, params replicated"
                                       + (", Adam state sharded: reduce-scatter + all-gather)" if args.optimizer == "sharded" else ")")},
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
+            **({"exchange": exchange} if exchange is not None else {}),
             "roofline": roof,
             "reference_algorithm_equivalent": {
                 "what": "SURVEY 8(d) byte model of the REFERENCE algorithm (64-bit keys, 6 radix passes, reference binning "
@@ -547,6 +575,35 @@ def main():
         except Exception:
             pass
         print(result_line, flush=True)
+
+
+def measure_exchange(job, steps):
+    """N > 1 (or --dp-path): the data-parallel exchange of the step, as the SCALE record needs it to be checkable -- the
+    RCCL group, every rank's view count, and the time of the two collectives (HIP events around reduce-scatter and
+    all-gather on the compute stream, eager steps, mean over `steps`, max over ranks)."""
+    from binocular3dgs_amd.step import ShardedAdam
+    opt = job.opt
+    out = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "dp_graph": bool(job.dp_graph),
+           "slab_bytes": int(job.stepper.slab.nbytes()), "optimizer": type(opt).__name__}
+    per_rank = [None] * dist.get_world_size()
+    dist.all_gather_object(per_rank, int(job.local_views))
+    out["views_per_rank"] = per_rank
+    if isinstance(opt, ShardedAdam) and opt.collective():
+        opt.record_events, opt.events = True, []
+        for _ in range(steps):
+            job.eager_step()
+        torch.cuda.synchronize(job.dev)
+        opt.record_events = False
+        rs = sum(e[0].elapsed_time(e[1]) for e in opt.events) / max(len(opt.events), 1)
+        ag = sum(e[2].elapsed_time(e[3]) for e in opt.events) / max(len(opt.events), 1)
+        t = torch.tensor([rs, ag], dtype=torch.float64, device=job.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out.update(reduce_scatter_ms=round(float(t[0]), 4), all_gather_ms=round(float(t[1]), 4),
+                   exchange_bytes_per_rank=int(2 * (opt.world - 1) * opt.chunk * 4),
+                   what="ShardedAdam: reduce_scatter(gradient slab) -> Adam on 1/N -> all_gather(parameters); link bytes per "
+                        "rank = 2 (N-1)/N of the padded slab")
+        opt.events = []
+    return out
 
 
 # ---- rocprofv3 counter passes over a short copy of the same workload (MI355X_MICROARCH.md, HBM / PMC sections) ------

@@ -176,6 +176,8 @@ class ShardedAdam:
         self.force_collective = False   # issue the collectives even in a 1-rank group (path check on one GPU)
         self.step_count = None
         self.skip_flag = None           # device int32: != 0 drops the update on the device (ViewShardedStep sets it)
+        self.record_events = False      # bench: keep HIP events around the reduce-scatter and the all-gather
+        self.events = []
         self._flatten(list(params), None, None)
 
     # ---- layout ---------------------------------------------------------------------------------
@@ -233,10 +235,16 @@ class ShardedAdam:
         lo = self.rank * self.chunk
         collective = self.collective()
         assert row_mask is None or (not collective and self.adam_impl is None and self.world == 1)
+        ev = None
+        if collective and self.record_events:      # bench: events around the two collectives on the compute stream
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         if collective:
             if self.gshard is None:
                 self.gshard = torch.zeros(self.chunk, dtype=torch.float32, device=self.pflat.device)
             dist.reduce_scatter_tensor(self.gshard, slab.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if ev:
+                ev[1].record()
             g = self.gshard
             if average:
                 g.div_(self.world)
@@ -258,7 +266,12 @@ class ShardedAdam:
                           for (p, gg, m, v, lr), w in zip(segs, widths)], self.step_count, self.betas, self.eps, decay,
                          opacity_seg, self.decay_first, True, self.pflat.device, row_mask, self.skip_flag)
         if collective:
+            if ev:
+                ev[2].record()
             dist.all_gather_into_tensor(self.pflat, self.pflat[lo:lo + self.chunk], group=self.group)
+            if ev:
+                ev[3].record()
+                self.events.append(ev)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:

@@ -76,3 +76,23 @@ def test_ranks_sharing_the_gpu_run_the_multi_gpu_control_flow(world):
     assert ex["strong_scaling_6_views"]["views_per_rank"] == ([3, 3] if world == 2 else [1, 1, 1, 1, 1, 1, 0, 0])
     assert ex["strong_scaling_6_views"]["iters_per_s"] > 0
     assert ex["config5_2M_1600x1600_8_views"]["views_per_rank"] == ([4, 4] if world == 2 else [1] * 8)
+    x = d["exchange"]          # what the SCALE record is checked against: the group, every rank's views, the collectives' time
+    assert x["backend"] == "gloo" and x["rccl_ranks"] == world and x["views_per_rank"] == [6] * world
+    assert x["reduce_scatter_ms"] > 0 and x["all_gather_ms"] > 0 and x["exchange_bytes_per_rank"] > 0
+
+
+@pytest.mark.parametrize("extra", [pytest.param(("--scaling", "strong", "--views", "8"), id="strong_8_views"),
+                                   pytest.param(("--dp-graph", "1"), id="weak_collectives_in_graph")])
+def test_rccl_call_signatures_on_a_one_rank_nccl_group(extra):
+    """`bench.py --dp-path`: the N > 1 code path on ONE MI355X with the REAL backend -- a 1-rank "nccl" (= RCCL) process
+    group, so that reduce_scatter_tensor / all_gather_into_tensor / all_reduce / barrier are issued with exactly the
+    arguments an 8-GPU run issues them with (every other N > 1 test uses gloo).  strong_8_views: configs[4]'s view-granular
+    sharding; weak_collectives_in_graph: the collectives and the Adam launch captured in the iteration's HIP graph."""
+    d = _run("--dp-path", "--no-extras", "--no-pmc", "--no-cpu-baseline", *extra)
+    assert d["value"] > 0 and d["n_gpus"] == 1
+    x = d["exchange"]
+    assert x["backend"] == "nccl" and x["rccl_ranks"] == 1 and x["optimizer"] == "ShardedAdam"
+    assert x["reduce_scatter_ms"] > 0 and x["all_gather_ms"] > 0
+    assert x["views_per_rank"] == [8 if "--views" in extra else 6]
+    if "--dp-graph" in extra:
+        assert x["dp_graph"] is True, "the RCCL collectives must be capturable in the HIP graph"
