@@ -415,12 +415,21 @@ def main():
             del o
     # (pixel, Gaussian) pairs the sequential algorithm visits: sum over pixels of the position of their last
     # contributor (n_contrib) -- the work unit of the blend kernels (they are not HBM bound)
-    pairs_per_view, n_binned = None, N_ref
+    pairs_per_view, n_binned, staged_per_launch = None, N_ref, None
     if fused is not None and job.local_views:
         from binocular3dgs_amd.debug import state_views
         s0 = fused.slots[0]
         n_binned = fused.num_rendered()[0]
         pairs_per_view = int(state_views(P, W, H, s0.capacity, s0.geom, s0.binning, s0.img)["n_contrib"].to(torch.int64).sum().item())
+        # list entries the blend backward actually STAGES: per tile the deepest position any of its pixels used,
+        # rounded up to the kernel's 64-entry chunks, summed over the tiles of all local views (state of the last step)
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        staged_per_launch = 0
+        for sl in fused.slots[:job.local_views]:
+            nc = torch.zeros((gy * 16, gx * 16), dtype=torch.int64, device=dev)
+            nc[:H, :W] = state_views(P, W, H, sl.capacity, sl.geom, sl.binning, sl.img)["n_contrib"].to(torch.int64)
+            deepest = nc.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(1).values
+            staged_per_launch += int((((deepest + 63) // 64) * 64).sum().item())
 
     result_line = None
     if rank == 0:
@@ -444,7 +453,18 @@ def main():
                               "per view (SURVEY 8d, render bwd); duration = HIP events on the launch stream, mean over "
                               "the K optimiser states of the timed region",
                 "note": "the blend kernels are VALU-bound (SURVEY 8d caveat): `valu` is their real roofline; the 64-byte "
-                        "records are served from L2 / Infinity Cache, so `traffic` sits below the algorithmic bytes",
+                        "records are served from L2 / Infinity Cache, so `traffic` sits below the algorithmic bytes.  "
+                        "With two binning rounds (the rule's choice at this workload) the launch is HANDED ~30 % of the "
+                        "instances one-round binning would hand it and walks the same list prefixes in the same time: "
+                        "SURVEY 8d's unit (bytes per instance handed to the kernel) drops with it -- `one_round_binning` "
+                        "below is the figure comparable with earlier rounds",
+                "staged": (None if not staged_per_launch or dur_ms <= 0 else {
+                    "instances_per_launch": staged_per_launch,
+                    "achieved": round((44.0 * staged_per_launch + 28.0 * HW * lv) / (dur_ms / 1e3) / 1e9, 1),
+                    "frac": round((44.0 * staged_per_launch + 28.0 * HW * lv) / (dur_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "what": "the same byte model on the list entries the kernel actually reads (every tile's list up to its "
+                            "deepest used position, in 64-entry chunks): the kernel's true algorithmic bytes, independent of "
+                            "how many instances the binning handed it"}),
                 "pixgauss_pairs_per_view": pairs_per_view,
                 "pixgauss_pairs_per_s": (None if not pairs_per_view or ms["render_bwd"] <= 0
                                          else round(pairs_per_view / (ms["render_bwd"] / 1e3), 1))}
@@ -558,6 +578,14 @@ def main():
     if rank == 0:
         if extras:
             result["extras"] = extras
+            o1 = extras.get("headline_one_round_binning")
+            if o1 and o1.get("render_bwd_algorithmic_GBps"):
+                result["roofline"]["one_round_binning"] = {
+                    "achieved": o1["render_bwd_algorithmic_GBps"], "frac": round(o1["render_bwd_algorithmic_GBps"] / HBM_PEAK_GBS, 4),
+                    "instances_per_launch": o1["instances_emitted_per_view"] * 6,
+                    "avg_launch_ms": round(o1["stage_ms_per_view"]["render_bwd"] * 6, 4), "iters_per_s": o1["iters_per_s"],
+                    "what": "the same workload with FusedRasterizer(seg1_fraction=0): every tile instance emitted, sorted and "
+                            "handed to the blend backward (SURVEY 8d's byte model applied to THAT count)"}
         if world == 1 and not args.inner:
             result["roofline"]["measured_copy_GBps"] = measured_copy_bandwidth(dev)
             if not args.no_pmc:
@@ -607,7 +635,7 @@ def measure_exchange(job, steps):
 
 
 # ---- rocprofv3 counter passes over a short copy of the same workload (MI355X_MICROARCH.md, HBM / PMC sections) ------
-FWD_KERNELS = re.compile(r"preprocess_fwd|radix|scan_chunk|emit_instances|tile_ranges|render_fwd")
+FWD_KERNELS = re.compile(r"preprocess_fwd|radix|scan_chunk|emit_instances|tile_ranges|render_fwd|repair_kernel")
 
 
 def _pmc_pass(args, counters, tag):
@@ -673,7 +701,7 @@ def pmc_passes(args, result):
         # of an untouched Gaussian is not read: between 24 and 28 B
         "calibration_adam_bytes": per_launch.get("adam_kernel"), "calibration_adam_expected": [24 * n_par, 28 * n_par],
         "per_launch_bytes": {k.replace("_kernel", ""): v for k, v in sorted(per_launch.items())
-                             if re.search(r"render|preprocess|radix|emit|scan|accumulate|adam", k)}}
+                             if re.search(r"render|preprocess|radix|emit|scan|accumulate|adam|repair", k)}}
     vd = {}
     for k in ("render_bwd_kernel", "render_fwd_kernel", "accumulate_views_kernel"):
         c = valu.get(k)
@@ -682,10 +710,18 @@ def pmc_passes(args, result):
         cyc = mean(c["GRBM_GUI_ACTIVE"]) / 8.0                 # the counter is summed over the 8 XCDs
         iv, tc = mean(c["SQ_INSTS_VALU"]), mean(c["SQ_THREAD_CYCLES_VALU"])
         vd[k] = {"valu_insts_per_launch": int(iv), "cycles_per_launch": int(cyc),
-                 "issue_frac": round(iv * 2.0 / (cyc * CUS * SIMDS_PER_CU), 4), "active_lanes_per_inst": round(tc / iv, 2)}
+                 "issue_frac": round(iv * 2.0 / (cyc * CUS * SIMDS_PER_CU), 4),
+                 # SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU: thread-cycles per instruction -- NOT a lane count (instructions
+                 # that occupy the pipe longer than one pass count more than 64 for a full wave); kept as a raw ratio.
+                 # SQ_INSTS_VALU itself is cross-checked statically: profiles/*_isa_counts.txt (tools/isa_count.py)
+                 "thread_cycles_per_inst": round(tc / iv, 2)}
     if vd:
         roof["valu"] = {"bound": "valu issue slots: 256 CUs x 4 SIMDs, one plain fp32 wave64 instruction per 2 cycles "
                                  "(tools/ubench/valu_rate.hip); transcendental / DPP / LDS-path instructions occupy 8",
+                        "isa_cross_check": "static count of the hot loops (tools/isa_count.py -> profiles/r03_isa_counts.txt): "
+                                           "backward 75 VALU + 17 LDS + 22 SALU per candidate, forward 30 VALU + 3 LDS + 15 "
+                                           "SALU; x the candidates per launch of tools/bwd_trace_batched.py (4.98M) = 374M of "
+                                           "the ~386M SQ_INSTS_VALU measured for the backward (the rest is staging)",
                         "frac": vd.get(roof["kernel"], {}).get("issue_frac"), "kernels": vd}
 
 
@@ -745,9 +781,10 @@ def cpu_baseline(P, W, H, seed):
     it_s = fwd_s + bwd_s
     return {"value": round(1.0 / it_s, 5), "unit": "iters/s", "cores": threads, "physical_cores": physical,
             "cpu_model": cpu_model, "kind": "port",
-            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H} (no gradient sum, no Adam): "
-                      f"fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; oracle/tile_ref.c, OpenMP {threads} threads "
-                      f"({physical} physical cores, {cpu_model})",
+            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H}: fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; "
+                      f"oracle/tile_ref.c called directly on torch-activated inputs (not through render() with the "
+                      f"*_python sub-steps of SURVEY 8d), per-view gradients NOT summed, NO Adam step: it flatters the CPU; "
+                      f"OpenMP {threads} threads ({physical} physical cores, {cpu_model})",
             "ms_per_view": round(it_s / nviews * 1e3, 1)}
 
 

@@ -189,7 +189,10 @@ __device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, floa
 
 constexpr int PRE_PRED_WORDS = 128;   // LDS copy of one view's predicted-open bitmap (8 KB for 8 views)
 template <bool RAW>
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreBatch pb) {
+#ifndef B3GS_PRE_WAVES
+#define B3GS_PRE_WAVES 5   /* waves per SIMD the projection must leave room for (<= 96 VGPRs) */
+#endif
+__global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   for (int v = 0; v < pb.n; v++)
     if (i < pb.out[v].ntiles) {   // empty = (max, 0): the tile sort's last pass min/maxes into it

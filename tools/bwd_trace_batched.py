@@ -54,6 +54,17 @@ print("mean resident waves %.0f (slots: 1024 SIMDs x occupancy)" % ((e_us - s_us
 print("wave duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % ((e_us - s_us).mean(), *np.percentile(e_us - s_us, [50, 90, 99]), (e_us - s_us).max()))
 print("iterations per wave: mean %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (it.mean(), *np.percentile(it, [50, 90, 99]), it.max()))
 print("corr(iters, duration) %.3f" % np.corrcoef(it, e_us - s_us)[0, 1])
+if WHICH == "bwd":
+    # candidates that reached the reduction (any pixel of the quadrant live) and how full their lanes were
+    nlive = (t[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+    nlanes = (t[:, 3] >> np.uint64(32)).astype(np.float64)
+    print("candidates evaluated %.3e, with a live lane %.3e (%.1f %%); live lanes per live candidate %.1f of 64 (%.1f %%)"
+          % (it.sum(), nlive.sum(), 100.0 * nlive.sum() / max(it.sum(), 1), nlanes.sum() / max(nlive.sum(), 1),
+             100.0 * nlanes.sum() / max(64.0 * nlive.sum(), 1)))
+    frac = nlanes / np.maximum(64.0 * nlive, 1)
+    w = nlive > 0
+    print("per-wave live-lane fraction: p10 %.2f p50 %.2f p90 %.2f; waves below 1/2: %.1f %% holding %.1f %% of the live candidates"
+          % (*np.percentile(frac[w], [10, 50, 90]), 100.0 * (frac[w] < 0.5).mean(), 100.0 * nlive[w][frac[w] < 0.5].sum() / nlive.sum()))
 late = s_us > 0.5 * span
 print("waves started in the second half: %d, their mean duration %.1f us" % (late.sum(), (e_us - s_us)[late].mean() if late.any() else 0))
 # imbalance between the four quadrant waves of a workgroup (they live until the tile is done): the share of wave-slot time
