@@ -6,9 +6,15 @@ tools/prof.sh ${tag}_default --no-extras --no-pmc > gpurun_out/${tag}_prof_stdou
 grep '^{"metric"' gpurun_out/${tag}_default_bench.log | tail -1 > gpurun_out/${tag}_profiled_run_bench_line.json
 python bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/${tag}_default_bench_line.json
 export PMC_TARGET="bench.py --inner --no-extras --no-pmc --no-cpu-baseline --steps 3 --warmup 1"
-tools/pmc.sh ${tag}_pmc_fetch_size "FETCH_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_f.txt 2>&1
-tools/pmc.sh ${tag}_pmc_write_size "WRITE_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_w.txt 2>&1
-tools/pmc.sh ${tag}_pmc_valu "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS" "render|preprocess|radix|emit|scan|accumulate|adam" > gpurun_out/${tag}_pmc_v.txt 2>&1
+tools/pmc.sh ${tag}_pmc_fetch_size "FETCH_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_f.txt 2>&1
+tools/pmc.sh ${tag}_pmc_write_size "WRITE_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_w.txt 2>&1
+tools/pmc.sh ${tag}_pmc_valu "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_v.txt 2>&1
+# round 3: static instruction mix of the blend loops, per-wave trace of the batched backward (candidates, live lanes,
+# residency), kernel stats of the reference-shaped surface (render() per view)
+python tools/isa_count.py > gpurun_out/${tag}_isa_counts.txt 2>&1
+python tools/bwd_trace_batched.py bwd 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_bwd_trace.txt
+python tools/bwd_trace_batched.py fwd 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_fwd_trace.txt
+PROF_STEPS=10 PROF_WARMUP=3 tools/prof.sh ${tag}_dropin --path dropin --optimizer b3gs --graph 0 --no-extras --no-pmc > gpurun_out/${tag}_dropin_stdout.txt 2>&1
 head -16 gpurun_out/${tag}_default_kernel_stats.csv
 python -c "
 import json
