@@ -598,21 +598,27 @@ __device__ __forceinline__ uint32_t key27(uint32_t k) {
   return d < KEY27_SPAN - 2u ? d : KEY27_SPAN - 2u;   // (out-of-span keys are flagged by the projection)
 }
 
+// ITEMS = keys per thread of a radix tile: 16 (4096-key tiles) for batches of views; 8 (2048-key tiles: twice the workgroups,
+// half the serial ranking rounds each) when ONE view is sorted alone and 245 tiles of 4096 would leave the CUs one
+// workgroup each (the reference-shaped surface renders view by view)
+template <int ITEMS>
 __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix9_hist(SortBatch sb, int shift, int xform) {
+  constexpr uint32_t TILE = ITEMS * B3GS_SORT_THREADS;
   __shared__ uint32_t h[HIST_TILES][512];
   const SortJob& job = sb.j[blockIdx.y];
   const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
   const uint32_t blk0 = blockIdx.x * HIST_TILES;
-  if (blk0 >= job.nblk) return;
+  const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
+  if (blk0 >= nblk) return;
   const uint32_t* __restrict__ keys = job.kin;
   const uint32_t n = job.n_cap;
-  if ((uint64_t)blk0 * B3GS_SORT_TILE >= n) return;
+  if ((uint64_t)blk0 * TILE >= n) return;
   h[sub][t] = 0;
   h[sub][t + 256] = 0;
   __syncthreads();
-  const uint64_t base = (uint64_t)(blk0 + sub) * B3GS_SORT_TILE;
+  const uint64_t base = (uint64_t)(blk0 + sub) * TILE;
 #pragma unroll
-  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+  for (int k = 0; k < ITEMS; k++) {
     const uint64_t i = base + k * B3GS_SORT_THREADS + t;
     if (i < n) {
       uint32_t kk = keys[i];
@@ -622,18 +628,20 @@ __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix9_hist(So
   }
   __syncthreads();
   if (sub == 0) {
-    const uint32_t hs = hist_stride(job.nblk);
+    const uint32_t hs = hist_stride(nblk);
     *reinterpret_cast<uint4*>(job.hist + (size_t)t * hs + blk0) = make_uint4(h[0][t], h[1][t], h[2][t], h[3][t]);
     *reinterpret_cast<uint4*>(job.hist + (size_t)(t + 256) * hs + blk0) =
         make_uint4(h[0][t + 256], h[1][t + 256], h[2][t + 256], h[3][t + 256]);
   }
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(256) radix9_rowscan(SortBatch sb) {
   __shared__ uint32_t tmp[8];
+  constexpr uint32_t TILE = ITEMS * B3GS_SORT_THREADS;
   const SortJob& job = sb.j[blockIdx.y];
-  const uint32_t nblk = job.nblk;
-  const uint32_t used = min(nblk, (job.n_cap + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);
+  const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
+  const uint32_t used = nblk;
   uint32_t* row = job.hist + (size_t)blockIdx.x * hist_stride(nblk);
   uint32_t carry = 0;
   for (uint32_t b0 = 0; b0 < used; b0 += 256) {
@@ -647,36 +655,38 @@ __global__ void __launch_bounds__(256) radix9_rowscan(SortBatch sb) {
   if (threadIdx.x == 0) job.hist[(size_t)512 * hist_stride(nblk) + blockIdx.x] = carry;  // totals
 }
 
+template <int ITEMS>
 __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb, int shift, int xform) {
+  constexpr uint32_t TILE = ITEMS * B3GS_SORT_THREADS;
   __shared__ uint32_t wave_cnt[4][512];
   __shared__ uint32_t blk_start[512];
   __shared__ uint32_t gbase[512];
   __shared__ uint32_t tmp[8];
-  __shared__ uint32_t s_key[B3GS_SORT_TILE];
-  __shared__ uint32_t s_val[B3GS_SORT_TILE];
+  __shared__ uint32_t s_key[TILE];
+  __shared__ uint32_t s_val[TILE];
   const SortJob& job = sb.j[blockIdx.y];
-  if (blockIdx.x >= job.nblk) return;
+  const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
+  if (blockIdx.x >= nblk) return;
   const uint32_t* __restrict__ keys_in = job.kin;
   const uint32_t* __restrict__ vals_in = job.vin;
   uint32_t* __restrict__ keys_out = job.kout;
   uint32_t* __restrict__ vals_out = job.vout;
-  const uint32_t nblk = job.nblk;
   const uint32_t* __restrict__ hist = job.hist;
   const uint32_t hstride = hist_stride(nblk);
   const uint32_t* __restrict__ totals = job.hist + (size_t)512 * hstride;
   const uint32_t n = job.n_cap;
-  const uint32_t tile_base = blockIdx.x * B3GS_SORT_TILE;
+  const uint32_t tile_base = blockIdx.x * TILE;
   if (tile_base >= n) return;
-  const uint32_t tile_n = min((uint32_t)B3GS_SORT_TILE, n - tile_base);
+  const uint32_t tile_n = min(TILE, n - tile_base);
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   const u64 lt = lanemask_lt();
 #pragma unroll
   for (int k = 0; k < 4; k++) { wave_cnt[k][threadIdx.x] = 0; wave_cnt[k][threadIdx.x + 256] = 0; }
   __syncthreads();
-  uint32_t key[B3GS_SORT_ITEMS], val[B3GS_SORT_ITEMS], rank[B3GS_SORT_ITEMS];
+  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t li = w * (ITEMS * 64) + r * 64 + lane;
     const bool valid = li < tile_n;
     const uint32_t gi = tile_base + li;
     uint32_t kk = valid ? keys_in[gi] : 0xFFFFFFFFu;
@@ -685,8 +695,8 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
     val[r] = valid ? (vals_in ? vals_in[gi] : gi) : 0u;
   }
 #pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t li = w * (ITEMS * 64) + r * 64 + lane;
     const bool valid = li < tile_n;
     const uint32_t d = (key[r] >> shift) & 0x1FF;
     u64 m = __ballot(valid);
@@ -733,8 +743,8 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
+  for (int r = 0; r < ITEMS; r++) {
+    const uint32_t li = w * (ITEMS * 64) + r * 64 + lane;
     if (li < tile_n) {
       const uint32_t d = (key[r] >> shift) & 0x1FF;
       const uint32_t p = wave_cnt[w][d] + rank[r];
@@ -744,7 +754,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < B3GS_SORT_ITEMS; k++) {
+  for (int k = 0; k < ITEMS; k++) {
     const uint32_t p = k * B3GS_SORT_THREADS + threadIdx.x;
     if (p < tile_n) {
       const uint32_t kk = s_key[p];
@@ -757,14 +767,24 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
 }
 
 // one 9-bit pass over all jobs (depth keys only: every job has values, n = n_cap = P)
-void radix9_pass(SortBatch& sb, int shift, bool xform, hipStream_t s) {
+template <int ITEMS>
+void radix9_pass_t(SortBatch& sb, int shift, bool xform, hipStream_t s) {
   uint32_t max_blk = 0;
-  for (int k = 0; k < sb.n; k++) max_blk = sb.j[k].nblk > max_blk ? sb.j[k].nblk : max_blk;
+  for (int k = 0; k < sb.n; k++) {
+    const uint32_t nb = (sb.j[k].n_cap + ITEMS * B3GS_SORT_THREADS - 1) / (ITEMS * B3GS_SORT_THREADS);
+    max_blk = nb > max_blk ? nb : max_blk;
+  }
   if (sb.n <= 0 || max_blk == 0) return;
-  hipLaunchKernelGGL(radix9_hist, dim3((max_blk + HIST_TILES - 1) / HIST_TILES, sb.n), dim3(HIST_TILES * B3GS_SORT_THREADS), 0, s,
-                     sb, shift, xform ? 1 : 0);
-  hipLaunchKernelGGL(radix9_rowscan, dim3(512, sb.n), dim3(256), 0, s, sb);
-  hipLaunchKernelGGL(radix9_scatter, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift, xform ? 1 : 0);
+  hipLaunchKernelGGL(radix9_hist<ITEMS>, dim3((max_blk + HIST_TILES - 1) / HIST_TILES, sb.n), dim3(HIST_TILES * B3GS_SORT_THREADS),
+                     0, s, sb, shift, xform ? 1 : 0);
+  hipLaunchKernelGGL(radix9_rowscan<ITEMS>, dim3(512, sb.n), dim3(256), 0, s, sb);
+  hipLaunchKernelGGL(radix9_scatter<ITEMS>, dim3(max_blk, sb.n), dim3(B3GS_SORT_THREADS), 0, s, sb, shift, xform ? 1 : 0);
+}
+void radix9_pass(SortBatch& sb, int shift, bool xform, hipStream_t s) {
+  static const int force = getenv("B3GS_SORT9_ITEMS") ? atoi(getenv("B3GS_SORT9_ITEMS")) : 0;   // (A/B switch)
+  const int items = force ? force : (sb.n == 1 ? 8 : 16);
+  if (items == 8) radix9_pass_t<8>(sb, shift, xform, s);
+  else radix9_pass_t<16>(sb, shift, xform, s);
 }
 
 // one pass over all jobs; swaps every job's in/out buffers afterwards (vin becomes non-null)
