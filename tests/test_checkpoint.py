@@ -234,3 +234,84 @@ def test_resumed_step_matches_the_reference_gpu():
     opt2.step()
     for n, p in zip(MODEL_ORDER, m2.parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"after_{n}"], rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# sharded optimiser state over two ranks (gloo, CPU): the moments live 1/N per rank; capture() gathers them into the
+# reference's state_dict, restore() hands every rank its shard back
+def _ckpt_rank(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    from test_dp_views_gloo import torch_adam_impl
+    from binocular3dgs_amd.step import FlatGradSlab
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    z, st = gold()
+    lrs = lrs_model_order(st)
+
+    def steps(model, opt, n, seed0):
+        slab = FlatGradSlab(model.parameters(), opt.padded_numel)
+        for k in range(n):
+            g = torch.Generator().manual_seed(seed0 + k)
+            for p in model.parameters():
+                p.grad.copy_(1e-3 * torch.randn(p.shape, generator=g))     # the same (already summed) gradient on every rank
+            if world > 1:
+                slab.flat.div_(world)                                       # ... so that the reduce-scatter SUM gives it back
+            opt.step(slab)
+
+    a = model_from_gold(z)
+    oa = ShardedAdam(a.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True,
+                     adam_impl=torch_adam_impl)
+    steps(a, oa, 3, 100)
+    tup = a.capture(oa)                       # collective: all-gathers the moments
+    import io                                 # (capture() returns the LIVE tensors, like the reference's: train.py saves at once)
+    buf = io.BytesIO()
+    torch.save(tup, buf)
+    buf.seek(0)
+    tup = torch.load(buf, weights_only=False)
+    steps(a, oa, 2, 103)                      # uninterrupted
+    b = GaussianModel.from_tensors(*[torch.zeros_like(p) for p in a.parameters()], sh_degree=1)
+    ob = ShardedAdam(b.parameters(), lrs, eps=1e-15, opacity_decay=0.995, opacity_index=5, decay_first=True,
+                     adam_impl=torch_adam_impl)
+    b.restore(tup, None, optimizer=ob)
+    steps(b, ob, 2, 103)                      # resumed
+    same = all(torch.equal(x, y) for x, y in zip(a.parameters(), b.parameters())) and \
+        torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq) and int(ob.step_count) == 5
+    if rank == 0:
+        sd = tup[10]
+        torch.save(dict(same=same, state={k: {kk: vv.clone() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                        names=[g["name"] for g in sd["param_groups"]], params=[p.detach().clone() for p in a.parameters()]), out)
+    else:
+        assert same
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_moments_are_captured_and_restored_across_ranks(tmp_path):
+    """ShardedAdam keeps 1/N of exp_avg / exp_avg_sq per rank: capture() on 2 ranks (gloo) yields the SAME reference-format
+    state_dict as one process, and restore() + two more steps equals the uninterrupted run on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    outs = []
+    for world in (1, 2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        out = str(tmp_path / f"w{world}.pt")
+        if world == 1:
+            _ckpt_rank(0, 1, port, out)
+        else:
+            mp.spawn(_ckpt_rank, args=(world, port, out), nprocs=world, join=True)
+        outs.append(torch.load(out, weights_only=False))
+    one, two = outs
+    assert one["same"] and two["same"] and one["names"] == two["names"] == list(REF)
+    for k in one["state"]:
+        for kk in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.allclose(one["state"][k][kk], two["state"][k][kk], rtol=1e-6, atol=1e-12), (k, kk)
+    for x, y in zip(one["params"], two["params"]):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-9)
