@@ -48,7 +48,8 @@ struct BinView {        // sized by N (and P for the histogram)
 };
 
 // words of ImgView::header beyond the counts (0: N1, 1: V, 2: N2, 3: open tiles)
-#define B3GS_HDR_REPAIR_BARRIER 8   /* [8] arrival counter of the repair kernel's grid barrier, [9] its status (bit 0: time-out) */
+#define B3GS_HDR_REPAIR_BARRIER 8   /* [8] arrival counter of the repair kernel's grid barrier, [9] its status (bit 0: time-out),
+                                     * [10] two-round forwards that needed the repair round, [11] two-round forwards (view 0's buffer) */
 
 struct ImgView {        // sized by W*H
   uint32_t* header;     // [64]  header[0] = N used by the forward that filled this buffer

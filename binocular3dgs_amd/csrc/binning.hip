@@ -350,7 +350,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
   __shared__ uint32_t tmp[8];
   const ScanJob& job = sb.j[blockIdx.x];
   const int nchunks = sb.nchunks;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && sb.repair_barrier) *sb.repair_barrier = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && sb.repair_barrier) {
+    *sb.repair_barrier = 0u;
+    sb.repair_barrier[3] += 1u;   // two-round forwards into this image buffer (header word 11; word 10 counts the repaired ones)
+  }
   // nchunks <= 2048: 8 per thread, sequential
   uint32_t loc[8], s = 0, v = 0;
 #pragma unroll
@@ -1183,6 +1186,7 @@ __global__ void __launch_bounds__(256) repair_kernel(RepairArgs ra) {
   const uint32_t G = gridDim.x, wg = blockIdx.x;
   uint32_t phase = 0;
   bool ok = true;
+  if (wg == 0 && threadIdx.x == 0) ra.barrier[2] += 1u;   // forwards whose prediction missed (the host watches the rate)
 #define REPAIR_SYNC()                                                   \
   do {                                                                  \
     ok = ok && grid_barrier(ra.barrier, ++phase * G);                   \

@@ -119,6 +119,8 @@ class FusedRasterizer:
         # 800x600, 6 views, tools/sizes_ab.sh: 0.44M instances per view -3 %, 1.2M -2 %, 2.4M +3 %, 4.8M +7 %, 9.6M
         # +16 %), with segment 1 sized for ~0.75M instances of a view.
         self.two_round_min_instances = 2_000_000
+        self.two_round_max_miss_rate = 0.3
+        self.two_round_disabled = None     # (missed, total) when check_overflow() sent "auto" back to one round
         self._seg1_auto = seg1_fraction == "auto"
         self.seg1_fraction = 0.0 if self._seg1_auto else float(seg1_fraction)
         # N of every slot's last forward lives on the device (no read-back per view); `high_water` keeps the largest N
@@ -403,11 +405,29 @@ class FusedRasterizer:
             self.grow(need=hw)
         return max(hw, 1)
 
+    def repair_rate(self, reset: bool = False):
+        """(forwards whose open-tile prediction missed, two-round forwards) since the counters were last reset: words 10 /
+        11 of slot 0's image header, kept by the binning kernels (they also count inside HIP-graph replays)."""
+        w = self.slots[0].img[:48].view(torch.int32)
+        missed, total = int(w[10].item()), int(w[11].item())
+        if reset:
+            w[10:12] = 0
+        return missed, total
+
     def _check_repair_status(self):
         """Word 9 of slot 0's image header: bit 0 is set when a grid barrier of the second binning round's persistent
         kernel timed out (a workgroup of its grid never became resident) -- that forward's repaired tiles are wrong."""
         if self.seg1_fraction <= 0.0 or not self.slots:
             return
+        # the rule's safety net: two rounds pay only while the prediction holds (the repair round's slow path costs about
+        # twice what the second round of one-launch-per-stage binning did).  Cameras that change too much from one forward
+        # of a slot to the next make it miss; when more than `two_round_max_miss_rate` of the forwards since the last check
+        # needed a repair, "auto" goes back to one round (outside a graph capture: a captured step keeps what it captured)
+        if self._seg1_auto and not torch.cuda.is_current_stream_capturing():
+            missed, total = self.repair_rate(reset=True)
+            if total >= 8 and missed > self.two_round_max_miss_rate * total:
+                self.seg1_fraction = 0.0
+                self.two_round_disabled = (missed, total)
         st = int(self.slots[0].img[:48].view(torch.int32)[9].item())
         if st:
             self.slots[0].img[:48].view(torch.int32)[9] = 0

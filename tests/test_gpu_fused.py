@@ -641,6 +641,49 @@ def test_two_round_binning_equals_one_round(scene):
                     assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 5e-5   # fp32 atomics: the chunking of the lists differs
 
 
+def test_auto_rule_goes_back_to_one_round_when_the_prediction_keeps_missing():
+    """The binning kernels count two-round forwards and the ones whose open-tile prediction missed (image-header words 11 /
+    10).  When more than `two_round_max_miss_rate` of the forwards since the last check needed the repair round -- here the
+    prediction is wiped before every forward, as a slot whose camera changes completely would see it -- check_overflow()
+    sends "auto" back to one round; images never depended on any of it."""
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H, P = 208, 144, 30000
+    model, pairs, bg = _setup(P=P, W=W, H=H)
+    with torch.no_grad():
+        model._scaling += 0.6
+    views = [(pairs[0][0], 0, True), (pairs[0][1], 1, False)]
+    fr = FusedRasterizer(model, W, H, num_slots=2)
+    fr.two_round_min_instances = 0                  # make the rule pick two rounds on this small scene
+    fr.fit_capacity(views, bg)
+    assert 0.0 < fr.seg1_fraction <= 0.125
+    with torch.no_grad():
+        want = [o["render"].clone() for o in fr.render_batch(views, bg)]
+    fr.repair_rate(reset=True)
+    for _ in range(10):
+        for sl in fr.slots:                         # forget the prediction: this forward's second round has work
+            sl.img[64 * 4:].zero_()
+        with torch.no_grad():
+            outs = fr.render_batch(views, bg)
+        for a, b in zip(outs, want):
+            assert torch.equal(a["render"], b)
+    missed, total = fr.repair_rate()
+    assert total == 10 and missed == 10
+    assert fr.check_overflow() == 0 and fr.seg1_fraction == 0.0 and fr.two_round_disabled == (10, 10)
+    with torch.no_grad():
+        outs = fr.render_batch(views, bg)           # one round from now on
+    for a, b in zip(outs, want):
+        assert torch.equal(a["render"], b)
+    # a settled prediction keeps two rounds
+    fr2 = FusedRasterizer(model, W, H, num_slots=2)
+    fr2.two_round_min_instances = 0
+    fr2.fit_capacity(views, bg)
+    fr2.repair_rate(reset=True)
+    with torch.no_grad():
+        for _ in range(10):
+            fr2.render_batch(views, bg)
+    assert fr2.check_overflow() == 0 and fr2.seg1_fraction > 0.0 and fr2.two_round_disabled is None
+
+
 def _lists(fr, P, W, H, slots):
     from binocular3dgs_amd.debug import state_views
     out = []
