@@ -55,7 +55,24 @@ def optimizer_state_dict(model, optimizer, lrs_by_name: Optional[Dict[str, float
     """`optimizer.state_dict()` as the reference's torch.optim.Adam would return it.  A torch optimiser whose groups
     carry the reference's names is passed through unchanged."""
     if isinstance(optimizer, torch.optim.Optimizer):
-        return optimizer.state_dict()
+        sd = optimizer.state_dict()
+        gs = sd["param_groups"]
+        names = [g.get("name") for g in gs]
+        if sorted(n for n in names if n) == sorted(REF_GROUPS) and all(len(g["params"]) == 1 for g in gs) and \
+                names != list(REF_GROUPS):
+            # named groups in another order (e.g. model.parameters()): emit them in the reference's order, so that the
+            # reference's positional load_state_dict() pairs every tensor with its own moments
+            by = dict(zip(names, gs))
+            state, groups = {}, []
+            for idx, n in enumerate(REF_GROUPS):
+                g = dict(by[n])
+                st = sd["state"].get(g["params"][0])
+                if st is not None:
+                    state[idx] = st
+                g["params"] = [idx]
+                groups.append(g)
+            return {"state": state, "param_groups": groups}
+        return sd
     m, v, step, lrs, betas, eps = _full_moments(optimizer)
     params = {n: getattr(model, _ATTR[n]) for n in REF_GROUPS}
     offs, off = {}, 0
@@ -124,6 +141,30 @@ def _moments_from_state_dict(model, opt_dict) -> Tuple[torch.Tensor, torch.Tenso
     return torch.cat(ms), torch.cat(vs), (steps[0] if steps else 0), {n: float(by_name[n]["lr"]) for n in REF_GROUPS}
 
 
+def _by_group_name(optimizer, opt_dict) -> dict:
+    """torch's load_state_dict() pairs parameter groups BY POSITION.  The checkpoint's groups are in the reference's
+    order (xyz, f_dc, f_rest, opacity, scaling, rotation); a torch optimiser built over `model.parameters()` has scaling /
+    rotation / opacity elsewhere.  When both sides name their single-tensor groups, the checkpoint is re-ordered to the
+    target's order first (each group keeps the TARGET's hyper-parameter keys it lacks, e.g. after a torch upgrade)."""
+    tgt = optimizer.state_dict()["param_groups"]
+    src = opt_dict["param_groups"]
+    if not (all("name" in g for g in tgt) and all("name" in g for g in src) and
+            all(len(g["params"]) == 1 for g in tgt) and all(len(g["params"]) == 1 for g in src)):
+        return opt_dict
+    by = {g["name"]: g for g in src}
+    if sorted(by) != sorted(g["name"] for g in tgt):
+        raise ValueError(f"checkpoint groups {sorted(by)} do not match the optimizer's {sorted(g['name'] for g in tgt)}")
+    groups, state = [], {}
+    for g in tgt:
+        sg = dict(g)
+        sg.update({k: v for k, v in by[g["name"]].items() if k != "params"})
+        groups.append(sg)
+        st = opt_dict["state"].get(by[g["name"]]["params"][0])
+        if st is not None:
+            state[g["params"][0]] = st
+    return {"state": state, "param_groups": groups}
+
+
 def restore(model, model_args: tuple, optimizer=None, optimizer_factory=None):
     """scene/gaussian_model.py:77-93: put a captured tuple back.  `optimizer` (FusedAdam / ShardedAdam / torch Adam built
     over model.parameters()) receives the Adam state; alternatively `optimizer_factory(model) -> optimizer` is called
@@ -150,7 +191,7 @@ def restore(model, model_args: tuple, optimizer=None, optimizer_factory=None):
     if optimizer is None:
         return None
     if isinstance(optimizer, torch.optim.Optimizer):
-        optimizer.load_state_dict(opt_dict)
+        optimizer.load_state_dict(_by_group_name(optimizer, opt_dict))
         model.optimizer = optimizer
         return optimizer
     from .step import FusedAdam, ShardedAdam

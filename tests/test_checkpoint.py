@@ -134,6 +134,33 @@ def test_restore_roundtrip_cpu_structures():
         m2.restore(tuple(bad), None, optimizer=opt2)
 
 
+def test_restore_into_a_torch_optimizer_in_model_order_pairs_groups_by_name():
+    """load_state_dict() pairs groups by POSITION; a torch.optim.Adam built over model.parameters() (xyz, f_dc, f_rest,
+    scaling, rotation, opacity) must still receive each tensor's own moments from a checkpoint in the reference's order."""
+    z, st = gold()
+    m = model_from_gold(z)
+    opt = FusedAdam(m.parameters(), lrs_model_order(st), eps=st["group_eps"])
+    load_moments(opt, z)
+    tup = m.capture(opt)
+    m2 = GaussianModel.from_tensors(*[torch.zeros_like(p) for p in m.parameters()], sh_degree=1)
+    topt = torch.optim.Adam([{"params": [p], "lr": 0.5, "name": n} for p, n in zip(m2.parameters(), MODEL_ORDER)], lr=0.0, eps=1e-15)
+    m2.restore(tup, None, optimizer=topt)
+    for p, n in zip(m2.parameters(), MODEL_ORDER):
+        assert np.array_equal(topt.state[p]["exp_avg"].numpy(), z[f"m_{n}"]), n
+        assert np.array_equal(topt.state[p]["exp_avg_sq"].numpy(), z[f"v_{n}"]), n
+        p.grad = torch.from_numpy(z[f"g_{n}"])
+    by = dict(zip(st["group_names"], st["group_lrs"]))
+    assert [g["lr"] for g in topt.param_groups] == [by[n] for n in MODEL_ORDER]
+    # ... and capture() of that torch optimiser emits the reference's order again
+    sd = m2.capture(topt)[10]
+    assert [g["name"] for g in sd["param_groups"]] == list(REF) and [g["params"] for g in sd["param_groups"]] == [[i] for i in range(6)]
+    for i, n in enumerate(REF):
+        assert np.array_equal(sd["state"][i]["exp_avg"].numpy(), z[f"m_{n}"]), n
+    topt.step()
+    for p, n in zip(m2.parameters(), MODEL_ORDER):
+        np.testing.assert_allclose(p.detach().numpy(), z[f"after_{n}"], rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scene"), reason="the reference tree exists in the build container only")
 def test_reference_restore_consumes_our_tuple():
     """Live check (build container): the reference's own GaussianModel.restore() takes the tuple this build captured and
