@@ -443,13 +443,15 @@ class FusedRasterizer:
             self.render_batch([(v[0], v[1]) for v in views], bg_color)
         need = max(self.num_rendered())
         self.high_water.zero_()
+        if int(self.overflow_flag.item()) & 2:     # a depth key outside the 27-bit span: sort all 32 bits from now on
+            self.depth_key_bits = 0
         self.overflow_flag.zero_()       # (a too-small start-up capacity is what this call is here to fix)
         if need * margin > self.capacity:
             self.grow(factor=margin, need=need)
         # two rounds: the nearest fraction of the depth order everywhere + the rest into the tiles predicted open
         # (the ones the previous forward of that slot left unterminated); segment 1 sized for ~0.75M instances of a view
-        self.seg1_fraction = (0.0 if need < self.two_round_min_instances else min(0.125, max(0.02, 0.75e6 / need))) \
-            if self._seg1_auto else frac
+        self.seg1_fraction = (0.0 if (need < self.two_round_min_instances or self.two_round_disabled)
+                              else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
         if self.seg1_fraction > 0.0:
             with torch.no_grad():     # one forward settles the open-tile prediction (the first one repairs many tiles)
                 self.render_batch([(v[0], v[1]) for v in views], bg_color)
