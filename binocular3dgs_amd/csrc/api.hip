@@ -383,6 +383,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     if (frac > 0.0f && frac < 1.0f && P > 1 && !views[0].fresh_image) {
       K1 = (int32_t)((double)frac * (double)P + 0.999999);
       K1 = K1 < 1 ? 1 : K1;
+      K1 = (int32_t)((((int64_t)K1 + 4095) / 4096) * 4096);   // whole 4096-Gaussian tiles of the depth order (binning.hip)
       for (int k = 0; k < nviews && K1; k++) {
         const B3gsScene& sc = *views[k].view;
         if ((b3gs_tile_bits(sc.W, sc.H) + 7) / 8 != (b3gs_tile_bits(views[0].view->W, views[0].view->H) + 7) / 8) K1 = 0;

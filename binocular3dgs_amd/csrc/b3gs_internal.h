@@ -39,6 +39,10 @@ struct GeomView {       // sized by P
   unsigned long long* pflag;  // [ceil(P / 64)] two-round forward: bit i set = the tile rect of Gaussian i reaches a tile that
                         //       is predicted open (written by the projection: the scan gathers the rects of the Gaussians
                         //       behind segment 1 only where this bit is set)
+  uint32_t* flist;      // [P]   two-round forward: per 4096-Gaussian tile of the depth order behind segment 1, the flagged
+                        //       Gaussians in depth order (local index | view flags); their number in fcount
+  uint32_t* fcount;     // [ceil(P / 4096)]
+  uint32_t* tsum;       // [ceil(P / 4096)] tile instances of every 4096-Gaussian tile of the depth order
 };
 
 struct BinView {        // sized by N (and P for the histogram)
@@ -125,6 +129,9 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
   t.bwd_rows = b3gs_carve<float>(cur, p * B3GS_SCRATCH_ROW);
   t.pflag = b3gs_carve<unsigned long long>(cur, (p + 63) / 64);
+  t.flist = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096 * 4096);
+  t.fcount = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096);
+  t.tsum = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096);
   if (v) *v = t;
   return (size_t)(cur - base);
 }

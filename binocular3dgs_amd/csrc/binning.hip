@@ -102,6 +102,9 @@ struct ScanJob {
   int32_t* overflow_flag;   // optional: set when N exceeds n_bound (the lists of this view are truncated)
   uint32_t n_bound;
   const unsigned long long* pflag;   // two-round: bit g set = Gaussian g's rect reaches a predicted-open tile (projection)
+  uint32_t* flist;          // two-round: per 4096-Gaussian tile behind K1, its flagged Gaussians in depth order (a pair shares
+  uint32_t* fcount;         //   the donor's list: entries carry a flag per view) and their number
+  uint32_t* tsum;           // instances of every 4096-Gaussian tile of the depth order
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
@@ -124,10 +127,15 @@ struct EmitJob {
   const uint32_t* open_count;   // round 2: their number (0: nothing to emit)
   const uint32_t* off_ptr;      // round 2: device word N1: the instances go behind segment 1 in the same arrays
   const uint32_t* chunk_base;   // round 1: exclusive instance offset of every scan chunk (soffs holds the sub-block sums)
+  const uint32_t* flist;        // round 1 of a two-round forward: the flagged Gaussians of every 4096-Gaussian tile behind K1,
+  const uint32_t* fcount;       //   in depth order (ScanJob::flist; a pair shares the donor's list), their number per tile,
+  const uint32_t* tsum;         //   and the instance total of every tile (a later tile of the same chunk starts behind it)
 };
 struct EmitBatch {
   int32_t n, P, first, subs;    // Gaussians [first, P) of the depth order; round 1: 256-Gaussian sub-blocks per scan chunk
   int32_t K1;                   // round 1: Gaussians behind K1 go to the predicted-open tiles only (K1 == P: one round)
+  int32_t dense_blocks;         // round 1: workgroups [0, dense_blocks) expand the 256-Gaussian sub-blocks of segment 1, the
+  int32_t tiles_per_chunk;      //   others walk the flagged list of one 4096-Gaussian tile behind K1 each
   EmitJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -193,134 +201,154 @@ constexpr int SCAN_MAX_SUBS = 64;
 #endif
 constexpr int SCAN_BATCH = B3GS_SCAN_BATCH;
 constexpr int SCAN_PRED_WORDS = 512;   // LDS copy of a tile bitmap (4 KB): up to 512 tile rows of <= 64 tiles, 256 of <= 128, ...   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
+// Behind segment 1 (two-round forward) a Gaussian only matters when its rect reaches a predicted-open tile: the
+// projection left that as one bit per Gaussian, ~5 % of them are flagged.  Letting every lane handle its own Gaussian
+// made every wave run the rect gather + bitmap popcounts for two or three live lanes (measured: +29 us here and +28 us in
+// the emission for that 5 %), so a 4096-Gaussian tile behind segment 1 is processed in two steps: the flags of its 16
+// sub-blocks are ballot-compacted IN DEPTH ORDER into an LDS list, then the list is walked with dense lanes.  The list
+// (local index | view flags) also goes to memory: the emission visits exactly these entries (EmitJob::flist).
+constexpr uint32_t FL_IDX = 0xFFFu, FL_A = 1u << 12, FL_B = 1u << 13;
+
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
   __shared__ uint32_t ssub[2][4][SCAN_MAX_SUBS];
   __shared__ unsigned long long s_pred[2][SCAN_PRED_WORDS];
+  __shared__ unsigned long long s_mask[SCAN_ITEMS][4];   // flagged lanes of (sub-block, wave) of the tile being compacted
+  __shared__ uint32_t s_base[SCAN_ITEMS][4];
+  __shared__ uint32_t s_list[SCAN_TILE];
+  __shared__ uint32_t s_H;
   const ScanJob& job = sb.j[blockIdx.y];
   if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
+  const bool pair = job.partner >= 0;
+  const ScanJob& pj = pair ? sb.j[job.partner] : job;
   const uint32_t* __restrict__ order = job.order;
   const int subs = sb.tiles_per_chunk * SCAN_ITEMS;
   const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+  const u64 lt = lanemask_lt();
   uint32_t sum = 0, vis = 0, sum2 = 0, vis2 = 0;
-  // Gaussians behind segment 1 count their tiles in the predicted-open bitmap: a few dependent word loads per rect, so
-  // the bitmap (304 bytes at 800x600) is staged in LDS when it fits
-  OpenMap pa = job.pred, pb2 = job.partner >= 0 ? sb.j[job.partner].pred : job.pred;
+  // the bitmaps of the tiles predicted open (304 bytes at 800x600) are staged in LDS when they fit
+  OpenMap pa = job.pred, pb2 = pj.pred;
   if (end > (int64_t)sb.K1) {
     const uint32_t na = pa.grid_y * pa.row_words, nb = pb2.grid_y * pb2.row_words;
     if (na <= (uint32_t)SCAN_PRED_WORDS && nb <= (uint32_t)SCAN_PRED_WORDS) {
       for (uint32_t k = threadIdx.x; k < na; k += SCAN_THREADS) s_pred[0][k] = pa.rows[k];
-      if (job.partner >= 0)
+      if (pair)
         for (uint32_t k = threadIdx.x; k < nb; k += SCAN_THREADS) s_pred[1][k] = pb2.rows[k];
       __syncthreads();
       pa.rows = s_pred[0];
       pb2.rows = s_pred[1];
     }
   }
-  // tiles_touched == area of the rectangle (preprocess keeps them consistent)
-  // (sub-blocks in batches of four: the four index loads, then the four dependent rect gathers, are in flight together)
-  // Behind segment 1 a Gaussian only matters when its rect reaches a predicted-open tile: the projection left that as
-  // one bit per Gaussian (125 KB per view: L2-resident), so the random 16-byte rect gather -- one 128-byte line each
-  // -- is paid for the flagged ones only (a few per cent).
-  if (job.partner >= 0) {
-    const ScanJob& pj = sb.j[job.partner];
-    const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);
-    const unsigned long long* __restrict__ fa_map = job.pflag;
-    const unsigned long long* __restrict__ fb_map = pj.pflag;
-    uint2* __restrict__ sa = job.srect;
-    uint2* __restrict__ sb2 = pj.srect;
-    for (int r0 = 0; r0 < subs; r0 += SCAN_BATCH) {   // subs is a multiple of 16
-      uint32_t oi[SCAN_BATCH];
-      uint4 rr[SCAN_BATCH];
-      bool fa[SCAN_BATCH], fb[SCAN_BATCH];
+  const uint2* __restrict__ rect1 = job.rect;
+  const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);   // pair: [P][2] rects, one 16-byte gather
+  const size_t stride = (size_t)job.rect_stride;
+  uint2* __restrict__ sa = job.srect;
+  uint2* __restrict__ sb2 = pj.srect;
+  for (int t = 0; t < sb.tiles_per_chunk; t++) {
+    const int64_t tb = begin + (int64_t)t * SCAN_TILE;
+    if (tb >= end) break;
+    const int64_t te = min(end, tb + (int64_t)SCAN_TILE);
+    const size_t tile = (size_t)blockIdx.x * sb.tiles_per_chunk + t;
+    uint32_t ts_a = 0, ts_b = 0;   // this thread's share of the tile's instance totals
+    if (tb < (int64_t)sb.K1) {
+      // ---- segment 1 (K1 is a multiple of the tile size, or P): every Gaussian emits its whole rect.
+      // tiles_touched == area of the rectangle (preprocess keeps them consistent); sub-blocks in batches: the index
+      // loads, then the dependent rect gathers (the random access of the binning), are in flight together
+      for (int r0 = 0; r0 < SCAN_ITEMS; r0 += SCAN_BATCH) {
+        uint32_t oi[SCAN_BATCH];
+        uint4 rr[SCAN_BATCH];
 #pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-        oi[k] = i < end ? order[i] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-        fa[k] = fb[k] = i < end;
-        if (i < end && i >= sb.K1) {
-          fa[k] = (fa_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
-          fb[k] = (fb_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
+        for (int k = 0; k < SCAN_BATCH; k++) {
+          const int64_t i = tb + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+          oi[k] = i < te ? order[i] : 0u;
         }
-      }
 #pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        rr[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (fa[k] || fb[k]) rr[k] = rect2[oi[k]];   // the random access of the binning: one line for both views of the pair
-      }
+        for (int k = 0; k < SCAN_BATCH; k++) {
+          const int64_t i = tb + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
+          rr[k] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < te) {
+            if (pair) rr[k] = rect2[oi[k]];
+            else { const uint2 q = rect1[oi[k] * stride]; rr[k].x = q.x; rr[k].y = q.y; }
+          }
+        }
 #pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int r = r0 + k;
-        const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
-        uint32_t ta = 0, tb = 0;
-        if (i < end) {
-          const uint2 ra = make_uint2(rr[k].x, rr[k].y), rb = make_uint2(rr[k].z, rr[k].w);
-          if (i < sb.K1) {
+        for (int k = 0; k < SCAN_BATCH; k++) {
+          const int r = r0 + k;
+          const int64_t i = tb + (int64_t)r * SCAN_THREADS + threadIdx.x;
+          uint32_t ta = 0, tb_ = 0;
+          if (i < te) {
+            const uint2 ra = make_uint2(rr[k].x, rr[k].y), rb = make_uint2(rr[k].z, rr[k].w);
             sa[i] = ra;
-            sb2[i] = rb;
             ta = rect_area(ra);
-            tb = rect_area(rb);
-          } else {   // behind segment 1: only the tiles predicted open
-            if (fa[k]) { ta = open_tiles(ra, pa); sa[i] = ra; }
-            if (fb[k]) { tb = open_tiles(rb, pb2); sb2[i] = rb; }
-            job.scount[i] = ta;
-            pj.scount[i] = tb;
+            if (pair) { sb2[i] = rb; tb_ = rect_area(rb); }
           }
+          ts_a += ta; vis += (ta != 0);
+          ts_b += tb_; vis2 += (tb_ != 0);
+          const uint32_t wa = wave_sum(ta), wb = wave_sum(tb_);
+          if (lane == 0) { ssub[0][w][t * SCAN_ITEMS + r] = wa; ssub[1][w][t * SCAN_ITEMS + r] = wb; }
         }
-        sum += ta; vis += (ta != 0);
-        sum2 += tb; vis2 += (tb != 0);
-        const uint32_t wa = wave_sum(ta), wb = wave_sum(tb);
-        if (lane == 0) { ssub[0][w][r] = wa; ssub[1][w][r] = wb; }
       }
-    }
-  } else {
-    const uint2* __restrict__ rect = job.rect;
-    const size_t stride = (size_t)job.rect_stride;
-    const unsigned long long* __restrict__ f_map = job.pflag;
-    uint2* __restrict__ srect = job.srect;
-    for (int r0 = 0; r0 < subs; r0 += SCAN_BATCH) {
-      uint32_t oi[SCAN_BATCH];
-      uint2 rr[SCAN_BATCH];
-      bool fl[SCAN_BATCH];
+    } else {
+      // ---- behind segment 1: compact the flagged Gaussians of the tile (in depth order), then walk them densely
+      uint32_t fl[SCAN_ITEMS];
 #pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-        oi[k] = i < end ? order[i] : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int64_t i = begin + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-        fl[k] = i < end;
-        if (i < end && i >= sb.K1) fl[k] = (f_map[oi[k] >> 6] >> (oi[k] & 63u)) & 1ull;
-        rr[k] = make_uint2(0u, 0u);
-        if (fl[k]) rr[k] = rect[oi[k] * stride];
-      }
-#pragma unroll
-      for (int k = 0; k < SCAN_BATCH; k++) {
-        const int r = r0 + k;
-        const int64_t i = begin + (int64_t)r * SCAN_THREADS + threadIdx.x;
-        uint32_t t = 0;
-        if (i < end) {
-          if (i < sb.K1) {
-            srect[i] = rr[k];
-            t = rect_area(rr[k]);
-          } else {
-            if (fl[k]) { t = open_tiles(rr[k], pa); srect[i] = rr[k]; }
-            job.scount[i] = t;
-          }
+      for (int r = 0; r < SCAN_ITEMS; r++) {
+        const int64_t i = tb + (int64_t)r * SCAN_THREADS + threadIdx.x;
+        uint32_t f = 0u;
+        if (i < te) {
+          const uint32_t g = order[i];
+          f = (uint32_t)((job.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_A;
+          if (pair) f |= (uint32_t)((pj.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_B;
         }
-        sum += t;
-        vis += (t != 0);
-        const uint32_t wa = wave_sum(t);
-        if (lane == 0) ssub[0][w][r] = wa;
+        fl[r] = f;
+        const u64 m = __ballot(f != 0u);
+        if (lane == 0) { s_mask[r][w] = m; ssub[0][w][t * SCAN_ITEMS + r] = 0u; ssub[1][w][t * SCAN_ITEMS + r] = 0u; }
       }
+      __syncthreads();
+      if (threadIdx.x < 64u) {   // 16 x 4 cells in depth order (sub-block major, then wave): exclusive prefix of their counts
+        const uint32_t c = (uint32_t)__popcll(s_mask[threadIdx.x >> 2][threadIdx.x & 3u]);
+        const uint32_t inc = wave_incl_scan(c);
+        s_base[threadIdx.x >> 2][threadIdx.x & 3u] = inc - c;
+        if (threadIdx.x == 63u) s_H = inc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < SCAN_ITEMS; r++)
+        if (fl[r]) s_list[s_base[r][w] + (uint32_t)__popcll(s_mask[r][w] & lt)] = (uint32_t)(r * SCAN_THREADS + threadIdx.x) | fl[r];
+      __syncthreads();
+      const uint32_t Hn = s_H;
+      uint32_t* __restrict__ flist = job.flist + tile * SCAN_TILE;
+      for (uint32_t e = threadIdx.x; e < Hn; e += SCAN_THREADS) {
+        const uint32_t ent = s_list[e];
+        const int64_t i = tb + (int64_t)(ent & FL_IDX);
+        const uint32_t g = order[i];
+        uint2 ra, rb = make_uint2(0u, 0u);
+        if (pair) { const uint4 q = rect2[g]; ra = make_uint2(q.x, q.y); rb = make_uint2(q.z, q.w); }
+        else ra = rect1[g * stride];
+        const uint32_t ta = (ent & FL_A) ? open_tiles(ra, pa) : 0u;
+        const uint32_t tb_ = (pair && (ent & FL_B)) ? open_tiles(rb, pb2) : 0u;
+        sa[i] = ra;
+        job.scount[i] = ta;
+        if (pair) { sb2[i] = rb; pj.scount[i] = tb_; }
+        flist[e] = ent;
+        ts_a += ta; vis += (ta != 0);
+        ts_b += tb_; vis2 += (tb_ != 0);
+      }
+      if (threadIdx.x == 0) job.fcount[tile] = Hn;
+      __syncthreads();   // (s_mask / s_list are reused by the next tile of the chunk)
     }
+    // the tile's instance totals (the emission of a later tile of the same chunk starts behind them)
+    uint32_t tot_a, tot_b;
+    block_excl_scan_256(ts_a, tmp, &tot_a);
+    block_excl_scan_256(ts_b, tmp, &tot_b);
+    if (threadIdx.x == 0) {
+      job.tsum[tile] = tot_a;
+      if (pair) pj.tsum[tile] = tot_b;
+    }
+    sum += ts_a;
+    sum2 += ts_b;
   }
   uint32_t tot, tot2;
   block_excl_scan_256(sum, tmp, &tot);      // (its barriers also publish ssub)
@@ -332,8 +360,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   if ((int)threadIdx.x < subs)
     job.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
         (ssub[0][0][threadIdx.x] + ssub[0][1][threadIdx.x]) + (ssub[0][2][threadIdx.x] + ssub[0][3][threadIdx.x]);
-  if (job.partner >= 0) {
-    const ScanJob& pj = sb.j[job.partner];
+  if (pair) {
     block_excl_scan_256(sum2, tmp, &tot);
     block_excl_scan_256(vis2, tmp, &tot2);
     if (threadIdx.x == 0) {
@@ -830,6 +857,49 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
   uint32_t* __restrict__ tile_out = job.tile_out + off;
   uint32_t* __restrict__ idx_out = job.idx_out ? job.idx_out + off : nullptr;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+  if (!ROUND2 && (int)bx >= eb.dense_blocks) {
+    // One 4096-Gaussian tile behind segment 1 of a two-round forward: only its flagged Gaussians can emit anything (into
+    // the tiles predicted open).  The scan left them as a list in depth order: dense lanes walk it 256 at a time; every
+    // lane writes the few instances of its own Gaussian (no cooperative expansion, no search).
+    const uint32_t tile = (uint32_t)(eb.K1 / SCAN_TILE) + (bx - (uint32_t)eb.dense_blocks);
+    const uint32_t Hn = job.fcount[tile];
+    if (Hn == 0u) return;
+    const uint32_t chunk = tile / (uint32_t)eb.tiles_per_chunk;
+    uint32_t carry = job.chunk_base[chunk];
+    for (uint32_t k = chunk * (uint32_t)eb.tiles_per_chunk; k < tile; k++) carry += job.tsum[k];
+    const uint32_t* __restrict__ flist = job.flist + (size_t)tile * SCAN_TILE;
+    for (uint32_t e0 = 0; e0 < Hn; e0 += 256u) {
+      const uint32_t e = e0 + threadIdx.x;
+      uint32_t sidx = 0, cnt = 0;
+      if (e < Hn) {
+        sidx = tile * (uint32_t)SCAN_TILE + (flist[e] & FL_IDX);
+        cnt = job.scount[sidx];       // 0 when the Gaussian is flagged for the other view of the pair only
+      }
+      uint32_t tot;
+      uint32_t pos = carry + block_excl_scan_256(cnt, s_tmp, &tot);
+      carry += tot;
+      if (cnt != 0u) {
+        const uint32_t gid = job.order[sidx];
+        const uint2 rc = job.srect[sidx];
+        const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+        for (uint32_t y = y0; y < y1; y++)
+          for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
+            uint32_t c0;
+            unsigned long long m = open_bits(job.open, y, wb, x0, x1, &c0);
+            while (m) {
+              const uint32_t t = y * job.open.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
+              m &= m - 1ull;
+              if (pos < n_cap) {
+                if (idx_out) { tile_out[pos] = t; idx_out[pos] = gid; }
+                else tile_out[pos] = (t << job.idx_bits) | gid;
+              }
+              pos++;
+            }
+          }
+      }
+    }
+    return;
+  }
   const int s = eb.first + (int)(bx * 256 + threadIdx.x);
   uint32_t gid = 0, cnt = 0, end = 0;
   uint2 rc = make_uint2(0, 0);
@@ -845,13 +915,10 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
       gid = job.order[s];
       rc = job.srect[s];
       end = job.soffs[s];
-    } else if (s < eb.K1) {
+    } else {   // (a dense block of round 1 lies inside segment 1: K1 is a multiple of the 4096-Gaussian tile, or P)
       gid = job.order[s];
       rc = job.srect[s];
       cnt = rect_area(rc);
-    } else if ((cnt = job.scount[s]) != 0u) {   // behind segment 1: almost every count is zero (4 bytes instead of 16)
-      gid = job.order[s];
-      rc = job.srect[s];
     }
   }
   if (!ROUND2) {
@@ -873,29 +940,6 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
 
   const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu;
   const uint32_t rw = x1 - x0;
-  if (!ROUND2 && (int)(bx * 256 + w * 64) >= eb.K1) {
-    // a wave behind segment 1 of a two-round forward: a handful of its Gaussians reach a predicted-open tile, a few
-    // instances each -- every lane walks its own rect over the bitmap (no cooperative expansion, no search)
-    if (cnt != 0u) {
-      uint32_t pos = end - cnt;
-      const uint32_t y1 = rc.y >> 16;
-      for (uint32_t y = y0; y < y1; y++)
-        for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
-          uint32_t c0;
-          unsigned long long m = open_bits(job.open, y, wb, x0, x1, &c0);
-          while (m) {
-            const uint32_t tile = y * job.open.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
-            m &= m - 1ull;
-            if (pos < n_cap) {
-              if (idx_out) { tile_out[pos] = tile; idx_out[pos] = gid; }
-              else tile_out[pos] = (tile << job.idx_bits) | gid;
-            }
-            pos++;
-          }
-        }
-    }
-    return;
-  }
   for (uint32_t j0 = wave_begin; wave_active && j0 < wave_end; j0 += 64) {
     const uint32_t j = j0 + lane;
     // smallest src with s_end[src] > j
@@ -909,10 +953,10 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
     const uint32_t src_cnt = __shfl(cnt, (int)lo, 64);
     const uint32_t src_gid = __shfl(gid, (int)lo, 64);
     const uint32_t src_x0 = __shfl(x0, (int)lo, 64), src_y0 = __shfl(y0, (int)lo, 64), src_rw = __shfl(rw, (int)lo, 64);
-    // the source lies behind segment 1 of a two-round forward: its instances are the predicted-open tiles of its rect
-    const bool masked = ROUND2 || (int)(bx * 256 + w * 64 + lo) >= eb.K1;
+    // round 2: the source's instances are the still-open tiles of its rect
+    const bool masked = ROUND2;
     uint2 src_rc = make_uint2(0u, 0u);
-    if (ROUND2 || (int)(bx * 256 + w * 64 + 63) >= eb.K1) {   // (wave-uniform)
+    if (ROUND2) {
       src_rc.x = __shfl(rc.x, (int)lo, 64);
       src_rc.y = __shfl(rc.y, (int)lo, 64);
     }
@@ -1253,6 +1297,19 @@ int tile_sort_passes(int W, int H) {
 
 }  // namespace
 
+// the view whose rects sit in the odd slots of view d's [P][2] rect array and which borrows d's depth order: d's scan
+// workgroups gather both rects with one load and keep ONE flagged list for the pair (or -1)
+static int scan_partner_of(const BinJob* jobs, int nviews, int d) {
+  const uint2* rd = jobs[d].rect ? jobs[d].rect : jobs[d].g.rect;
+  const int sd = jobs[d].rect ? jobs[d].rect_stride : 1;
+  for (int v = 0; v < nviews; v++) {
+    const uint2* rv = jobs[v].rect ? jobs[v].rect : jobs[v].g.rect;
+    const int sv = jobs[v].rect ? jobs[v].rect_stride : 1;
+    if (jobs[v].order_from == d && sv == 2 && sd == 2 && rv == rd + 1) return v;
+  }
+  return -1;
+}
+
 static const uint32_t* depth_order_of(const BinJob* jobs, int v) {
   const BinJob& jb = jobs[v];
   return jb.order_from == -1 ? jb.g.sval[0] : (jb.order_from >= 0 ? jobs[jb.order_from].g.sval[0] : jb.order);
@@ -1341,15 +1398,14 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
                       jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
                       open_map(jb.im.pred_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
-                      (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0), jb.g.pflag};
+                      (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0), jb.g.pflag,
+                      jb.g.flist, jb.g.fcount, jb.g.tsum};
   }
   // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
   // into d's gather
-  for (int v = 0; v < nviews; v++) {
-    const int d = jobs[v].order_from;
-    if (d < 0 || sc.j[d].partner != -1 || sc.j[v].rect_stride != 2 || sc.j[d].rect_stride != 2 ||
-        sc.j[v].rect != sc.j[d].rect + 1)
-      continue;
+  for (int d = 0; d < nviews; d++) {
+    const int v = jobs[d].order_from == -1 ? scan_partner_of(jobs, nviews, d) : -1;
+    if (v < 0) continue;
     sc.j[d].partner = v;
     sc.j[v].partner = -2;
   }
@@ -1388,8 +1444,12 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   eb.first = 0;
   {   // the chunking of b3gs_launch_depth_order_batch's scan
     const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
-    eb.subs = ((total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS) * SCAN_ITEMS;
+    eb.tiles_per_chunk = (total_tiles + SCAN_MAX_CHUNKS - 1) / SCAN_MAX_CHUNKS;
+    eb.subs = eb.tiles_per_chunk * SCAN_ITEMS;
   }
+  // segment 1 as 256-Gaussian sub-blocks, then one workgroup per 4096-Gaussian tile behind it (flagged lists)
+  eb.dense_blocks = K1 < P ? K1 / 256 : (P + 255) / 256;
+  const int emit_blocks = eb.dense_blocks + (K1 < P ? (P - K1 + SCAN_TILE - 1) / SCAN_TILE : 0);
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -1402,23 +1462,28 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
     const int gx = (jb.W + B3GS_TILE - 1) / B3GS_TILE;
     const int idx_bits = b3gs_packed_idx_bits(P, jb.W, jb.H);
     const OpenMap pm = open_map(jb.im.pred_rows, jb.W, jb.H);
+    // the flagged lists of a pair live with the view whose workgroups scanned both
+    const int dn = jb.order_from;
+    const GeomView& fg = (dn >= 0 && scan_partner_of(jobs, nviews, dn) == v) ? jobs[dn].g : jb.g;
     if (idx_bits >= 0) {
       // (tile << idx_bits | index) fits 32 bits: ONE word per instance through emission, both passes and the
       // blend kernels (which mask the index out) -- half the tile-sort traffic.  The words ping-pong
       // between val[first] and val[first ^ 1] and end in val[0], where the point list is expected.
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp,
+                        fg.flist, fg.fcount, jb.g.tsum};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header, jb.im.ranges, n_cap, idx_bits, nullptr};
     } else {
-      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp};
+      eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0, jb.g.scount, pm, nullptr, nullptr, jb.g.scan_tmp,
+                        fg.flist, fg.fcount, jb.g.tsum};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, nullptr};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header, jb.im.ranges, n_cap, 0, nullptr};
     }
   }
   if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
-  hipLaunchKernelGGL(emit_instances<false>, dim3((P + 255) / 256, nviews), dim3(256), 0, s, eb);
+  hipLaunchKernelGGL(emit_instances<false>, dim3(emit_blocks, nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
   for (int p = 0; p < passes; p++) {
@@ -1477,6 +1542,8 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   eb.K1 = P;
   eb.first = K1;
   eb.subs = 1;
+  eb.dense_blocks = 0x7FFFFFFF;
+  eb.tiles_per_chunk = 1;
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -1491,13 +1558,13 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
     const OpenMap om = open_map(jb.im.open_rows, jb.W, jb.H);
     if (idx_bits >= 0) {
       eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.val[first], nullptr, n_cap, gx, idx_bits,
-                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr};
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr, nullptr, nullptr, nullptr};
       tb.j[v] = SortJob{jb.b.val[first], nullptr, jb.b.val[first ^ 1], nullptr, jb.g.header + 2, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), idx_bits, jb.b.hist, nullptr, jb.g.header};
       rb.j[v] = RangeJob{jb.b.val[0], jb.g.header + 2, jb.im.ranges2, n_cap, idx_bits, jb.g.header};
     } else {
       eb.j[v] = EmitJob{depth_order_of(jobs, v), jb.g.soffs, jb.g.srect, jb.b.key[first], jb.b.val[first], n_cap, gx, 0,
-                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr};
+                        jb.g.scount, om, jb.im.header + 3, jb.g.header, nullptr, nullptr, nullptr, nullptr};
       tb.j[v] = SortJob{jb.b.key[first], jb.b.val[first], jb.b.key[first ^ 1], jb.b.val[first ^ 1], jb.g.header + 2, n_cap,
                         b3gs_sort_blocks((int64_t)n_cap), 0, jb.b.hist, nullptr, jb.g.header};
       rb.j[v] = RangeJob{jb.b.key[0], jb.g.header + 2, jb.im.ranges2, n_cap, 0, jb.g.header};
