@@ -77,7 +77,21 @@ struct SortJob {
   uint2* ranges;         // non-null on the LAST pass of the tile sort: per-tile [begin, end) by atomic min / max
   const uint32_t* off_ptr;   // null, or a device word: the n elements start at that offset of kin / vin / kout / vout
                              // (segment 2 of the tile lists sits behind segment 1 in the same arrays; ranges are absolute)
+  // depth sort of a two-round forward: one bit per element (bit i of word i / 64) that the FIRST pass -- the one that
+  // creates the values -- puts into bits 30 / 31 of the value, so that the flag travels with the order (ORDER_* below)
+  const unsigned long long* flag[2];
 };
+// A depth order's words: Gaussian index | flags.  The flags say "the rect of this Gaussian reaches a tile that is predicted
+// open" for the view that owns the order (A) and for its binocular partner (B): the scan behind segment 1 reads them with
+// the order itself instead of gathering GeomView::pflag at a random index per lane (measured: that gather -- 6M separate L2
+// requests per iteration -- was 25 of the scan's 67 us).
+constexpr uint32_t ORDER_IDX = 0x3FFFFFFFu, ORDER_A = 1u << 30, ORDER_B = 1u << 31;
+__device__ __forceinline__ uint32_t order_value(const SortJob& job, uint32_t gi) {
+  uint32_t v = gi;
+  if (job.flag[0]) v |= (uint32_t)((job.flag[0][gi >> 6] >> (gi & 63u)) & 1ull) << 30;
+  if (job.flag[1]) v |= (uint32_t)((job.flag[1][gi >> 6] >> (gi & 63u)) & 1ull) << 31;
+  return v;
+}
 struct SortBatch {
   int32_t n;
   SortJob j[B3GS_MAX_FUSED_VIEWS];
@@ -105,6 +119,7 @@ struct ScanJob {
   uint32_t* flist;          // two-round: per 4096-Gaussian tile behind K1, its flagged Gaussians in depth order (a pair shares
   uint32_t* fcount;         //   the donor's list: entries carry a flag per view) and their number
   uint32_t* tsum;           // instances of every 4096-Gaussian tile of the depth order
+  int32_t order_flags;      // two-round: the order words carry this view's (and its partner's) flag bits (ORDER_A / ORDER_B)
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
@@ -209,6 +224,20 @@ constexpr int SCAN_PRED_WORDS = 512;   // LDS copy of a tile bitmap (4 KB): up t
 // (local index | view flags) also goes to memory: the emission visits exactly these entries (EmitJob::flist).
 constexpr uint32_t FL_IDX = 0xFFFu, FL_A = 1u << 12, FL_B = 1u << 13;
 
+#ifdef B3GS_BIN_TRACE   // (tools/bin_trace.py: per-workgroup wall-clock stamps of the scan and the emission; never in the product build)
+__device__ unsigned long long g_bin_trace[2][8192][8];
+#define BIN_TRACE(k, wg, slot, val) do { if (threadIdx.x == 0 && (wg) < 8192u) g_bin_trace[k][wg][slot] = (val); } while (0)
+#define BIN_NOW() wall_clock64()
+extern "C" size_t b3gs_debug_bin_trace(unsigned long long* host) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bin_trace), sizeof(g_bin_trace));
+  return sizeof(g_bin_trace) / 8;
+}
+#else
+#define BIN_TRACE(k, wg, slot, val) do { } while (0)
+#define BIN_NOW() 0ull
+#endif
+
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t tmp[8];
   __shared__ uint32_t ssub[2][4][SCAN_MAX_SUBS];
@@ -218,6 +247,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t s_list[SCAN_TILE];
   __shared__ uint32_t s_H;
   const ScanJob& job = sb.j[blockIdx.y];
+  const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
+  BIN_TRACE(0, twg, 0, BIN_NOW());
+  BIN_TRACE(0, twg, 5, 0ull);
   if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
   const bool pair = job.partner >= 0;
   const ScanJob& pj = pair ? sb.j[job.partner] : job;
@@ -241,6 +273,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
       pb2.rows = s_pred[1];
     }
   }
+  BIN_TRACE(0, twg, 1, BIN_NOW());
   const uint2* __restrict__ rect1 = job.rect;
   const uint4* __restrict__ rect2 = reinterpret_cast<const uint4*>(job.rect);   // pair: [P][2] rects, one 16-byte gather
   const size_t stride = (size_t)job.rect_stride;
@@ -262,7 +295,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
 #pragma unroll
         for (int k = 0; k < SCAN_BATCH; k++) {
           const int64_t i = tb + (int64_t)(r0 + k) * SCAN_THREADS + threadIdx.x;
-          oi[k] = i < te ? order[i] : 0u;
+          oi[k] = i < te ? (order[i] & ORDER_IDX) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < SCAN_BATCH; k++) {
@@ -298,15 +331,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
         const int64_t i = tb + (int64_t)r * SCAN_THREADS + threadIdx.x;
         uint32_t f = 0u;
         if (i < te) {
-          const uint32_t g = order[i];
-          f = (uint32_t)((job.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_A;
-          if (pair) f |= (uint32_t)((pj.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_B;
+          const uint32_t o = order[i];
+          if (job.order_flags) {   // the flags came with the order (own depth sort)
+            f = ((o >> 30) & 1u) * FL_A;
+            if (pair) f |= (o >> 31) * FL_B;
+          } else {                 // a borrowed order carries the donor's flags: look this view's up
+            const uint32_t g = o & ORDER_IDX;
+            f = (uint32_t)((job.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_A;
+            if (pair) f |= (uint32_t)((pj.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_B;
+          }
         }
         fl[r] = f;
         const u64 m = __ballot(f != 0u);
         if (lane == 0) { s_mask[r][w] = m; ssub[0][w][t * SCAN_ITEMS + r] = 0u; ssub[1][w][t * SCAN_ITEMS + r] = 0u; }
       }
       __syncthreads();
+      BIN_TRACE(0, twg, 2, BIN_NOW());
       if (threadIdx.x < 64u) {   // 16 x 4 cells in depth order (sub-block major, then wave): exclusive prefix of their counts
         const uint32_t c = (uint32_t)__popcll(s_mask[threadIdx.x >> 2][threadIdx.x & 3u]);
         const uint32_t inc = wave_incl_scan(c);
@@ -319,11 +359,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
         if (fl[r]) s_list[s_base[r][w] + (uint32_t)__popcll(s_mask[r][w] & lt)] = (uint32_t)(r * SCAN_THREADS + threadIdx.x) | fl[r];
       __syncthreads();
       const uint32_t Hn = s_H;
+      BIN_TRACE(0, twg, 3, BIN_NOW());
+      BIN_TRACE(0, twg, 7, (unsigned long long)Hn);
       uint32_t* __restrict__ flist = job.flist + tile * SCAN_TILE;
       for (uint32_t e = threadIdx.x; e < Hn; e += SCAN_THREADS) {
         const uint32_t ent = s_list[e];
         const int64_t i = tb + (int64_t)(ent & FL_IDX);
-        const uint32_t g = order[i];
+        const uint32_t g = order[i] & ORDER_IDX;
         uint2 ra, rb = make_uint2(0u, 0u);
         if (pair) { const uint4 q = rect2[g]; ra = make_uint2(q.x, q.y); rb = make_uint2(q.z, q.w); }
         else ra = rect1[g * stride];
@@ -338,6 +380,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
       }
       if (threadIdx.x == 0) job.fcount[tile] = Hn;
       __syncthreads();   // (s_mask / s_list are reused by the next tile of the chunk)
+      BIN_TRACE(0, twg, 4, BIN_NOW());
     }
     // the tile's instance totals (the emission of a later tile of the same chunk starts behind them)
     uint32_t tot_a, tot_b;
@@ -371,6 +414,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
       pj.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
           (ssub[1][0][threadIdx.x] + ssub[1][1][threadIdx.x]) + (ssub[1][2][threadIdx.x] + ssub[1][3][threadIdx.x]);
   }
+  BIN_TRACE(0, twg, 5, BIN_NOW());
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb) {
@@ -531,7 +575,7 @@ __device__ __forceinline__ void radix_scatter_body(const SortBatch& sb, int pass
     const bool valid = li < tile_n;
     const uint32_t gi = tile_base + li;
     key[r] = valid ? keys_in[gi] : 0xFFFFFFFFu;
-    val[r] = (HAS_VAL && valid && vals_out) ? (vals_in ? vals_in[gi] : gi) : 0u;
+    val[r] = (HAS_VAL && valid && vals_out) ? (vals_in ? vals_in[gi] : order_value(job, gi)) : 0u;
   }
 #pragma unroll
   for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
@@ -722,7 +766,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
     uint32_t kk = valid ? keys_in[gi] : 0xFFFFFFFFu;
     if (xform && valid) kk = key27(kk);
     key[r] = kk;
-    val[r] = valid ? (vals_in ? vals_in[gi] : gi) : 0u;
+    val[r] = valid ? (vals_in ? vals_in[gi] : order_value(job, gi)) : 0u;
   }
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
@@ -879,7 +923,7 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
       uint32_t pos = carry + block_excl_scan_256(cnt, s_tmp, &tot);
       carry += tot;
       if (cnt != 0u) {
-        const uint32_t gid = job.order[sidx];
+        const uint32_t gid = job.order[sidx] & ORDER_IDX;
         const uint2 rc = job.srect[sidx];
         const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
         for (uint32_t y = y0; y < y1; y++)
@@ -912,11 +956,11 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
   if (!ROUND2 && job.soffs[bx] == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
   if (s < P) {
     if (ROUND2) {
-      gid = job.order[s];
+      gid = job.order[s] & ORDER_IDX;
       rc = job.srect[s];
       end = job.soffs[s];
     } else {   // (a dense block of round 1 lies inside segment 1: K1 is a multiple of the 4096-Gaussian tile, or P)
-      gid = job.order[s];
+      gid = job.order[s] & ORDER_IDX;
       rc = job.srect[s];
       cnt = rect_area(rc);
     }
@@ -981,7 +1025,10 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
 template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ EmitShared sh;
+  const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (!ROUND2) { BIN_TRACE(1, twg, 0, BIN_NOW()); BIN_TRACE(1, twg, 7, (unsigned long long)((int)blockIdx.x >= eb.dense_blocks)); }
   emit_instances_body<ROUND2>(eb, blockIdx.x, blockIdx.y, sh);
+  if (!ROUND2) BIN_TRACE(1, twg, 5, BIN_NOW());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1029,7 +1076,7 @@ __device__ __forceinline__ void scan2_chunk_sums_body(const Scan2Batch& sb, uint
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int64_t i = i0 + (int64_t)k * SCAN_THREADS;
-      oi[k] = i < end ? order[i] : 0u;
+      oi[k] = i < end ? (order[i] & ORDER_IDX) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1355,11 +1402,18 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   for (int v = 0; v < nviews; v++) span27 = span27 && jobs[v].key_bits == 27;
   const int npass = span27 ? 3 : 4;
   const int first_dst = span27 ? 0 : 1;
+  const int K1 = b3gs_seg1_count(jobs[0], P);
   for (int v = 0; v < nviews; v++) {
     if (jobs[v].order_from != -1) continue;
     const GeomView& g = jobs[v].g;
-    db.j[db.n++] = SortJob{g.depth_key, nullptr, g.skey[first_dst], g.sval[first_dst], nullptr, (uint32_t)P, pblk, 0, g.hist,
-                           nullptr, nullptr};
+    SortJob& sj = db.j[db.n++];
+    sj = SortJob{g.depth_key, nullptr, g.skey[first_dst], g.sval[first_dst], nullptr, (uint32_t)P, pblk, 0, g.hist,
+                 nullptr, nullptr, {nullptr, nullptr}};
+    if (K1 < P) {   // two rounds: the predicted-tile flags of this view and of its scan partner travel with the order
+      const int pv = scan_partner_of(jobs, nviews, v);
+      sj.flag[0] = g.pflag;
+      sj.flag[1] = pv >= 0 ? jobs[pv].g.pflag : nullptr;
+    }
   }
   for (int pass = 0; pass < npass; pass++) {
     if (span27) radix9_pass(db, 9 * pass, pass == 0, s);
@@ -1378,7 +1432,6 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   }
 
   // ---- 2. scan of tiles_touched in depth order -> soffs, N, V (segment 1 = the first K1 Gaussians of the order)
-  const int K1 = b3gs_seg1_count(jobs[0], P);
   const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
   ScanBatch sc;
   sc.n = nviews;
@@ -1399,7 +1452,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
                       jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
                       open_map(jb.im.pred_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
                       (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0), jb.g.pflag,
-                      jb.g.flist, jb.g.fcount, jb.g.tsum};
+                      jb.g.flist, jb.g.fcount, jb.g.tsum, (K1 < P && jb.order_from == -1) ? 1 : 0};
   }
   // a view that borrows view d's depth order AND whose rects sit in the odd slots of d's [P][2] array is folded
   // into d's gather

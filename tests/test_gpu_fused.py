@@ -752,10 +752,14 @@ def test_depth_key_outside_the_27_bit_span_is_detected_and_falls_back():
     assert torch.equal(got, want) and not fr.check_overflow()
 
 
-@pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16)])
+@pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16), (4097, 40, 24),
+                                   (8192, 33, 17), (12289, 272, 16), (20000, 16, 16)])
 def test_two_round_binning_edge_sizes(P, W, H):
-    """Two-round binning at the edges: a single tile (no tile-sort pass: the ranges of segment 2 come from tile_ranges
-    with the device-side offset), K1 = 1, fewer Gaussians than a wave, ragged borders.  Bit-identical images to one round."""
+    """Two-round binning at the edges.  Segment 1 is a whole number of 4096-Gaussian tiles of the depth order, so fewer than
+    4097 Gaussians are always binned in one round (the first four sizes: the request must simply be honoured as one round);
+    above: ONE Gaussian behind segment 1, a last tile that is exactly full / holds one Gaussian, a single image tile (no
+    tile-sort pass: the ranges of segment 2 come from tile_ranges with the device-side offset), ragged borders.
+    Bit-identical images to one round."""
     from binocular3dgs_amd import synth
     from binocular3dgs_amd.fused import FusedRasterizer
     model = synth.synth_model(P, seed=P, device="cuda", width=W, height=H, requires_grad=False)
