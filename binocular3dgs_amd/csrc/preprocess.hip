@@ -30,7 +30,20 @@ struct Mat16 {
 __device__ __forceinline__ Mat16 load_mat(const float* __restrict__ p) {
   Mat16 r;
 #pragma unroll
-  for (int i = 0; i < 16; i++) r.m[i] = p[i];  // wave-uniform -> scalar loads
+  for (int i = 0; i < 16; i++) r.m[i] = p[i];
+  return r;
+}
+// The same for data that no kernel of the launch writes (camera matrices, camera position) at a wave-uniform address:
+// through the constant address space the loads become scalar (s_load_dwordx16: ONE round trip into SGPRs).  As plain
+// loads they are vector loads -- the compiler cannot prove that the kernel's own stores leave them alone -- in several
+// dependent groups per view of the projection's view loop, holding 35 VGPRs.
+typedef const float __attribute__((address_space(4))) cfloat_k;
+__device__ __forceinline__ cfloat_k* uniform_ptr(const float* p) { return (cfloat_k*)(uintptr_t)p; }
+__device__ __forceinline__ Mat16 load_mat_uniform(const float* p) {
+  cfloat_k* q = uniform_ptr(p);
+  Mat16 r;
+#pragma unroll
+  for (int i = 0; i < 16; i++) r.m[i] = q[i];
   return r;
 }
 
@@ -77,6 +90,15 @@ struct ShView {
   const float* dc;
   const float* rest;
   __device__ __forceinline__ float operator()(int k, int ch) const { return k == 0 ? dc[ch] : rest[3 * (k - 1) + ch]; }
+};
+// The same with rows 0..3 (degree <= 1) in this thread's column of an LDS table: the forward projects one Gaussian into
+// every view of the batch, and a load inside the view loop is one exposed L2 round trip per view (the compiler cannot hoist
+// it past the stores); held in registers across the loop the 12 values push the kernel past 96 VGPRs (measured: spills, or
+// one wave per SIMD less: no gain).  Measured on MI355X: 176-187 -> 167-171 us.
+struct ShLds {
+  const float* lo;     // &table[0][tid], row stride 256 floats
+  const float* rest;
+  __device__ __forceinline__ float operator()(int k, int ch) const { return k < 4 ? lo[(3 * k + ch) * 256] : rest[3 * (k - 1) + ch]; }
 };
 template <bool RAW>
 __device__ __forceinline__ ShView sh_view(const SceneX& sx_, int i) {
@@ -163,7 +185,8 @@ __device__ __forceinline__ int clampi_from_float(float v, int hi) {
 }
 
 // SH -> RGB for one channel; sh points at coefficient 0 of this Gaussian, stride 3 floats
-__device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, float x, float y, float z) {
+template <typename SHV>
+__device__ __forceinline__ float sh_eval(int deg, const SHV& sh, int ch, float x, float y, float z) {
 #define SH(k) sh(k, ch)
   float r = SH_C0 * SH(0);
   if (deg > 0) {
@@ -187,6 +210,17 @@ __device__ __forceinline__ float sh_eval(int deg, const ShView& sh, int ch, floa
   return r;
 }
 
+#ifdef B3GS_PRE_TRACE   // (tools/pre_trace.py: per-workgroup wall-clock stamps of the projection; never in the product build)
+__device__ unsigned long long g_pre_trace[8192][12];
+#define PRE_TRACE(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 8192u) g_pre_trace[blockIdx.x][slot] = (val); } while (0)
+extern "C" size_t b3gs_debug_pre_trace(unsigned long long* host) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pre_trace), sizeof(g_pre_trace));
+  return sizeof(g_pre_trace) / 8;
+}
+#else
+#define PRE_TRACE(slot, val) do { } while (0)
+#endif
 constexpr int PRE_PRED_WORDS = 128;   // LDS copy of one view's predicted-open bitmap (8 KB for 8 views)
 template <bool RAW>
 #ifndef B3GS_PRE_WAVES
@@ -194,6 +228,9 @@ template <bool RAW>
 #endif
 __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(PreBatch pb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  PRE_TRACE(0, wall_clock64());
+  PRE_TRACE(10, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_ID
+  PRE_TRACE(11, (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));   // XCC_ID
   for (int v = 0; v < pb.n; v++)
     if (i < pb.out[v].ntiles) {   // empty = (max, 0): the tile sort's last pass min/maxes into it
       pb.out[v].ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
@@ -204,12 +241,33 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   // two-round forward: the bitmaps of the tiles predicted open (304 bytes per view at 800x600) are read once per
   // Gaussian and view below -- staged in LDS when they fit
   __shared__ unsigned long long s_pred[B3GS_MAX_FUSED_VIEWS][PRE_PRED_WORDS];
+  // ... and, when a tile row is one word (<= 64 x 64 tiles), which rows / columns hold a predicted tile at all: most
+  // Gaussians miss both masks and never walk the rows of their rect
+  __shared__ unsigned long long s_any[B3GS_MAX_FUSED_VIEWS][2];
   if (pb.out[0].pred_rows) {
-    for (int v = 0; v < pb.n; v++)
-      if (pb.out[v].nrowwords <= PRE_PRED_WORDS && (int)threadIdx.x < pb.out[v].nrowwords)
-        s_pred[v][threadIdx.x] = pb.out[v].pred_rows[threadIdx.x];
+    for (int v = 0; v < pb.n; v++) {
+      const int nw = pb.out[v].nrowwords;
+      unsigned long long wd = 0ull;
+      if (nw <= PRE_PRED_WORDS && (int)threadIdx.x < nw) {
+        wd = pb.out[v].pred_rows[threadIdx.x];
+        s_pred[v][threadIdx.x] = wd;
+      }
+      if (threadIdx.x < 64u) {
+        const int gx = (pb.sc[v].W + B3GS_TILE - 1) / B3GS_TILE, gy = (pb.sc[v].H + B3GS_TILE - 1) / B3GS_TILE;
+        unsigned long long rows = ~0ull, cols = ~0ull;
+        if (gx <= 64 && gy <= 64 && nw == gy) {   // word y = row y
+          rows = __ballot(wd != 0ull);
+          uint32_t lo = (uint32_t)wd, hi = (uint32_t)(wd >> 32);
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) { lo |= (uint32_t)__shfl_xor((int)lo, d, 64); hi |= (uint32_t)__shfl_xor((int)hi, d, 64); }
+          cols = ((unsigned long long)hi << 32) | lo;
+        }
+        if (threadIdx.x == 0) { s_any[v][0] = rows; s_any[v][1] = cols; }
+      }
+    }
     __syncthreads();
   }
+  __shared__ float s_sh[12][256];
   if (i >= pb.sc[0].P) return;
   // view-independent part, once per Gaussian: position, 3D covariance (all views of a batch share the
   // scale modifier), activated opacity
@@ -223,15 +281,29 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   float c6[6];
   cov3d_of<RAW>(sx_, i, c6);
   const float op = load_opacity<RAW>(sx_, i);
-  const ShView sh = sh_view<RAW>(sx_, i);
+  const ShView shm = sh_view<RAW>(sx_, i);
+  ShLds sh;
+  sh.rest = shm.rest;
+  sh.lo = &s_sh[0][threadIdx.x];
+  if (RAW || !sx_.sc.colors_precomp) {
+    s_sh[0][threadIdx.x] = shm.dc[0]; s_sh[1][threadIdx.x] = shm.dc[1]; s_sh[2][threadIdx.x] = shm.dc[2];
+    if (sx_.sc.M >= 4) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) s_sh[3 + k][threadIdx.x] = shm.rest[k];
+    }
+  }
 
   uint2 held_rect = make_uint2(0u, 0u);
+  PRE_TRACE(1, wall_clock64());
 #pragma unroll 1
   for (int v = 0; v < pb.n; v++) {
+  PRE_TRACE(2 + v, wall_clock64());
   const B3gsScene& sc = pb.sc[v];
   const PreOut& g = pb.out[v];
-  const Mat16 vm = load_mat(sc.viewmatrix);
-  const Mat16 pm = load_mat(sc.projmatrix);
+  const Mat16 vm = load_mat_uniform(sc.viewmatrix);
+  const Mat16 pm = load_mat_uniform(sc.projmatrix);
+  cfloat_k* cp = uniform_ptr(sc.campos);
+  const float campos[3] = {cp[0], cp[1], cp[2]};
 
   int32_t radius_out = 0;
   uint32_t touched = 0, dkey = 0xFFFFFFFFu, clamp_bits = 0;
@@ -278,7 +350,7 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
           rgb[1] = sc.colors_precomp[3 * (size_t)i + 1];
           rgb[2] = sc.colors_precomp[3 * (size_t)i + 2];
         } else {
-          float dx = px3 - sc.campos[0], dy = py3 - sc.campos[1], dz = pz3 - sc.campos[2];
+          float dx = px3 - campos[0], dy = py3 - campos[1], dz = pz3 - campos[2];
           float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
           dx = dx * inv; dy = dy * inv; dz = dz * inv;
 #pragma unroll
@@ -333,8 +405,16 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   if (g.pred_rows) {
     // two-round forward: does this Gaussian reach a tile that is predicted open?  One bit per Gaussian (a wave's 64
     // consecutive Gaussians = one word): behind segment 1 the scan gathers a rect only where the bit is set
-    const bool hit = touched != 0u &&
-                     open_tiles(rect, open_map(g.nrowwords <= PRE_PRED_WORDS ? s_pred[v] : g.pred_rows, sc.W, sc.H)) != 0u;
+    bool hit = false;
+    if (touched != 0u) {
+      const uint32_t rx0 = rect.x & 0xFFFFu, ry0 = rect.x >> 16, rx1 = rect.y & 0xFFFFu, ry1 = rect.y >> 16;
+      // rows / columns of the rect as bit masks (exact when the grid fits 64 x 64; otherwise the "any" masks are all ones)
+      const unsigned long long rm = (ry1 - ry0 >= 64u ? ~0ull : ((1ull << (ry1 - ry0)) - 1ull)) << (ry0 & 63u);
+      const unsigned long long cm = (rx1 - rx0 >= 64u ? ~0ull : ((1ull << (rx1 - rx0)) - 1ull)) << (rx0 & 63u);
+      const bool exact = s_any[v][0] != ~0ull || s_any[v][1] != ~0ull;
+      if (!exact || ((s_any[v][0] & rm) != 0ull && (s_any[v][1] & cm) != 0ull))
+        hit = open_tiles(rect, open_map(g.nrowwords <= PRE_PRED_WORDS ? s_pred[v] : g.pred_rows, sc.W, sc.H)) != 0u;
+    }
     const unsigned long long word = __ballot(hit);
     if ((threadIdx.x & 63u) == 0u) g.pflag[(size_t)i >> 6] = word;
   }
@@ -343,6 +423,7 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   else g.rect[(size_t)i * g.rect_stride] = rect;
   g.clamped[i] = clamp_bits;
   }
+  PRE_TRACE(9, wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------
