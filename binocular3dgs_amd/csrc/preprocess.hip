@@ -565,7 +565,8 @@ __device__ __forceinline__ void gaussian_backward(const SceneX& sx_, const Mat16
   // colour: SH coefficients and view direction
   if (do_sh) {
     const ShView sh = sh_view<RAW>(sx_, i);
-    float ddx = mx3 - sc.campos[0], ddy = my3 - sc.campos[1], ddz = mz3 - sc.campos[2];
+    cfloat_k* cp = uniform_ptr(sc.campos);   // (wave-uniform, read-only: scalar loads)
+    float ddx = mx3 - cp[0], ddy = my3 - cp[1], ddz = mz3 - cp[2];
     float inv = 1.0f / sqrtf((ddx * ddx + ddy * ddy) + ddz * ddz);
     const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
     float gdir[3] = {0.f, 0.f, 0.f};
@@ -702,8 +703,8 @@ __global__ void __launch_bounds__(256)
     if (dL_drots) reinterpret_cast<float4*>(dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  const Mat16 vm = load_mat(sc.viewmatrix);
-  const Mat16 pm = load_mat(sc.projmatrix);
+  const Mat16 vm = load_mat_uniform(sc.viewmatrix);
+  const Mat16 pm = load_mat_uniform(sc.projmatrix);
 
   PixSums in;
   if (RAW) {
@@ -782,7 +783,7 @@ struct MultiViews {
 };
 
 #ifndef B3GS_ACC_WAVES
-#define B3GS_ACC_WAVES 3   /* 168 VGPRs (40 B spilled) beats 182 VGPRs at 2 waves per SIMD: 0.060 -> 0.053 ms per view */
+#define B3GS_ACC_WAVES 3   /* 145 VGPRs, no spills (camera matrices in SGPRs); 4 waves = 128 VGPRs + 76 B of spills: 62.4 vs 59.7 us */
 #endif
 // Most visible Gaussians of a view lie behind the saturation point of every pixel they cover: only ~8 % of the
 // (Gaussian, view) rows receive anything from the blend backward, ~20 % of the Gaussians have at least one such view.
@@ -918,8 +919,8 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
       sx_.sc.W = vr.W; sx_.sc.H = vr.H;
       sx_.sc.tan_fovx = vr.tan_fovx; sx_.sc.tan_fovy = vr.tan_fovy;
       sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
-      const Mat16 vm = load_mat(vr.viewmatrix);
-      const Mat16 pm = load_mat(vr.projmatrix);
+      const Mat16 vm = load_mat_uniform(vr.viewmatrix);
+      const Mat16 pm = load_mat_uniform(vr.projmatrix);
       const PixSums in = load_scratch_row(vr.scratch, i);   // read the sums, leave the row zero for the next iteration
       GaussGrad gg;
       gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
