@@ -783,7 +783,7 @@ struct MultiViews {
 };
 
 #ifndef B3GS_ACC_WAVES
-#define B3GS_ACC_WAVES 3   /* 145 VGPRs, no spills (camera matrices in SGPRs); 4 waves = 128 VGPRs + 76 B of spills: 62.4 vs 59.7 us */
+#define B3GS_ACC_WAVES 3   /* the pair-chunk kernel below needs 128 VGPRs (no spills): the hardware runs it at 4 waves per SIMD */
 #endif
 // Most visible Gaussians of a view lie behind the saturation point of every pixel they cover: only ~8 % of the
 // (Gaussian, view) rows receive anything from the blend backward, ~20 % of the Gaussians have at least one such view.
@@ -885,80 +885,157 @@ __global__ void __launch_bounds__(256, 8)
   if (threadIdx.x == 0) g_count[blockIdx.x] = n_list;
 }
 
+// SH sink of the chain-rule kernel below: coefficients 0..REG-1 of ONE (Gaussian, view) pair in registers (they are added
+// to the Gaussian's LDS row afterwards); higher ones go to memory with an atomic add (several lanes may serve one Gaussian)
+template <int REG>
+struct ShPairReg {
+  float acc[3 * REG];
+  float* rest;
+  __device__ __forceinline__ void put(int k, int ch, float v) {
+    if (k < REG) acc[3 * k + ch] += v;   // k, ch are compile-time constants at every call site
+    else unsafeAtomicAdd(rest + 3 * (k - 1) + ch, v);
+  }
+};
+
+// Phase 2: the chain rule of the touched (Gaussian, view) pairs.  A touched Gaussian has a gradient in 2.4 of the 6
+// views on average; with lane = Gaussian and the view loop around it every wave ran all 6 view iterations with 40 % of its
+// lanes (measured 60 us, latency-bound at 3 waves per SIMD).  Now, per group of 256 list entries: the entries of every
+// view are compacted (ballots) into dense position lists, cut into chunks of <= 64 positions of ONE view, and the chunks
+// are dealt to the four waves: a wave runs ~3 dense chunks instead of 6 sparse view iterations, the view of a chunk is
+// wave-uniform (matrices through scalar loads).  The 23 gradients of a pair are added to the Gaussian's row of an LDS
+// table (ds_add_f32: the pairs of one Gaussian sit in different chunks); the entry's own thread then finishes the row
+// (sigmoid chain of the opacity) and stores it.
+constexpr int CH_GROUP = 256;
+constexpr int CH_ROW = 25;      // 23 gradients per Gaussian, odd row stride: conflict-free column access
 __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
     accumulate_chain_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
                             const uint32_t* __restrict__ g_list, const uint32_t* __restrict__ g_count) {
+  __shared__ float s_acc[CH_GROUP][CH_ROW];
+  __shared__ uint8_t s_idx[B3GS_MAX_FUSED_VIEWS][CH_GROUP];   // (view, position) -> entry of the group
+  __shared__ uint32_t s_wcnt[B3GS_MAX_FUSED_VIEWS][4];
+  __shared__ uint32_t s_chunk[B3GS_MAX_FUSED_VIEWS * 4];      // view | first position << 8 | positions << 20
+  __shared__ uint32_t s_nchunk;
   const int blk_first = first + (int)blockIdx.x * ACC_BLOCK;
   const int nrest = 3 * (base.M - 1);
   const uint32_t* __restrict__ s_list = g_list + (size_t)blockIdx.x * ACC_BLOCK;
-  // ---- phase 2 ------------------------------------------------------------------------------------------
   const uint32_t n_list = g_count[blockIdx.x];
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   SceneX sx_;
   sx_.sc = base;
   sx_.raw = raw;
   sx_.raw_mode = 1;
   sx_.tight = 0;
 #pragma unroll 1
-  for (uint32_t e = threadIdx.x; e < n_list; e += 256) {
-    const uint32_t ent = s_list[e];
-    const int i = blk_first + (int)(ent & 0xFFFFu);
+  for (uint32_t e0 = 0; e0 < n_list; e0 += CH_GROUP) {
+    const uint32_t e = e0 + threadIdx.x;
+    const uint32_t ent = e < n_list ? s_list[e] : 0u;
     const uint32_t mask = ent >> 16;
+    const int i = blk_first + (int)(ent & 0xFFFFu);
     const size_t i3 = 3 * (size_t)i;
-    float dxyz[3] = {0.f, 0.f, 0.f}, dscaling[3] = {0.f, 0.f, 0.f}, dop = 0.f;
-    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
-    ShAddReg<4> sink;
 #pragma unroll
-    for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
-    sink.dc = rg.features_dc + i3;
-    sink.rest = rg.features_rest + (size_t)nrest * i;
-    if (overwrite && base.M > 4)  // coefficients beyond the register window accumulate in memory
-      for (int k = 9; k < nrest; k++) sink.rest[k] = 0.f;
-    for (int v = 0; v < mv.n; v++) {
-      if (!((mask >> v) & 1u)) continue;
+    for (int k = 0; k < 23; k++) s_acc[threadIdx.x][k] = 0.f;
+    if (mask != 0u && overwrite && base.M > 4) {   // coefficients beyond the register window accumulate in memory
+      float* rest = rg.features_rest + (size_t)nrest * i;
+      for (int k = 9; k < nrest; k++) rest[k] = 0.f;
+    }
+    // ---- positions of this group's entries inside every view's list
+    uint32_t rank[B3GS_MAX_FUSED_VIEWS];
+#pragma unroll
+    for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++) {
+      rank[v] = 0;
+      if (v < mv.n) {
+        const unsigned long long b = __ballot((mask >> v) & 1u);
+        rank[v] = (uint32_t)__builtin_popcountll(b & lt);
+        if (lane == 0) s_wcnt[v][w] = (uint32_t)__builtin_popcountll(b);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++)
+      if (v < mv.n && ((mask >> v) & 1u)) {
+        uint32_t base_w = 0;
+        for (unsigned k = 0; k < w; k++) base_w += s_wcnt[v][k];
+        s_idx[v][base_w + rank[v]] = (uint8_t)threadIdx.x;
+      }
+    if (threadIdx.x == 0) {   // chunks of <= 64 positions of one view
+      uint32_t nc = 0;
+      for (int v = 0; v < mv.n; v++) {
+        const uint32_t tot = (s_wcnt[v][0] + s_wcnt[v][1]) + (s_wcnt[v][2] + s_wcnt[v][3]);
+        for (uint32_t p0 = 0; p0 < tot; p0 += 64u) s_chunk[nc++] = (uint32_t)v | (p0 << 8) | (min(64u, tot - p0) << 20);
+      }
+      s_nchunk = nc;
+    }
+    __syncthreads();
+    // ---- the pairs, chunk by chunk
+    const uint32_t nchunk = s_nchunk;
+#pragma unroll 1
+    for (uint32_t c = w; c < nchunk; c += 4u) {
+      const uint32_t cd = __builtin_amdgcn_readfirstlane(s_chunk[c]);
+      const int v = (int)(cd & 0xFFu);
+      const uint32_t p0 = (cd >> 8) & 0xFFFu, np = cd >> 20;
+      if (lane >= np) continue;
+      const uint32_t t2 = s_idx[v][p0 + lane];
+      const int i2 = blk_first + (int)(s_list[e0 + t2] & 0xFFFFu);
       const B3gsViewRef& vr = mv.v[v];
       sx_.sc.W = vr.W; sx_.sc.H = vr.H;
       sx_.sc.tan_fovx = vr.tan_fovx; sx_.sc.tan_fovy = vr.tan_fovy;
       sx_.sc.viewmatrix = vr.viewmatrix; sx_.sc.projmatrix = vr.projmatrix; sx_.sc.campos = vr.campos;
       const Mat16 vm = load_mat_uniform(vr.viewmatrix);
       const Mat16 pm = load_mat_uniform(vr.projmatrix);
-      const PixSums in = load_scratch_row(vr.scratch, i);   // read the sums, leave the row zero for the next iteration
+      const PixSums in = load_scratch_row(vr.scratch, i2);   // read the sums, leave the row zero for the next iteration
+      ShPairReg<4> sink;
+#pragma unroll
+      for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
+      sink.rest = rg.features_rest + (size_t)nrest * i2;
       GaussGrad gg;
-      gaussian_backward<true>(sx_, vm, pm, i, vr.clamped[i], in, true, true, gg, sink);
-      dxyz[0] += gg.dmean[0]; dxyz[1] += gg.dmean[1]; dxyz[2] += gg.dmean[2];
+      gaussian_backward<true>(sx_, vm, pm, i2, vr.clamped[i2], in, true, true, gg, sink);
       float dsc[3];
       float4 dr;
       raw_chain(gg, dsc, dr);
-      dscaling[0] += dsc[0]; dscaling[1] += dsc[1]; dscaling[2] += dsc[2];
-      drot.x += dr.x; drot.y += dr.y; drot.z += dr.z; drot.w += dr.w;
-      dop += in.gop;
+      float* row = s_acc[t2];
+      atomicAdd(row + 0, gg.dmean[0]); atomicAdd(row + 1, gg.dmean[1]); atomicAdd(row + 2, gg.dmean[2]);
+      atomicAdd(row + 3, dsc[0]); atomicAdd(row + 4, dsc[1]); atomicAdd(row + 5, dsc[2]);
+      atomicAdd(row + 6, dr.x); atomicAdd(row + 7, dr.y); atomicAdd(row + 8, dr.z); atomicAdd(row + 9, dr.w);
+      atomicAdd(row + 10, in.gop);
+#pragma unroll
+      for (int k = 0; k < 12; k++) atomicAdd(row + 11 + k, sink.acc[k]);
     }
-    const float op = load_opacity<true>(sx_, i);
-    dop = dop * op * (1.0f - op);
-    const int nreg = base.M < 4 ? base.M : 4;
-    float4* rot_dst = reinterpret_cast<float4*>(rg.rotation) + i;
-    if (overwrite) {
-      rg.xyz[i3] = dxyz[0]; rg.xyz[i3 + 1] = dxyz[1]; rg.xyz[i3 + 2] = dxyz[2];
-      rg.scaling[i3] = dscaling[0]; rg.scaling[i3 + 1] = dscaling[1]; rg.scaling[i3 + 2] = dscaling[2];
-      *rot_dst = drot;
-      rg.opacity[i] = dop;
+    __syncthreads();
+    // ---- every entry's own thread finishes and stores its row
+    if (mask != 0u) {
+      const float* row = s_acc[threadIdx.x];
+      const float op = load_opacity<true>(sx_, i);
+      const float dop = row[10] * op * (1.0f - op);
+      const int nreg = base.M < 4 ? base.M : 4;
+      float4* rot_dst = reinterpret_cast<float4*>(rg.rotation) + i;
+      float* dc = rg.features_dc + i3;
+      float* rest = rg.features_rest + (size_t)nrest * i;
+      if (overwrite) {
+        rg.xyz[i3] = row[0]; rg.xyz[i3 + 1] = row[1]; rg.xyz[i3 + 2] = row[2];
+        rg.scaling[i3] = row[3]; rg.scaling[i3 + 1] = row[4]; rg.scaling[i3 + 2] = row[5];
+        *rot_dst = make_float4(row[6], row[7], row[8], row[9]);
+        rg.opacity[i] = dop;
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) sink.dc[ch] = sink.acc[ch];
+        for (int ch = 0; ch < 3; ch++) dc[ch] = row[11 + ch];
 #pragma unroll
-      for (int k = 1; k < 4; k++)
-        if (k < nreg) { sink.rest[3 * (k - 1)] = sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] = sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] = sink.acc[3 * k + 2]; }
-    } else {
-      rg.xyz[i3] += dxyz[0]; rg.xyz[i3 + 1] += dxyz[1]; rg.xyz[i3 + 2] += dxyz[2];
-      rg.scaling[i3] += dscaling[0]; rg.scaling[i3 + 1] += dscaling[1]; rg.scaling[i3 + 2] += dscaling[2];
-      float4 cur = *rot_dst;
-      cur.x += drot.x; cur.y += drot.y; cur.z += drot.z; cur.w += drot.w;
-      *rot_dst = cur;
-      rg.opacity[i] += dop;
+        for (int k = 1; k < 4; k++)
+          if (k < nreg) { rest[3 * (k - 1)] = row[11 + 3 * k]; rest[3 * (k - 1) + 1] = row[12 + 3 * k]; rest[3 * (k - 1) + 2] = row[13 + 3 * k]; }
+      } else {
+        rg.xyz[i3] += row[0]; rg.xyz[i3 + 1] += row[1]; rg.xyz[i3 + 2] += row[2];
+        rg.scaling[i3] += row[3]; rg.scaling[i3 + 1] += row[4]; rg.scaling[i3 + 2] += row[5];
+        float4 cur = *rot_dst;
+        cur.x += row[6]; cur.y += row[7]; cur.z += row[8]; cur.w += row[9];
+        *rot_dst = cur;
+        rg.opacity[i] += dop;
 #pragma unroll
-      for (int ch = 0; ch < 3; ch++) sink.dc[ch] += sink.acc[ch];
+        for (int ch = 0; ch < 3; ch++) dc[ch] += row[11 + ch];
 #pragma unroll
-      for (int k = 1; k < 4; k++)
-        if (k < nreg) { sink.rest[3 * (k - 1)] += sink.acc[3 * k]; sink.rest[3 * (k - 1) + 1] += sink.acc[3 * k + 1]; sink.rest[3 * (k - 1) + 2] += sink.acc[3 * k + 2]; }
+        for (int k = 1; k < 4; k++)
+          if (k < nreg) { rest[3 * (k - 1)] += row[11 + 3 * k]; rest[3 * (k - 1) + 1] += row[12 + 3 * k]; rest[3 * (k - 1) + 2] += row[13 + 3 * k]; }
+      }
     }
+    // (the next group's zero fill of row t is thread t's own; its chunks start behind the barriers above)
   }
 }
 
