@@ -33,6 +33,15 @@ typedef unsigned long long u64;
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
+// clear bit j of a wave-uniform 64-bit mask: one scalar instruction (the compiler's  m & (m - 1)  is three, and the
+// blend loops are co-limited by the scalar unit)
+__device__ __forceinline__ void clear_bit(u64& m, int j) {
+#ifdef B3GS_NO_BITSET0
+  m &= ~(1ull << j);
+#else
+  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(j));
+#endif
+}
 __device__ __forceinline__ u64 uniform_u64(u64 v) {
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -247,7 +256,7 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
       } while (0)
       while (m) {
         const int j = __builtin_ctzll(m);
-        m &= m - 1;
+        clear_bit(m, j);
         B3GS_FWD_CANDIDATE(j);
         // "is any pixel of the quadrant still active" only after every B3GS_FWD_CHECK_EVERY-th candidate: a candidate
         // evaluated after the last pixel finished blends weight zero everywhere, and the check is a third of the loop's
@@ -256,7 +265,7 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
         for (int rep = 1; rep < B3GS_FWD_CHECK_EVERY; rep++) {
           if (m == 0) break;
           const int j2 = __builtin_ctzll(m);
-          m &= m - 1;
+          clear_bit(m, j2);
           B3GS_FWD_CANDIDATE(j2);
         }
         if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
@@ -631,19 +640,19 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
       const float4* const sC = sh.f.C + pw * 64;
 #if B3GS_BWD_PREFETCH
       int j = 63 - __builtin_clzll(m);
-      m &= ~(1ull << j);
+      clear_bit(m, j);
       float4 A0 = sA[j], B0 = sB[j], C0 = sC[j], A1, B1, C1;
       while (true) {
         bool more = m != 0;
         int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
-        m &= ~(1ull << jn);
+        clear_bit(m, jn);
         A1 = sA[jn]; B1 = sB[jn]; C1 = sC[jn];
         B3GS_BWD_CANDIDATE(A0, B0, C0, j);
         if (!more) break;
         j = jn;
         more = m != 0;
         jn = more ? 63 - __builtin_clzll(m) : j;
-        m &= ~(1ull << jn);
+        clear_bit(m, jn);
         A0 = sA[jn]; B0 = sB[jn]; C0 = sC[jn];
         B3GS_BWD_CANDIDATE(A1, B1, C1, j);
         if (!more) break;
@@ -652,7 +661,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
 #else
       while (m) {
         const int j = 63 - __builtin_clzll(m);
-        m &= ~(1ull << j);
+        clear_bit(m, j);
         const float4 A0 = sA[j], B0 = sB[j], C0 = sC[j];
         B3GS_BWD_CANDIDATE(A0, B0, C0, j);
       }
