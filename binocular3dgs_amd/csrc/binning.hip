@@ -21,6 +21,7 @@
 // All kernels read the element count from device memory (N is produced on the device), so the
 // same launches serve the sync-free forward; grids are sized from a host-side bound.
 #include "b3gs_internal.h"
+#include <utility>
 #include <cstdlib>
 
 namespace {
@@ -86,11 +87,30 @@ struct SortJob {
 // the order itself instead of gathering GeomView::pflag at a random index per lane (measured: that gather -- 6M separate L2
 // requests per iteration -- was 25 of the scan's 67 us).
 constexpr uint32_t ORDER_IDX = 0x3FFFFFFFu, ORDER_A = 1u << 30, ORDER_B = 1u << 31;
-__device__ __forceinline__ uint32_t order_value(const SortJob& job, uint32_t gi) {
-  uint32_t v = gi;
-  if (job.flag[0]) v |= (uint32_t)((job.flag[0][gi >> 6] >> (gi & 63u)) & 1ull) << 30;
-  if (job.flag[1]) v |= (uint32_t)((job.flag[1][gi >> 6] >> (gi & 63u)) & 1ull) << 31;
-  return v;
+// The flag words of the 64-element rows one wave ranks (row r = elements [first + 64 r, first + 64 r + 64), first % 64 == 0):
+// lane r holds the words of row r -- one coalesced load per flag array and wave; a per-element lookup was two more
+// (wave-uniform) vector loads per key and cost the first depth-sort pass 9 us.
+struct WaveFlags {
+  unsigned long long a, b;
+};
+__device__ __forceinline__ WaveFlags load_wave_flags(const SortJob& job, uint32_t first, int rows, uint32_t n, unsigned lane) {
+  WaveFlags f{0ull, 0ull};
+  if (job.flag[0] && (int)lane < rows) {
+    const size_t wi = (size_t)(first >> 6) + lane;
+    if (wi * 64u < n) {
+      f.a = job.flag[0][wi];
+      if (job.flag[1]) f.b = job.flag[1][wi];
+    }
+  }
+  return f;
+}
+template <int R>
+__device__ __forceinline__ uint32_t order_value(const WaveFlags& f, unsigned lane, uint32_t gi) {
+  const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f.a, R), ahi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f.a >> 32), R);
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)f.b, R), bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(f.b >> 32), R);
+  const uint32_t sh = lane & 31u;
+  const uint32_t wa = lane < 32u ? alo : ahi, wb = lane < 32u ? blo : bhi;
+  return gi | (((wa >> sh) & 1u) * ORDER_A) | (((wb >> sh) & 1u) * ORDER_B);
 }
 struct SortBatch {
   int32_t n;
@@ -186,6 +206,24 @@ __device__ __forceinline__ uint32_t kth_open_tile(uint2 rc, uint32_t k, const Op
       k -= c;
     }
   return y0 * om.grid_x + x0;   // not reached
+}
+
+// keys (and values) of the rows a wave ranks: wave w owns the slab [w ITEMS 64, (w + 1) ITEMS 64) of the tile, row r = 64
+// consecutive elements.  A pass without input values creates them: element index | the flags of SortJob::flag.
+template <bool HAS_VAL, int... R>
+__device__ __forceinline__ void sort_load_rows(std::integer_sequence<int, R...>, uint32_t (&key)[sizeof...(R)],
+                                               uint32_t (&val)[sizeof...(R)], const uint32_t* __restrict__ keys_in,
+                                               const uint32_t* __restrict__ vals_in, bool want_val, const WaveFlags& wf,
+                                               uint32_t tile_base, uint32_t tile_n, unsigned w, unsigned lane) {
+  constexpr int ITEMS = (int)sizeof...(R);
+  ((void)([&] {
+     const uint32_t li = w * (ITEMS * 64) + R * 64 + lane;
+     const bool valid = li < tile_n;
+     const uint32_t gi = tile_base + li;
+     key[R] = valid ? keys_in[gi] : 0xFFFFFFFFu;
+     val[R] = (HAS_VAL && valid && want_val) ? (vals_in ? vals_in[gi] : order_value<R>(wf, lane, gi)) : 0u;
+   }()),
+   ...);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,8 +371,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
         if (i < te) {
           const uint32_t o = order[i];
           if (job.order_flags) {   // the flags came with the order (own depth sort)
-            f = ((o >> 30) & 1u) * FL_A;
-            if (pair) f |= (o >> 31) * FL_B;
+            f = (o & ORDER_A) ? FL_A : 0u;
+            if (pair && (o & ORDER_B)) f |= FL_B;
           } else {                 // a borrowed order carries the donor's flags: look this view's up
             const uint32_t g = o & ORDER_IDX;
             f = (uint32_t)((job.pflag[g >> 6] >> (g & 63u)) & 1ull) * FL_A;
@@ -569,14 +607,10 @@ __device__ __forceinline__ void radix_scatter_body(const SortBatch& sb, int pass
 
   // wave w owns the contiguous slab [w*1024, (w+1)*1024) of the tile, 16 rounds of 64
   uint32_t key[B3GS_SORT_ITEMS], val[B3GS_SORT_ITEMS], rank[B3GS_SORT_ITEMS];
-#pragma unroll
-  for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
-    const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
-    const bool valid = li < tile_n;
-    const uint32_t gi = tile_base + li;
-    key[r] = valid ? keys_in[gi] : 0xFFFFFFFFu;
-    val[r] = (HAS_VAL && valid && vals_out) ? (vals_in ? vals_in[gi] : order_value(job, gi)) : 0u;
-  }
+  WaveFlags wf{0ull, 0ull};
+  if (HAS_VAL && vals_out && !vals_in) wf = load_wave_flags(job, tile_base + w * (B3GS_SORT_ITEMS * 64), B3GS_SORT_ITEMS, n, lane);
+  sort_load_rows<HAS_VAL>(std::make_integer_sequence<int, B3GS_SORT_ITEMS>{}, key, val, keys_in, vals_in, vals_out != nullptr, wf,
+                          tile_base, tile_n, w, lane);
 #pragma unroll
   for (int r = 0; r < B3GS_SORT_ITEMS; r++) {
     const uint32_t li = w * (B3GS_SORT_ITEMS * 64) + r * 64 + lane;
@@ -758,15 +792,13 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
   for (int k = 0; k < 4; k++) { wave_cnt[k][threadIdx.x] = 0; wave_cnt[k][threadIdx.x + 256] = 0; }
   __syncthreads();
   uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+  WaveFlags wf{0ull, 0ull};
+  if (!vals_in) wf = load_wave_flags(job, tile_base + w * (ITEMS * 64), ITEMS, n, lane);
+  sort_load_rows<true>(std::make_integer_sequence<int, ITEMS>{}, key, val, keys_in, vals_in, true, wf, tile_base, tile_n, w, lane);
+  if (xform) {
 #pragma unroll
-  for (int r = 0; r < ITEMS; r++) {
-    const uint32_t li = w * (ITEMS * 64) + r * 64 + lane;
-    const bool valid = li < tile_n;
-    const uint32_t gi = tile_base + li;
-    uint32_t kk = valid ? keys_in[gi] : 0xFFFFFFFFu;
-    if (xform && valid) kk = key27(kk);
-    key[r] = kk;
-    val[r] = valid ? (vals_in ? vals_in[gi] : order_value(job, gi)) : 0u;
+    for (int r = 0; r < ITEMS; r++)
+      if (w * (ITEMS * 64) + r * 64 + lane < tile_n) key[r] = key27(key[r]);
   }
 #pragma unroll
   for (int r = 0; r < ITEMS; r++) {
