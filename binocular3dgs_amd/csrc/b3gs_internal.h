@@ -34,7 +34,7 @@ struct GeomView {       // sized by P
   uint2* srect;         // [P]   rect in depth order
   uint32_t* scount;     // [P]   segment 2: tiles of the rect that were not finished after segment 1, in depth order
   uint32_t* hist;       // radix histogram scratch, 256 * nblk(P)
-  uint32_t* scan_tmp;   // [4096] block sums for scans
+  uint32_t* scan_tmp;   // [2048] chunk offsets of the scan | [2048][4] partial sums | [2048][4] partial visible counts
   float* bwd_rows;      // [P * B3GS_SCRATCH_ROW] drop-in backward: per-Gaussian sums of the blend backward (one row each)
   unsigned long long* pflag;  // [ceil(P / 64)] two-round forward: bit i set = the tile rect of Gaussian i reaches a tile that
                         //       is predicted open (written by the projection: the scan gathers the rects of the Gaussians
@@ -126,7 +126,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.srect = b3gs_carve<uint2>(cur, p);
   t.scount = b3gs_carve<uint32_t>(cur, p);
   t.hist = b3gs_carve<uint32_t>(cur, b3gs_sort_scratch_words((int64_t)p));
-  t.scan_tmp = b3gs_carve<uint32_t>(cur, 4096);
+  t.scan_tmp = b3gs_carve<uint32_t>(cur, 2048 + 2 * 4 * 2048);
   t.bwd_rows = b3gs_carve<float>(cur, p * B3GS_SCRATCH_ROW);
   t.pflag = b3gs_carve<unsigned long long>(cur, (p + 63) / 64);
   t.flist = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096 * 4096);

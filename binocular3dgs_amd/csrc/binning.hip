@@ -125,8 +125,9 @@ struct ScanJob {
                             //       order: this job's workgroups gather both with ONE 16-byte load; -2: done by its partner
   uint2* srect;             // the same in depth order (written by the first scan launch: ONE gather per view)
   uint32_t* soffs;          // segment 1: [ceil(K1 / 256)] sums of the 256-Gaussian sub-blocks (the emission scans inside them)
-  uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS]
-  uint32_t* chunk_vis;      // [SCAN_MAX_CHUNKS]
+  uint32_t* chunk_sums;     // [SCAN_MAX_CHUNKS] out: instances before every chunk (scan_chunk_offsets)
+  uint4* part_sum;          // [SCAN_MAX_CHUNKS] instances of every chunk, as up to four partial sums (a tile of segment 1 is
+  uint4* part_vis;          //   gathered by four workgroups: ScanBatch::split); the same for the visible Gaussians
   uint32_t* header;
   uint32_t* img_header;
   int32_t* n_out;
@@ -143,6 +144,11 @@ struct ScanJob {
 };
 struct ScanBatch {
   int32_t n, P, K1, tiles_per_chunk, nchunks;   // K1 == P: one round (every Gaussian emits its whole rect)
+  // split > 1 (needs tiles_per_chunk == 1): the first dense_chunks chunks -- segment 1, every Gaussian's rect gathered at a
+  // random address -- are served by `split` workgroups each.  One workgroup per 4096-Gaussian tile left the gathers of
+  // segment 1 on 31 of the 245 chunks of a view: those workgroups ran 42 us (the misses one CU can keep in flight) while
+  // the rest of the chip waited.
+  int32_t split, dense_chunks;
   uint32_t* repair_barrier;   // two-round forward: arrival counter of the repair kernel's grid barrier, reset here
   ScanJob j[B3GS_MAX_FUSED_VIEWS];
 };
@@ -169,8 +175,9 @@ struct EmitJob {
 struct EmitBatch {
   int32_t n, P, first, subs;    // Gaussians [first, P) of the depth order; round 1: 256-Gaussian sub-blocks per scan chunk
   int32_t K1;                   // round 1: Gaussians behind K1 go to the predicted-open tiles only (K1 == P: one round)
-  int32_t dense_blocks;         // round 1: workgroups [0, dense_blocks) expand the 256-Gaussian sub-blocks of segment 1, the
-  int32_t tiles_per_chunk;      //   others walk the flagged list of one 4096-Gaussian tile behind K1 each
+  int32_t compact_blocks;       // round 1: workgroups [0, compact_blocks) walk the flagged list of one 4096-Gaussian tile behind
+  int32_t dense_blocks;         //   K1 each (the longer ones: first in the grid), the next dense_blocks expand the 256-Gaussian
+  int32_t tiles_per_chunk;      //   sub-blocks of segment 1
   EmitJob j[B3GS_MAX_FUSED_VIEWS];
 };
 
@@ -250,8 +257,12 @@ constexpr int SCAN_MAX_SUBS = 64;
 // and the stores of that many items per thread are in flight together.  The kernel is one dependent chain of memory round
 // trips per step with ~3 workgroups per CU: measured on MI355X: 4, 8 and 16 within 1 % (the rect gathers of the flagged half of the Gaussians bound the kernel).
 #ifndef B3GS_SCAN_BATCH
-#define B3GS_SCAN_BATCH 8
+#define B3GS_SCAN_BATCH 4
 #endif
+#ifndef B3GS_SCAN_SPLIT
+#define B3GS_SCAN_SPLIT 4    /* workgroups per 4096-Gaussian tile of segment 1 (divides 16 / B3GS_SCAN_BATCH) */
+#endif
+constexpr int SCAN_SPLIT = B3GS_SCAN_SPLIT;
 constexpr int SCAN_BATCH = B3GS_SCAN_BATCH;
 constexpr int SCAN_PRED_WORDS = 512;   // LDS copy of a tile bitmap (4 KB): up to 512 tile rows of <= 64 tiles, 256 of <= 128, ...   // sub-blocks per chunk: 16 * tiles_per_chunk (P < 2^24 keeps tiles_per_chunk <= 2)
 // Behind segment 1 (two-round forward) a Gaussian only matters when its rect reaches a predicted-open tile: the
@@ -293,7 +304,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   const ScanJob& pj = pair ? sb.j[job.partner] : job;
   const uint32_t* __restrict__ order = job.order;
   const int subs = sb.tiles_per_chunk * SCAN_ITEMS;
-  const int64_t begin = (int64_t)blockIdx.x * sb.tiles_per_chunk * SCAN_TILE;
+  // which chunk, and which of its 256-Gaussian sub-blocks [r_lo, r_hi) (all, unless this is one of the `split` workgroups of
+  // a segment-1 chunk)
+  uint32_t chunk = blockIdx.x, part = 0;
+  int r_lo = 0, r_hi = SCAN_ITEMS;
+  if (sb.split > 1) {
+    if ((int)blockIdx.x < sb.dense_chunks * sb.split) {
+      chunk = blockIdx.x / (uint32_t)sb.split;
+      part = blockIdx.x % (uint32_t)sb.split;
+      r_lo = (int)part * (SCAN_ITEMS / sb.split);
+      r_hi = r_lo + SCAN_ITEMS / sb.split;
+    } else {
+      chunk = (uint32_t)sb.dense_chunks + (blockIdx.x - (uint32_t)(sb.dense_chunks * sb.split));
+    }
+  }
+  if ((int)chunk >= sb.nchunks) return;
+  const int64_t begin = (int64_t)chunk * sb.tiles_per_chunk * SCAN_TILE;
   const int64_t end = min((int64_t)sb.P, begin + (int64_t)sb.tiles_per_chunk * SCAN_TILE);
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
   const u64 lt = lanemask_lt();
@@ -321,13 +347,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
     const int64_t tb = begin + (int64_t)t * SCAN_TILE;
     if (tb >= end) break;
     const int64_t te = min(end, tb + (int64_t)SCAN_TILE);
-    const size_t tile = (size_t)blockIdx.x * sb.tiles_per_chunk + t;
+    const size_t tile = (size_t)chunk * sb.tiles_per_chunk + t;
     uint32_t ts_a = 0, ts_b = 0;   // this thread's share of the tile's instance totals
     if (tb < (int64_t)sb.K1) {
       // ---- segment 1 (K1 is a multiple of the tile size, or P): every Gaussian emits its whole rect.
       // tiles_touched == area of the rectangle (preprocess keeps them consistent); sub-blocks in batches: the index
       // loads, then the dependent rect gathers (the random access of the binning), are in flight together
-      for (int r0 = 0; r0 < SCAN_ITEMS; r0 += SCAN_BATCH) {
+      for (int r0 = r_lo; r0 < r_hi; r0 += SCAN_BATCH) {
         uint32_t oi[SCAN_BATCH];
         uint4 rr[SCAN_BATCH];
 #pragma unroll
@@ -424,7 +450,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
     uint32_t tot_a, tot_b;
     block_excl_scan_256(ts_a, tmp, &tot_a);
     block_excl_scan_256(ts_b, tmp, &tot_b);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && r_hi - r_lo == SCAN_ITEMS) {   // (split tiles: tiles_per_chunk == 1, nobody reads their tsum)
       job.tsum[tile] = tot_a;
       if (pair) pj.tsum[tile] = tot_b;
     }
@@ -434,22 +460,35 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   uint32_t tot, tot2;
   block_excl_scan_256(sum, tmp, &tot);      // (its barriers also publish ssub)
   block_excl_scan_256(vis, tmp, &tot2);
+  // this workgroup's share of the chunk total; a workgroup that serves the whole chunk writes the other shares as zero
+  const bool whole = r_hi - r_lo == SCAN_ITEMS;
+  const bool my_subs = (int)threadIdx.x < subs && (whole || ((int)threadIdx.x >= r_lo && (int)threadIdx.x < r_hi));
   if (threadIdx.x == 0) {
-    job.chunk_sums[blockIdx.x] = tot;
-    job.chunk_vis[blockIdx.x] = tot2;
+    if (whole) {
+      job.part_sum[chunk] = make_uint4(tot, 0u, 0u, 0u);
+      job.part_vis[chunk] = make_uint4(tot2, 0u, 0u, 0u);
+    } else {
+      reinterpret_cast<uint32_t*>(job.part_sum + chunk)[part] = tot;
+      reinterpret_cast<uint32_t*>(job.part_vis + chunk)[part] = tot2;
+    }
   }
-  if ((int)threadIdx.x < subs)
-    job.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
+  if (my_subs)
+    job.soffs[(size_t)chunk * subs + threadIdx.x] =
         (ssub[0][0][threadIdx.x] + ssub[0][1][threadIdx.x]) + (ssub[0][2][threadIdx.x] + ssub[0][3][threadIdx.x]);
   if (pair) {
     block_excl_scan_256(sum2, tmp, &tot);
     block_excl_scan_256(vis2, tmp, &tot2);
     if (threadIdx.x == 0) {
-      pj.chunk_sums[blockIdx.x] = tot;
-      pj.chunk_vis[blockIdx.x] = tot2;
+      if (whole) {
+        pj.part_sum[chunk] = make_uint4(tot, 0u, 0u, 0u);
+        pj.part_vis[chunk] = make_uint4(tot2, 0u, 0u, 0u);
+      } else {
+        reinterpret_cast<uint32_t*>(pj.part_sum + chunk)[part] = tot;
+        reinterpret_cast<uint32_t*>(pj.part_vis + chunk)[part] = tot2;
+      }
     }
-    if ((int)threadIdx.x < subs)
-      pj.soffs[(size_t)blockIdx.x * subs + threadIdx.x] =
+    if (my_subs)
+      pj.soffs[(size_t)chunk * subs + threadIdx.x] =
           (ssub[1][0][threadIdx.x] + ssub[1][1][threadIdx.x]) + (ssub[1][2][threadIdx.x] + ssub[1][3][threadIdx.x]);
   }
   BIN_TRACE(0, twg, 5, BIN_NOW());
@@ -468,9 +507,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     int idx = threadIdx.x * 8 + k;
-    loc[k] = idx < nchunks ? job.chunk_sums[idx] : 0u;
+    uint4 ps = make_uint4(0u, 0u, 0u, 0u), pv = ps;
+    if (idx < nchunks) { ps = job.part_sum[idx]; pv = job.part_vis[idx]; }
+    loc[k] = (ps.x + ps.y) + (ps.z + ps.w);
     s += loc[k];
-    v += idx < nchunks ? job.chunk_vis[idx] : 0u;
+    v += (pv.x + pv.y) + (pv.z + pv.w);
   }
   uint32_t tot, totv;
   uint32_t base = block_excl_scan_256(s, tmp, &tot);
@@ -918,9 +959,11 @@ void radix_pass(SortBatch& sb, int shift, hipStream_t s, int bits = 8) {
 // ---------------------------------------------------------------------------------------------
 // instance emission in depth order (wave-cooperative expansion)
 // ---------------------------------------------------------------------------------------------
+constexpr int EMIT_PRED_WORDS = 256;   // LDS copy of the predicted-open bitmap (2 KB) when it fits
 struct EmitShared {
   uint32_t s_end[4][64];
   uint32_t s_tmp[8];
+  unsigned long long s_open[EMIT_PRED_WORDS];
 };
 template <bool ROUND2>
 __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_t bx, uint32_t by, EmitShared& sh) {
@@ -933,49 +976,72 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
   uint32_t* __restrict__ tile_out = job.tile_out + off;
   uint32_t* __restrict__ idx_out = job.idx_out ? job.idx_out + off : nullptr;
   const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-  if (!ROUND2 && (int)bx >= eb.dense_blocks) {
+  if (!ROUND2 && (int)bx < eb.compact_blocks) {
     // One 4096-Gaussian tile behind segment 1 of a two-round forward: only its flagged Gaussians can emit anything (into
     // the tiles predicted open).  The scan left them as a list in depth order: dense lanes walk it 256 at a time; every
     // lane writes the few instances of its own Gaussian (no cooperative expansion, no search).
-    const uint32_t tile = (uint32_t)(eb.K1 / SCAN_TILE) + (bx - (uint32_t)eb.dense_blocks);
+    const uint32_t tile = (uint32_t)(eb.K1 / SCAN_TILE) + bx;
     const uint32_t Hn = job.fcount[tile];
     if (Hn == 0u) return;
     const uint32_t chunk = tile / (uint32_t)eb.tiles_per_chunk;
     uint32_t carry = job.chunk_base[chunk];
     for (uint32_t k = chunk * (uint32_t)eb.tiles_per_chunk; k < tile; k++) carry += job.tsum[k];
     const uint32_t* __restrict__ flist = job.flist + (size_t)tile * SCAN_TILE;
-    for (uint32_t e0 = 0; e0 < Hn; e0 += 256u) {
-      const uint32_t e = e0 + threadIdx.x;
-      uint32_t sidx = 0, cnt = 0;
-      if (e < Hn) {
-        sidx = tile * (uint32_t)SCAN_TILE + (flist[e] & FL_IDX);
-        cnt = job.scount[sidx];       // 0 when the Gaussian is flagged for the other view of the pair only
+    // the bitmap of the predicted tiles from LDS: a lane reads one word per row of its rect, one after the other
+    OpenMap om = job.open;
+    const uint32_t nw = om.grid_y * om.row_words;
+    if (nw <= (uint32_t)EMIT_PRED_WORDS) {
+      for (uint32_t k = threadIdx.x; k < nw; k += 256u) sh.s_open[k] = om.rows[k];
+      __syncthreads();
+      om.rows = sh.s_open;
+    }
+    // Two 256-entry rounds per trip: the list entries of both, then the dependent gathers of both, are in flight together
+    // (a round is a chain of two memory round trips; most tiles hold fewer than 512 entries)
+    for (uint32_t e0 = 0; e0 < Hn; e0 += 512u) {
+      uint32_t sidx[2], cnt[2] = {0u, 0u}, gid[2] = {0u, 0u};
+      uint2 rc[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+      bool in[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t e = e0 + 256u * h + threadIdx.x;
+        in[h] = e < Hn;
+        sidx[h] = in[h] ? tile * (uint32_t)SCAN_TILE + (flist[e] & FL_IDX) : 0u;
       }
-      uint32_t tot;
-      uint32_t pos = carry + block_excl_scan_256(cnt, s_tmp, &tot);
-      carry += tot;
-      if (cnt != 0u) {
-        const uint32_t gid = job.order[sidx] & ORDER_IDX;
-        const uint2 rc = job.srect[sidx];
-        const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
-        for (uint32_t y = y0; y < y1; y++)
-          for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
-            uint32_t c0;
-            unsigned long long m = open_bits(job.open, y, wb, x0, x1, &c0);
-            while (m) {
-              const uint32_t t = y * job.open.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
-              m &= m - 1ull;
-              if (pos < n_cap) {
-                if (idx_out) { tile_out[pos] = t; idx_out[pos] = gid; }
-                else tile_out[pos] = (t << job.idx_bits) | gid;
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        if (in[h]) {
+          cnt[h] = job.scount[sidx[h]];       // 0 when the Gaussian is flagged for the other view of the pair only
+          gid[h] = job.order[sidx[h]] & ORDER_IDX;
+          rc[h] = job.srect[sidx[h]];
+        }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (e0 + 256u * h >= Hn) break;
+        uint32_t tot;
+        uint32_t pos = carry + block_excl_scan_256(cnt[h], s_tmp, &tot);
+        carry += tot;
+        if (cnt[h] != 0u) {
+          const uint32_t x0 = rc[h].x & 0xFFFFu, y0 = rc[h].x >> 16, x1 = rc[h].y & 0xFFFFu, y1 = rc[h].y >> 16;
+          for (uint32_t y = y0; y < y1; y++)
+            for (uint32_t wb = x0 >> 6; wb <= (x1 - 1u) >> 6; wb++) {
+              uint32_t c0;
+              unsigned long long m = open_bits(om, y, wb, x0, x1, &c0);
+              while (m) {
+                const uint32_t t = y * om.grid_x + c0 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                if (pos < n_cap) {
+                  if (idx_out) { tile_out[pos] = t; idx_out[pos] = gid[h]; }
+                  else tile_out[pos] = (t << job.idx_bits) | gid[h];
+                }
+                pos++;
               }
-              pos++;
             }
-          }
+        }
       }
     }
     return;
   }
+  if (!ROUND2) bx -= (uint32_t)eb.compact_blocks;   // the (longer) list workgroups come first in the grid
   const int s = eb.first + (int)(bx * 256 + threadIdx.x);
   uint32_t gid = 0, cnt = 0, end = 0;
   uint2 rc = make_uint2(0, 0);
@@ -985,7 +1051,7 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
     if (s < P) cnt = job.scount[s];
     if (__ballot(cnt != 0) == 0) return;
   }
-  if (!ROUND2 && job.soffs[bx] == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
+  const uint32_t own_sum = ROUND2 ? 1u : job.soffs[bx];   // (looked at behind the loads below: one round trip, not two)
   if (s < P) {
     if (ROUND2) {
       gid = job.order[s] & ORDER_IDX;
@@ -998,11 +1064,16 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
     }
   }
   if (!ROUND2) {
+    // (lane k < sub reads the sum of sub-block k: one load per wave instead of a serial loop of up to 15 dependent ones)
+    const uint32_t chunk = bx / (uint32_t)eb.subs, sub = bx % (uint32_t)eb.subs;
+    const uint32_t before = (lane < sub && lane < (uint32_t)eb.subs) ? job.soffs[(size_t)chunk * eb.subs + lane] : 0u;
+    uint32_t base = job.chunk_base[chunk];
+    if (own_sum == 0u) return;   // nothing in this sub-block (culled tail, finished tiles only)
+    base += wave_sum(before);
     // inclusive end of every Gaussian's instance run: offset of this 256-Gaussian sub-block (chunk base + the sums of
     // the sub-blocks before it: uniform scalar loads) + the scan inside the sub-block
-    const uint32_t chunk = bx / (uint32_t)eb.subs, sub = bx % (uint32_t)eb.subs;
-    uint32_t base = job.chunk_base[chunk];
-    for (uint32_t k = 0; k < sub; k++) base += job.soffs[(size_t)chunk * eb.subs + k];
+    if (sub > 64u)   // (more than 64 sub-blocks per chunk: P > 2^24, not reachable through the scan's own limit)
+      for (uint32_t k = 64u; k < sub; k++) base += job.soffs[(size_t)chunk * eb.subs + k];
     uint32_t tot;
     end = base + block_excl_scan_256(cnt, s_tmp, &tot) + cnt;
   }
@@ -1058,8 +1129,17 @@ template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ EmitShared sh;
   const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
-  if (!ROUND2) { BIN_TRACE(1, twg, 0, BIN_NOW()); BIN_TRACE(1, twg, 7, (unsigned long long)((int)blockIdx.x >= eb.dense_blocks)); }
-  emit_instances_body<ROUND2>(eb, blockIdx.x, blockIdx.y, sh);
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (!ROUND2) {
+    // round 1 is a 1-D grid: the list workgroups of ALL views first (they run longest and would otherwise start behind
+    // every other view's workgroups), then the sub-blocks of segment 1; the view is the fast index in both parts
+    const uint32_t nc = (uint32_t)eb.compact_blocks * (uint32_t)eb.n;
+    if (blockIdx.x < nc) { bx = blockIdx.x / (uint32_t)eb.n; by = blockIdx.x % (uint32_t)eb.n; }
+    else { const uint32_t d = blockIdx.x - nc; bx = (uint32_t)eb.compact_blocks + d / (uint32_t)eb.n; by = d % (uint32_t)eb.n; }
+    BIN_TRACE(1, twg, 0, BIN_NOW());
+    BIN_TRACE(1, twg, 7, (unsigned long long)((int)bx < eb.compact_blocks));
+  }
+  emit_instances_body<ROUND2>(eb, bx, by, sh);
   if (!ROUND2) BIN_TRACE(1, twg, 5, BIN_NOW());
 }
 
@@ -1480,7 +1560,8 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     const BinJob& jb = jobs[v];
     const uint2* rect = jb.rect ? jb.rect : jb.g.rect;
     const int32_t rstride = jb.rect ? jb.rect_stride : 1;
-    sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp, jb.g.scan_tmp + SCAN_MAX_CHUNKS,
+    sc.j[v] = ScanJob{depth_order_of(jobs, v), rect, rstride, -1, jb.g.srect, jb.g.soffs, jb.g.scan_tmp,
+                      reinterpret_cast<uint4*>(jb.g.scan_tmp + SCAN_MAX_CHUNKS), reinterpret_cast<uint4*>(jb.g.scan_tmp + 5 * SCAN_MAX_CHUNKS),
                       jb.g.header, jb.im.header, jb.n_out, jb.g.scount,
                       open_map(jb.im.pred_rows, jb.W, jb.H), jb.high_water, jb.overflow_flag,
                       (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0), jb.g.pflag,
@@ -1494,7 +1575,10 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
     sc.j[d].partner = v;
     sc.j[v].partner = -2;
   }
-  hipLaunchKernelGGL(scan_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
+  sc.split = sc.tiles_per_chunk == 1 ? SCAN_SPLIT : 1;
+  sc.dense_chunks = K1 < P ? K1 / SCAN_TILE : sc.nchunks;
+  const int scan_blocks = sc.split > 1 ? sc.dense_chunks * sc.split + (sc.nchunks - sc.dense_chunks) : sc.nchunks;
+  hipLaunchKernelGGL(scan_chunk_sums, dim3(scan_blocks, nviews), dim3(SCAN_THREADS), 0, s, sc);
   hipLaunchKernelGGL(scan_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
   // (no per-Gaussian offsets: the emission scans inside its 256-Gaussian sub-block, see scan_chunk_sums)
 }
@@ -1534,7 +1618,8 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   }
   // segment 1 as 256-Gaussian sub-blocks, then one workgroup per 4096-Gaussian tile behind it (flagged lists)
   eb.dense_blocks = K1 < P ? K1 / 256 : (P + 255) / 256;
-  const int emit_blocks = eb.dense_blocks + (K1 < P ? (P - K1 + SCAN_TILE - 1) / SCAN_TILE : 0);
+  eb.compact_blocks = K1 < P ? (P - K1 + SCAN_TILE - 1) / SCAN_TILE : 0;
+  const int emit_blocks = eb.compact_blocks + eb.dense_blocks;
   SortBatch tb;
   tb.n = nviews;
   RangeBatch rb;
@@ -1568,7 +1653,7 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
     }
   }
   if (max_cap == 0) return;  // im.ranges was reset to "empty" by the preprocess launch
-  hipLaunchKernelGGL(emit_instances<false>, dim3(emit_blocks, nviews), dim3(256), 0, s, eb);
+  hipLaunchKernelGGL(emit_instances<false>, dim3(emit_blocks * nviews), dim3(256), 0, s, eb);
 
   // ---- 4. stable split by tile id
   for (int p = 0; p < passes; p++) {
@@ -1628,6 +1713,7 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
   eb.first = K1;
   eb.subs = 1;
   eb.dense_blocks = 0x7FFFFFFF;
+  eb.compact_blocks = 0;
   eb.tiles_per_chunk = 1;
   SortBatch tb;
   tb.n = nviews;
