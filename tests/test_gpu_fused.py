@@ -895,6 +895,51 @@ def test_sparse_gradient_rows_equal_dense_rows(P):
             assert rel_l2(x.cpu().numpy(), y.cpu().numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("K", [4, 16])
+def test_overwrite_chain_rule_of_a_batch_equals_accumulation_per_view(K):
+    """`accumulate_chain_kernel` deals the (Gaussian, view) pairs of a batch to its waves as dense chunks and sums them in
+    an LDS row per Gaussian; SH coefficients beyond degree 1 (K = 16) go to memory with atomic adds after the row's own
+    thread zeroed them (overwrite mode).  One overwrite pass over six views must equal six single-view passes ADDED into
+    zeroed gradients, on top of sentinel-filled gradients, for every parameter tensor."""
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H, P = 160, 120, 20000
+    model, pairs, bg = _setup(P=P, W=W, H=H, K=K)
+    model.active_sh_degree = {4: 1, 16: 3}[K]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    views = []
+    for i, (cam, scam, _t) in enumerate(pairs):
+        views += [(cam, 2 * i, True), (scam, 2 * i + 1, False)]
+
+    def backward(outs):
+        o, g = [], []
+        for x, v in zip(outs, views):
+            o.append(x["render"]); g.append(gc)
+            if v[2]:
+                o += [x["rendered_depth"], x["rendered_alpha"]]; g += [gd, ga]
+        torch.autograd.backward(o, g)
+
+    fr = FusedRasterizer(model, W, H, num_slots=len(views))
+    for p in model.parameters():
+        p.grad = torch.full_like(p, -7.0)                      # overwritten, not added to
+    fr.begin_deferred()
+    backward(fr.render_batch(views, bg))
+    fr.finish_deferred(overwrite=True)
+    torch.cuda.synchronize()
+    got = [p.grad.clone() for p in model.parameters()]
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    for k, v in enumerate(views):                              # one view at a time, added
+        out = fr.render(v[0], bg, slot=v[1])
+        torch.autograd.backward([out["render"]] + ([out["rendered_depth"], out["rendered_alpha"]] if v[2] else []),
+                                [gc] + ([gd, ga] if v[2] else []))
+    torch.cuda.synchronize()
+    for n, a, p in zip(["xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity"], got, model.parameters()):
+        if p.numel():
+            assert float(p.grad.abs().max()) > 0
+            assert rel_l2(a.cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, n
+
+
 def test_sparse_row_and_row_mask_argument_errors():
     """(i) sparse-row accumulate over a Gaussian range must start at a multiple of 64 (the bitmap is written word-wise);
     (ii) a masked Adam step rejects negative row geometry; both leave a message in b3gs_last_error."""
