@@ -753,7 +753,8 @@ def test_depth_key_outside_the_27_bit_span_is_detected_and_falls_back():
 
 
 @pytest.mark.parametrize("P,W,H", [(2, 16, 16), (65, 16, 16), (257, 40, 24), (3000, 33, 17), (5000, 272, 16), (4097, 40, 24),
-                                   (8192, 33, 17), (12289, 272, 16), (20000, 16, 16)])
+                                   (8192, 33, 17), (12289, 272, 16), (20000, 16, 16),
+                                   pytest.param(8_500_000, 96, 64, id="8.5M_two_scan_tiles_per_chunk")])
 def test_two_round_binning_edge_sizes(P, W, H):
     """Two-round binning at the edges.  Segment 1 is a whole number of 4096-Gaussian tiles of the depth order, so fewer than
     4097 Gaussians are always binned in one round (the first four sizes: the request must simply be honoured as one round);
