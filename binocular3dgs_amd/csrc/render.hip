@@ -463,9 +463,70 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[9] = wgt * px.dD;
 }
 
+// ---- the candidate step of the blend backward, shared by the tile-workgroup kernel and the quadrant-wave kernel below.
+// The macros use the surrounding kernel's locals: px, base, pending, q0..q3, pend_g, red_rd, red_base, red_stride,
+// red_writer, red_m0 and (TRACE) n_iter / n_live / n_lanes.
+#define B3GS_RETIRE_PENDING()                                                          \
+  do {                                                                                 \
+    float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));       \
+    v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));            \
+    v = dpp_add<0xB1, 0xF>(v); /* quad_perm [1,0,3,2] */                               \
+    v = dpp_add<0x4E, 0xF>(v); /* quad_perm [2,3,0,1] -> 4 parts of component rk */    \
+    if (red_writer) unsafeAtomicAdd(red_base + __umul24(pend_g, red_stride), v);       \
+  } while (0)
+
+  // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
+#define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
+  do {                                                                                           \
+    const float dx_ = A.x - px.fpx, dy_ = A.y - px.fpy;                                          \
+    const float u_ = A.z * dx_, v_ = B.x * dy_, nw_ = -A.w * dx_;                                \
+    /* == blend_power(): same products, same order (the forward must agree on every skip decision) */ \
+    const float power = __builtin_fmaf(nw_, dy_, -0.5f * __builtin_fmaf(v_, dy_, u_ * dx_));     \
+    const float G = __expf(power);                                                               \
+    const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);                                          \
+    const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
+    if (TRACE) n_iter++;                                                                         \
+    if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
+      if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
+      float p[10];                                                                               \
+      bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
+      B3GS_ROW_WRITES(p);                                                                        \
+      if (B3GS_BWD_PIPELINE && pending) B3GS_RETIRE_PENDING();                                   \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
+      __builtin_amdgcn_wave_barrier();                                                           \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
+      q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];                            \
+      pend_g = (uint32_t)__float_as_int(Cc.z);                                                   \
+      if (B3GS_BWD_PIPELINE) pending = true;                                                     \
+      else B3GS_RETIRE_PENDING();   /* experiment: reduce at once (16 fewer live VGPRs) */        \
+    }                                                                                            \
+  } while (0)
+  // row k of the per-wave scratch <- component k of every lane.  ds_write_addtid_b32 (address = M0 + offset
+  // + 4*lane, no address VGPR); s_nop: a SALU write of M0 needs one wait state before an LDS add-TID
+  // instruction, which the assembler does not insert inside an asm block.
+#define B3GS_ROW_WRITES(p)                                                                       \
+  asm volatile(                                                                                  \
+      "s_mov_b32 m0, %10\n\t"                                                                    \
+      "s_nop 0\n\t"                                                                              \
+      "ds_write_addtid_b32 %0 offset:0\n\t"                                                      \
+      "ds_write_addtid_b32 %1 offset:272\n\t"                                                    \
+      "ds_write_addtid_b32 %2 offset:544\n\t"                                                    \
+      "ds_write_addtid_b32 %3 offset:816\n\t"                                                    \
+      "ds_write_addtid_b32 %4 offset:1088\n\t"                                                   \
+      "ds_write_addtid_b32 %5 offset:1360\n\t"                                                   \
+      "ds_write_addtid_b32 %6 offset:1632\n\t"                                                   \
+      "ds_write_addtid_b32 %7 offset:1904\n\t"                                                   \
+      "ds_write_addtid_b32 %8 offset:2176\n\t"                                                   \
+      "ds_write_addtid_b32 %9 offset:2448"                                                       \
+      :                                                                                          \
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),  \
+        "v"(p[8]), "v"(p[9]), "s"(red_m0)                                                        \
+      : "memory")
+
+
 template <int CHUNK, bool TRACE>
 __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
-    render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
+    render_bwd_tile_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileSharedBwd<CHUNK> sh;
   __shared__ uint32_t s_max_last[4];
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
@@ -564,63 +625,6 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   float4 q0, q1, q2, q3;      // pending reduction reads
   uint32_t pend_g = 0;        // Gaussian they belong to (P < 2^24: 24-bit multiply for the row offset)
   bool pending = false;
-#define B3GS_RETIRE_PENDING()                                                          \
-  do {                                                                                 \
-    float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));       \
-    v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));            \
-    v = dpp_add<0xB1, 0xF>(v); /* quad_perm [1,0,3,2] */                               \
-    v = dpp_add<0x4E, 0xF>(v); /* quad_perm [2,3,0,1] -> 4 parts of component rk */    \
-    if (red_writer) unsafeAtomicAdd(red_base + __umul24(pend_g, red_stride), v);       \
-  } while (0)
-
-  // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
-#define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
-  do {                                                                                           \
-    const float dx_ = A.x - px.fpx, dy_ = A.y - px.fpy;                                          \
-    const float u_ = A.z * dx_, v_ = B.x * dy_, nw_ = -A.w * dx_;                                \
-    /* == blend_power(): same products, same order (the forward must agree on every skip decision) */ \
-    const float power = __builtin_fmaf(nw_, dy_, -0.5f * __builtin_fmaf(v_, dy_, u_ * dx_));     \
-    const float G = __expf(power);                                                               \
-    const float alpha = fminf(B3GS_ALPHA_MAX, B.y * G);                                          \
-    const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
-    if (TRACE) n_iter++;                                                                         \
-    if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
-      if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
-      float p[10];                                                                               \
-      bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
-      B3GS_ROW_WRITES(p);                                                                        \
-      if (B3GS_BWD_PIPELINE && pending) B3GS_RETIRE_PENDING();                                   \
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                     \
-      __builtin_amdgcn_wave_barrier();                                                           \
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                     \
-      q0 = red_rd[0]; q1 = red_rd[1]; q2 = red_rd[2]; q3 = red_rd[3];                            \
-      pend_g = (uint32_t)__float_as_int(Cc.z);                                                   \
-      if (B3GS_BWD_PIPELINE) pending = true;                                                     \
-      else B3GS_RETIRE_PENDING();   /* experiment: reduce at once (16 fewer live VGPRs) */        \
-    }                                                                                            \
-  } while (0)
-  // row k of the per-wave scratch <- component k of every lane.  ds_write_addtid_b32 (address = M0 + offset
-  // + 4*lane, no address VGPR); s_nop: a SALU write of M0 needs one wait state before an LDS add-TID
-  // instruction, which the assembler does not insert inside an asm block.
-#define B3GS_ROW_WRITES(p)                                                                       \
-  asm volatile(                                                                                  \
-      "s_mov_b32 m0, %10\n\t"                                                                    \
-      "s_nop 0\n\t"                                                                              \
-      "ds_write_addtid_b32 %0 offset:0\n\t"                                                      \
-      "ds_write_addtid_b32 %1 offset:272\n\t"                                                    \
-      "ds_write_addtid_b32 %2 offset:544\n\t"                                                    \
-      "ds_write_addtid_b32 %3 offset:816\n\t"                                                    \
-      "ds_write_addtid_b32 %4 offset:1088\n\t"                                                   \
-      "ds_write_addtid_b32 %5 offset:1360\n\t"                                                   \
-      "ds_write_addtid_b32 %6 offset:1632\n\t"                                                   \
-      "ds_write_addtid_b32 %7 offset:1904\n\t"                                                   \
-      "ds_write_addtid_b32 %8 offset:2176\n\t"                                                   \
-      "ds_write_addtid_b32 %9 offset:2448"                                                       \
-      :                                                                                          \
-      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),  \
-        "v"(p[8]), "v"(p[9]), "s"(red_m0)                                                        \
-      : "memory")
-
   for (int c = (int)((max_last - 1) / CHUNK); c >= 0; c--) {
     stage_chunk(sh.f, tl, bv.idx_mask, rec, (uint32_t)(c * CHUNK), (float)(tile_x * B3GS_TILE), (float)(tile_y * B3GS_TILE));
     __syncthreads();
@@ -669,10 +673,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     }
     __syncthreads();
   }
-#undef B3GS_BWD_CANDIDATE
-#undef B3GS_ROW_WRITES
   if (pending) B3GS_RETIRE_PENDING();
-#undef B3GS_RETIRE_PENDING
   if (TRACE && lane == 0) {
     unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;            // shader cycles this wave lived
@@ -681,6 +682,210 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     t[3] = (unsigned long long)n_live | ((unsigned long long)n_lanes << 32);   // live iterations | live lanes summed
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Blend backward with ONE WAVE PER WORKGROUP: workgroup = (tile, 8x8 quadrant).  The tile-workgroup kernel above
+// couples the four quadrant waves of a tile through two barriers per 64 staged list entries (one wave stages, three
+// wait; then all wait for the slowest quadrant) and holds the tile's wave slots until its heaviest quadrant is done
+// (tools/bwd_trace_batched.py: 11.5 % of the wave-slot time is held by waves that have finished; jobs of 4 x ~100 us
+// leave the machine emptying for the last 15 % of the launch).  Here every quadrant stages its own 64 entries -- the
+// record gathers are repeated by the four quadrants of a tile (L1 / L2 hits: the four workgroups are dispatched
+// back to back) and every lane tests ITS entry against ITS quadrant only, so the test work is the same -- walks
+// only its own depth (wave_last), has no barrier at all, and is a job a quarter as long.
+template <int SC>
+struct WaveSharedBwd {
+  float4 A[SC], B[SC], C[SC];
+  float red[10 * RED_STRIDE];
+};
+// REGS: the staged records stay in the staging lanes' REGISTERS (lane t holds list entry base + t) and the record of
+// candidate j is fetched with eleven v_readlane_b32 (wave-uniform: the values land in SGPRs) instead of three broadcast
+// LDS reads.  The backward is bound by the LDS pipe -- per candidate and wave: 10 ds_write_addtid_b32 (2 cycles each) + 4
+// ds_read_b128 (8 each) of the reduction + 2 ds_read_b128 + 1 ds_read_b96 of the record (8 each, broadcast or not) = 76
+// cycles, x 4 SIMDs = 304 per CU and candidate-quad against the measured 290 -- so the record reads are a third of it.
+template <bool TRACE, int SC, bool REGS>
+__global__ void __launch_bounds__(64, REGS ? 8 : B3GS_BWD_WAVES)
+    render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
+  __shared__ WaveSharedBwd<REGS ? 1 : SC> sh;
+  const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  unsigned n_iter = 0, n_live = 0, n_lanes = 0;
+  const unsigned w = blockIdx.x & 3u, blk = blockIdx.x >> 2;     // quadrant, tile-level block
+  // longest-tile-first inside the XCD class (BlendBatch::order); placement never affects results
+  const int bid = batch.order ? 8 * (int)batch.order[(blk & 7u) * (unsigned)batch.cls_size + (blk >> 3)] + (int)(blk & 7u) : (int)blk;
+  const BlendView bv = select_view(batch, bid);
+  const int W = bv.W, H = bv.H, grid_x = bv.grid_x, ntiles = bv.ntiles;
+  const float4* __restrict__ rec = bv.rec;
+  const float* __restrict__ bg = bv.bg;
+  float* __restrict__ dL_dmeans2D = bv.dL_dmeans2D;
+  float* __restrict__ dL_dcolors = bv.dL_dcolors;
+  float* __restrict__ dL_dopacity = bv.dL_dopacity;
+  float* __restrict__ dL_dcov3D = bv.dL_dcov3D;
+  const unsigned cov_stride = bv.cov_stride;
+  const int tile = tile_of_block(bid - bv.block_base, ntiles);
+  if (tile >= ntiles) return;
+  const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+  const unsigned lane = threadIdx.x;
+  const int ipx = tile_x * B3GS_TILE + (int)((w & 1) * 8 + (lane & 7));
+  const int ipy = tile_y * B3GS_TILE + (int)((w >> 1) * 8 + (lane >> 3));
+  const bool inside = ipx < W && ipy < H;
+  const TileList tl = tile_list(bv, tile, true);   // n_contrib counts positions of segment 1 + segment 2
+
+  BwdPixel px;
+  px.fpx = (float)ipx;
+  px.fpy = (float)ipy;
+  px.half_w = 0.5f * (float)W;
+  px.half_h = 0.5f * (float)H;
+  px.last = 0;
+  px.T_final = 0.f;
+  px.dCr = px.dCg = px.dCb = px.dD = px.dA = 0.f;
+  if (inside) {
+    const size_t pix = (size_t)ipy * W + ipx, hw = (size_t)H * W;
+    px.last = bv.n_contrib[pix];
+    px.T_final = bv.final_T[pix];
+    px.dCr = bv.dL_dcolor[pix];
+    px.dCg = bv.dL_dcolor[hw + pix];
+    px.dCb = bv.dL_dcolor[2 * hw + pix];
+    if (bv.dL_ddepth) px.dD = bv.dL_ddepth[pix];
+    if (bv.dL_dalpha) px.dA = bv.dL_dalpha[pix];
+  }
+  px.bg_dot = (bg[0] * px.dCr + bg[1] * px.dCg) + bg[2] * px.dCb;
+  px.T = px.T_final;
+  px.Bw = 0.f;
+  uint32_t wave_last = px.last;   // deepest list position any pixel of the quadrant used
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, (uint32_t)__shfl_xor((int)wave_last, d, 64));
+  wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+  if (wave_last == 0) {
+    if (TRACE && lane == 0) {   // (the trace buffer is reused: an idle quadrant leaves an empty record, not a stale one)
+      unsigned long long* t = trace + 4 * ((size_t)blk * 4 + w);
+      t[0] = 0ull;
+      t[1] = (r_start << 32) | (r_start & 0xFFFFFFFFull);
+      t[2] = 0ull;
+      t[3] = 0ull;
+    }
+    return;
+  }
+  if (wave_last > 400) __builtin_amdgcn_s_setprio(3);
+  else if (wave_last > 330) __builtin_amdgcn_s_setprio(2);
+  else if (wave_last > 260) __builtin_amdgcn_s_setprio(1);
+
+  const unsigned rk = lane >> 2, rpart = lane & 3;
+  float* red_base;
+  unsigned red_stride;
+  if (rk < 2) { red_base = dL_dmeans2D + rk; red_stride = bv.m2d_stride; }
+  else if (rk < 5) { red_base = dL_dcov3D + (rk - 2); red_stride = cov_stride; }
+  else if (rk == 5) { red_base = dL_dopacity; red_stride = bv.op_stride; }
+  else if (rk < 9) { red_base = dL_dcolors + (rk - 6); red_stride = bv.col_stride; }
+  else { red_base = dL_dcov3D + 3; red_stride = cov_stride; }
+  const bool red_writer = (rk < 10u) && (rpart == 0);
+  float* const red = sh.red;
+  const uint32_t red_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)red);
+  const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
+  float4 q0, q1, q2, q3;
+  uint32_t pend_g = 0;
+  bool pending = false;
+
+  // this quadrant's pixel rectangle relative to the tile origin
+  const float qx0 = (float)((w & 1) * 8), qy0 = (float)((w >> 1) * 8);
+  const float tile_px = (float)(tile_x * B3GS_TILE), tile_py = (float)(tile_y * B3GS_TILE);
+  for (int c = (int)((wave_last - 1) / (uint32_t)SC); c >= 0; c--) {
+    const uint32_t base = (uint32_t)c * (uint32_t)SC;
+    // ---- stage 64 list entries; the lane's entry against THIS quadrant (bounding box, then the exact test of stage_chunk)
+    const uint32_t q = base + lane;
+    bool hit = false;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    int id = 0;
+    if ((SC == 64 || lane < (unsigned)SC) && q < tl.total && q < wave_last) {
+      const uint32_t word = q < tl.len1 ? tl.list1[tl.first1 + q] : tl.list2[tl.first2 + (q - tl.len1)];
+      id = (int)(word & bv.idx_mask);
+      const float4* r = rec + 4 * (size_t)id;
+      r0 = r[0]; r1 = r[1]; r2 = r[2];
+      if (!REGS) {
+        sh.A[lane] = r0;
+        sh.B[lane] = r1;
+        sh.C[lane] = make_float4(r2.x, r2.y, __int_as_float(id), 0.f);
+      }
+      const float ax = (tile_px + qx0) - r0.x, bx = ax + 7.0f;   // quadrant rectangle relative to the mean
+      const float ay = (tile_py + qy0) - r0.y, by = ay + 7.0f;
+      hit = (ax <= r2.z) && (bx >= -r2.z) && (ay <= r2.w) && (by >= -r2.w);
+      if (hit) {
+        const float cxx = r0.z, cxy = r0.w, cyy = r1.x;
+        const float tau = __logf(255.0f * r1.y) * 1.0005f + 2e-3f;
+        const float icx = __builtin_amdgcn_rcpf(cxx), icy = __builtin_amdgcn_rcpf(cyy);
+        const bool in_rect = (ax <= 0.0f) && (bx >= 0.0f) && (ay <= 0.0f) && (by >= 0.0f);
+        float fmin = 3.0e38f;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float dx = e ? bx : ax;                                   // vertical edge
+          const float dy = fminf(fmaxf(-cxy * dx * icy, ay), by);
+          fmin = fminf(fmin, 0.5f * (cxx * dx * dx + cyy * dy * dy) + cxy * dx * dy);
+          const float ey = e ? by : ay;                                   // horizontal edge
+          const float ex = fminf(fmaxf(-cxy * ey * icx, ax), bx);
+          fmin = fminf(fmin, 0.5f * (cxx * ex * ex + cyy * ey * ey) + cxy * ex * ey);
+        }
+        hit = in_rect || !(fmin > tau);
+      }
+    }
+    u64 m = __ballot(hit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (REGS) {
+      // the candidate's Gaussian index from the staging lane (one v_readlane_b32), its record through the SCALAR cache
+      // (s_load from the record array: nothing in this launch writes it; the staging lanes' gathers have just pulled the
+      // line into L2).  Measured alternatives: all eleven values by v_readlane_b32 (803 us: a cross-lane read costs ~8
+      // cycles of the vector ALU); both s_loads forced into one issue by inline asm (same time).
+      typedef const float __attribute__((address_space(4))) cfloat_k;
+      while (m) {
+        const int j = 63 - __builtin_clzll(m);
+        clear_bit(m, j);
+        const int idj = __builtin_amdgcn_readlane(id, j);
+        cfloat_k* rs = (cfloat_k*)(uintptr_t)(rec + 4 * (size_t)idj);
+        const float4 A0 = make_float4(rs[0], rs[1], rs[2], rs[3]);
+        const float4 B0 = make_float4(rs[4], rs[5], rs[6], rs[7]);
+        const float4 C0 = make_float4(rs[8], rs[9], __int_as_float(idj), 0.f);
+        B3GS_BWD_CANDIDATE(A0, B0, C0, j);
+      }
+    } else if (m != 0) {
+      const float4* const sA = sh.A;
+      const float4* const sB = sh.B;
+      const float4* const sC = sh.C;
+      int j = 63 - __builtin_clzll(m);
+      clear_bit(m, j);
+      float4 A0 = sA[j], B0 = sB[j], C0 = sC[j], A1, B1, C1;
+      while (true) {
+        bool more = m != 0;
+        int jn = more ? 63 - __builtin_clzll(m) : j;   // (re-reads the current record on the last entry)
+        clear_bit(m, jn);
+        A1 = sA[jn]; B1 = sB[jn]; C1 = sC[jn];
+        B3GS_BWD_CANDIDATE(A0, B0, C0, j);
+        if (!more) break;
+        j = jn;
+        more = m != 0;
+        jn = more ? 63 - __builtin_clzll(m) : j;
+        clear_bit(m, jn);
+        A0 = sA[jn]; B0 = sB[jn]; C0 = sC[jn];
+        B3GS_BWD_CANDIDATE(A1, B1, C1, j);
+        if (!more) break;
+        j = jn;
+      }
+    }
+    // (the next round's record stores follow this round's record reads in the wave's in-order LDS queue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (pending) B3GS_RETIRE_PENDING();
+  if (TRACE && lane == 0) {
+    unsigned long long* t = trace + 4 * ((size_t)blk * 4 + w);
+    t[0] = __builtin_readcyclecounter() - t_start;
+    t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
+    t[2] = n_iter;
+    t[3] = (unsigned long long)n_live | ((unsigned long long)n_lanes << 32);
+  }
+}
+#undef B3GS_BWD_CANDIDATE
+#undef B3GS_ROW_WRITES
+#undef B3GS_RETIRE_PENDING
 
 #ifndef B3GS_FWD_CHUNK
 #define B3GS_FWD_CHUNK 256
@@ -817,10 +1022,20 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   unsigned long long* trace = getenv("B3GS_BWD_TRACE") ? trace_buffer(total) : nullptr;
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
-  if (trace) hipLaunchKernelGGL((render_bwd_kernel<64, true>), dim3(total), dim3(256), 0, s, batch, trace);
-  else if (bwd_chunk == 256) hipLaunchKernelGGL((render_bwd_kernel<256, false>), dim3(total), dim3(256), 0, s, batch, trace);
-  else if (bwd_chunk == 128) hipLaunchKernelGGL((render_bwd_kernel<128, false>), dim3(total), dim3(256), 0, s, batch, trace);
-  else hipLaunchKernelGGL((render_bwd_kernel<64, false>), dim3(total), dim3(256), 0, s, batch, trace);
+  // default: one wave per workgroup (quadrant), records through the scalar cache; B3GS_BWD_KERNEL=tile selects the
+  // tile-workgroup kernel (four quadrant waves sharing an LDS stage), =wave the quadrant kernel with LDS-staged records
+  static const char* which = getenv("B3GS_BWD_KERNEL");
+  const bool tile_wg = which && !strcmp(which, "tile"), wave_lds = which && !strcmp(which, "wave");
+  if (!tile_wg) {
+    if (trace) hipLaunchKernelGGL((render_bwd_kernel<true, 64, true>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    else if (wave_lds) hipLaunchKernelGGL((render_bwd_kernel<false, 64, false>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    else hipLaunchKernelGGL((render_bwd_kernel<false, 64, true>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    return;
+  }
+  if (trace) hipLaunchKernelGGL((render_bwd_tile_kernel<64, true>), dim3(total), dim3(256), 0, s, batch, trace);
+  else if (bwd_chunk == 256) hipLaunchKernelGGL((render_bwd_tile_kernel<256, false>), dim3(total), dim3(256), 0, s, batch, trace);
+  else if (bwd_chunk == 128) hipLaunchKernelGGL((render_bwd_tile_kernel<128, false>), dim3(total), dim3(256), 0, s, batch, trace);
+  else hipLaunchKernelGGL((render_bwd_tile_kernel<64, false>), dim3(total), dim3(256), 0, s, batch, trace);
 }
 
 BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView& b, const ImgView& im) {
