@@ -709,7 +709,13 @@ __global__ void __launch_bounds__(64, REGS ? 8 : B3GS_BWD_WAVES)
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
   unsigned n_iter = 0, n_live = 0, n_lanes = 0;
+#ifdef B3GS_BWD_QUAD_LINEAR
   const unsigned w = blockIdx.x & 3u, blk = blockIdx.x >> 2;     // quadrant, tile-level block
+#else
+  // workgroup g runs on XCD g % 8: the four quadrants of a tile-level block stay on that block's XCD (its L2 holds the
+  // tile's records), i.e. quadrant = bits 3..4, tile-level block = (g >> 5) * 8 + g % 8
+  const unsigned w = (blockIdx.x >> 3) & 3u, blk = ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u);
+#endif
   // longest-tile-first inside the XCD class (BlendBatch::order); placement never affects results
   const int bid = batch.order ? 8 * (int)batch.order[(blk & 7u) * (unsigned)batch.cls_size + (blk >> 3)] + (int)(blk & 7u) : (int)blk;
   const BlendView bv = select_view(batch, bid);
