@@ -406,6 +406,9 @@ constexpr int RED_STRIDE = 68;
 #ifndef B3GS_BWD_PREFETCH
 #define B3GS_BWD_PREFETCH 1   /* fetch the next candidate's record (3 broadcast ds_read_b128) before evaluating the current one */
 #endif
+#ifndef B3GS_BWD_QWAVES
+#define B3GS_BWD_QWAVES 8   /* the quadrant-wave kernel: 55 VGPRs */
+#endif
 #ifndef B3GS_BWD_WAVES
 #define B3GS_BWD_WAVES 7  /* waves per SIMD the register allocator must leave room for */
 #endif
@@ -703,7 +706,7 @@ struct WaveSharedBwd {
 // ds_read_b128 (8 each) of the reduction + 2 ds_read_b128 + 1 ds_read_b96 of the record (8 each, broadcast or not) = 76
 // cycles, x 4 SIMDs = 304 per CU and candidate-quad against the measured 290 -- so the record reads are a third of it.
 template <bool TRACE, int SC, bool REGS>
-__global__ void __launch_bounds__(64, REGS ? 8 : B3GS_BWD_WAVES)
+__global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
     render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ WaveSharedBwd<REGS ? 1 : SC> sh;
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
