@@ -719,9 +719,10 @@ def pmc_passes(args, result):
         roof["valu"] = {"bound": "valu issue slots: 256 CUs x 4 SIMDs, one plain fp32 wave64 instruction per 2 cycles "
                                  "(tools/ubench/valu_rate.hip); transcendental / DPP / LDS-path instructions occupy 8",
                         "isa_cross_check": "static count of the hot loops (tools/isa_count.py -> profiles/r03_final_isa_counts.txt): "
-                                           "backward 75 VALU + 17 LDS + 22 SALU per candidate, forward 30 VALU + 3 LDS + 15 "
-                                           "SALU; x the candidates per launch of tools/bwd_trace_batched.py (4.98M) = 374M of "
-                                           "the ~386M SQ_INSTS_VALU measured for the backward (the rest is staging)",
+                                           "backward (one wave per tile quadrant, records through the scalar cache) 74 VALU + "
+                                           "14 LDS + 26 SALU/SMEM per candidate, forward 30 VALU + 3 LDS + 15 SALU; x the "
+                                           "candidates per launch of tools/bwd_trace_batched.py (4.98M) = 369M of the ~385M "
+                                           "SQ_INSTS_VALU measured for the backward (the rest is staging)",
                         "frac": vd.get(roof["kernel"], {}).get("issue_frac"), "kernels": vd}
 
 
