@@ -110,7 +110,10 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const TileList
   const unsigned tid = threadIdx.x;
   const uint32_t q = q0 + tid;
   int id = -1;
-  bool hit[4] = {false, false, false, false};
+  // bit q of `hits`: the staged Gaussian can reach quadrant q.  (A bit mask and a rolled loop over the quadrants: the four
+  // exact tests unrolled side by side were what set the register count of BOTH blend kernels -- 70 instead of 44 VGPRs for
+  // the forward -- and staging runs once per 256 list entries.)
+  uint32_t hits = 0u;
   if (CHUNK < 256 && tid >= (unsigned)CHUNK) return id;  // whole waves: wave-uniform exit
   if (q < tl.total) {
     const uint32_t word = q < tl.len1 ? tl.list1[tl.first1 + q] : tl.list2[tl.first2 + (q - tl.len1)];
@@ -126,23 +129,21 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const TileList
     const float ly = r0.y - r2.w - tile_py, hy = r0.y + r2.w - tile_py;
     const bool xl = (lx <= 7.0f) && (hx >= 0.0f), xr = (lx <= 15.0f) && (hx >= 8.0f);
     const bool yt = (ly <= 7.0f) && (hy >= 0.0f), yb = (ly <= 15.0f) && (hy >= 8.0f);
-    hit[0] = xl && yt;
-    hit[1] = xr && yt;
-    hit[2] = xl && yb;
-    hit[3] = xr && yb;
+    hits = (uint32_t)(xl && yt) | ((uint32_t)(xr && yt) << 1) | ((uint32_t)(xl && yb) << 2) | ((uint32_t)(xr && yb) << 3);
     // Exact test for the quadrants the bounding box reaches: the smallest value of the quadratic form
     // over the quadrant's pixel rectangle against tau = ln(255 opacity) (alpha >= 1/255 <=> form <= tau).
     // One thread does this once per staged Gaussian; every candidate it removes saves a 64-lane evaluation
     // in each direction.  Conservative: continuous rectangle >= pixel centres, plus a rounding margin.
-    if (hit[0] || hit[1] || hit[2] || hit[3]) {
+    if (hits) {
       const float cxx = r0.z, cxy = r0.w, cyy = r1.x;
       const float tau = __logf(255.0f * r1.y) * 1.0005f + 2e-3f;
       const float icx = __builtin_amdgcn_rcpf(cxx), icy = __builtin_amdgcn_rcpf(cyy);
       const float ox = tile_px - r0.x, oy = tile_py - r0.y;   // rectangle corner relative to the mean
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float ax = ox + (float)((q & 1) * 8), bx = ax + 7.0f;
-        const float ay = oy + (float)((q >> 1) * 8), by = ay + 7.0f;
+#pragma unroll 1
+      for (int qd = 0; qd < 4; qd++) {
+        if (!((hits >> qd) & 1u)) continue;
+        const float ax = ox + (float)((qd & 1) * 8), bx = ax + 7.0f;
+        const float ay = oy + (float)((qd >> 1) * 8), by = ay + 7.0f;
         const bool inside = (ax <= 0.0f) && (bx >= 0.0f) && (ay <= 0.0f) && (by >= 0.0f);
         float fmin = 3.0e38f;
 #pragma unroll
@@ -155,15 +156,15 @@ __device__ __forceinline__ int stage_chunk(TileShared<CHUNK>& sh, const TileList
           fmin = fminf(fmin, 0.5f * (cxx * ex * ex + cyy * ey * ey) + cxy * ex * ey);
         }
         // (a NaN anywhere fails `!(fmin > tau)`'s complement only by keeping the candidate)
-        hit[q] = hit[q] && (inside || !(fmin > tau));
+        if (!(inside || !(fmin > tau))) hits &= ~(1u << qd);
       }
     }
   }
   const unsigned w = tid >> 6;
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const u64 m = __ballot(hit[q]);
-    if ((tid & 63) == 0) sh.mask[q][w] = m;
+  for (int qd = 0; qd < 4; qd++) {
+    const u64 m = __ballot((hits >> qd) & 1u);
+    if ((tid & 63) == 0) sh.mask[qd][w] = m;
   }
   return id;
 }
@@ -228,13 +229,10 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
 #pragma unroll 1
     for (int pw = 0; pw < CHUNK / 64; pw++) {
       u64 m = uniform_u64(sh.mask[w][pw]);
-#define B3GS_FWD_CANDIDATE(j)                                                                            \
+#define B3GS_FWD_CANDIDATE(A, B, Cc, j)                                                                  \
       do {                                                                                               \
         if (TRACE) n_iter++;                                                                             \
         const int gidx = pw * 64 + (j);                                                                  \
-        const float4 A = sh.A[gidx];                                                                     \
-        const float4 B = sh.B[gidx];                                                                     \
-        const float4 Cc = sh.C[gidx];                                                                    \
         const float dx = A.x - fpx, dy = A.y - fpy;                                                      \
         const float power = blend_power(A, B.x, dx, dy);                                                 \
         const float alpha = fminf(B3GS_ALPHA_MAX, B.y * __expf(power));                                  \
@@ -257,7 +255,11 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
       while (m) {
         const int j = __builtin_ctzll(m);
         clear_bit(m, j);
-        B3GS_FWD_CANDIDATE(j);
+        {
+          const float4 A = sh.A[pw * 64 + j], B = sh.B[pw * 64 + j];
+          const float2 Cc = *reinterpret_cast<const float2*>(&sh.C[pw * 64 + j]);
+          B3GS_FWD_CANDIDATE(A, B, Cc, j);
+        }
         // "is any pixel of the quadrant still active" only after every B3GS_FWD_CHECK_EVERY-th candidate: a candidate
         // evaluated after the last pixel finished blends weight zero everywhere, and the check is a third of the loop's
         // scalar instructions (measured on MI355X, every 1 / 2 / 3 / 4 / 6 / 8: 282 / 278 / 274 / 273 / 273 / 275 us)
@@ -266,10 +268,14 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
           if (m == 0) break;
           const int j2 = __builtin_ctzll(m);
           clear_bit(m, j2);
-          B3GS_FWD_CANDIDATE(j2);
+          const float4 A = sh.A[pw * 64 + j2], B = sh.B[pw * 64 + j2];
+          const float2 Cc = *reinterpret_cast<const float2*>(&sh.C[pw * 64 + j2]);
+          B3GS_FWD_CANDIDATE(A, B, Cc, j2);
         }
         if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
       }
+      // (fetching the NEXT candidate's record before evaluating the current one -- the backward's scheme, two register sets
+      // swapping roles -- measured 285 vs 273 us here: the forward's step is too short for the extra control flow)
 #undef B3GS_FWD_CANDIDATE
       if (__builtin_amdgcn_ballot_w64(Tw != 0.0f) == 0) break;
     }
