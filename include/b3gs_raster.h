@@ -167,7 +167,9 @@ typedef struct B3gsForwardView {
   int32_t* device_num_rendered;  /* N = tile instances binned (segment 1 + segment 2) */
   int32_t depth_order_from;
   /* Two-round ("termination-aware") binning.  0 < seg1_fraction < 1: only the nearest ceil(seg1_fraction * P) Gaussians
-   * of the depth order are binned first (segment 1 of every tile list); the blend forward marks the tiles whose pixels
+   * of the depth order -- rounded UP to a whole number of the scan's 4096-Gaussian tiles; when that reaches P (always below
+   * 4097 Gaussians) the forward is binned in one round -- are binned first (segment 1 of every tile list); the blend
+   * forward marks the tiles whose pixels
    * all terminated inside it (T < 1e-4: nothing behind can contribute), and the remaining Gaussians are binned into the
    * OTHER tiles only (segment 2), which are then blended again over segment 1 + segment 2.  Images, n_contrib-relative
    * gradients and the order inside every list are those of one-round binning; only the instances no pixel could have
