@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_sums(ScanBatch sb) {
   __shared__ uint32_t s_list[SCAN_TILE];
   __shared__ uint32_t s_H;
   const ScanJob& job = sb.j[blockIdx.y];
-  const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
+  [[maybe_unused]] const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
   BIN_TRACE(0, twg, 0, BIN_NOW());
   BIN_TRACE(0, twg, 5, 0ull);
   if (job.partner == -2) return;   // this view's rects are gathered by its partner's workgroups
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void emit_instances_body(const EmitBatch& eb, uint32_
 template <bool ROUND2>
 __global__ void __launch_bounds__(256) emit_instances(EmitBatch eb) {
   __shared__ EmitShared sh;
-  const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
+  [[maybe_unused]] const uint32_t twg = blockIdx.y * gridDim.x + blockIdx.x;
   uint32_t bx = blockIdx.x, by = blockIdx.y;
   if (!ROUND2) {
     // round 1 is a 1-D grid: the list workgroups of ALL views first (they run longest and would otherwise start behind
