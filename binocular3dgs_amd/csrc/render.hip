@@ -179,6 +179,14 @@ __device__ __forceinline__ float blend_power(const float4& A, float cyy, float d
 // machine (one view's 1900 tiles fill it exactly once, so every launch paid its own tail:
 // measured 126 us for one view, 446 us for six in one launch).
 // `bid` = default block index (tile of a view, see select_view / tile_of_block); `slot` = where a trace record goes
+// sensitivity probes (tools only): extra instructions of one kind per candidate, to see which unit paces the loop
+#if defined(B3GS_FWD_SENS_SALU)
+#define B3GS_FWD_SENS asm volatile("s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1" ::: "s2", "scc")
+#elif defined(B3GS_FWD_SENS_VALU)
+#define B3GS_FWD_SENS asm volatile("v_add_u32 v60, v60, 1\n v_add_u32 v61, v61, 1\n v_add_u32 v62, v62, 1\n v_add_u32 v63, v63, 1" ::: "v60", "v61", "v62", "v63")
+#else
+#define B3GS_FWD_SENS do { } while (0)
+#endif
 #ifndef B3GS_FWD_CHECK_EVERY
 #define B3GS_FWD_CHECK_EVERY 4   /* candidates between two "is the quadrant finished" checks of the forward's hot loop */
 #endif
@@ -233,6 +241,7 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
       do {                                                                                               \
         if (TRACE) n_iter++;                                                                             \
         const int gidx = pw * 64 + (j);                                                                  \
+        B3GS_FWD_SENS;                                                                                   \
         const float dx = A.x - fpx, dy = A.y - fpy;                                                      \
         const float power = blend_power(A, B.x, dx, dy);                                                 \
         const float alpha = fminf(B3GS_ALPHA_MAX, B.y * __expf(power));                                  \
