@@ -481,6 +481,8 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[9] = wgt * px.dD;
 }
 
+// where the reduced component of Gaussian g goes (redefined by the quadrant kernel's row mode)
+#define B3GS_RED_ADDR(g) (red_base + __umul24((g), red_stride))
 // ---- the candidate step of the blend backward, shared by the tile-workgroup kernel and the quadrant-wave kernel below.
 // The macros use the surrounding kernel's locals: px, base, pending, q0..q3, pend_g, red_rd, red_base, red_stride,
 // red_writer, red_m0 and (TRACE) n_iter / n_live / n_lanes.
@@ -488,9 +490,15 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   do {                                                                                 \
     float v = ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));       \
     v += ((q2.x + q2.y) + (q2.z + q2.w)) + ((q3.x + q3.y) + (q3.z + q3.w));            \
-    v = dpp_add<0xB1, 0xF>(v); /* quad_perm [1,0,3,2] */                               \
-    v = dpp_add<0x4E, 0xF>(v); /* quad_perm [2,3,0,1] -> 4 parts of component rk */    \
-    if (red_writer) unsafeAtomicAdd(red_base + __umul24(pend_g, red_stride), v);       \
+    /* sum over the four parts of component rk: two fused DPP adds, quad_perm [1,0,3,2] then [2,3,0,1].  As inline */ \
+    /* asm: left to the compiler the second add sinks behind the writer branch and becomes v_mov + v_mov_dpp + v_add */ \
+    /* (a VALU write needs two wait states before a DPP read of the same register) */   \
+    asm("s_nop 1\n\t"                                                                   \
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+        "s_nop 1\n\t"                                                                   \
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" \
+        : "+v"(v));                                                                      \
+    if (red_writer) unsafeAtomicAdd(B3GS_RED_ADDR(pend_g), v);                         \
   } while (0)
 
   // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
@@ -720,7 +728,11 @@ struct WaveSharedBwd {
 // LDS reads.  The backward is bound by the LDS pipe -- per candidate and wave: 10 ds_write_addtid_b32 (2 cycles each) + 4
 // ds_read_b128 (8 each) of the reduction + 2 ds_read_b128 + 1 ds_read_b96 of the record (8 each, broadcast or not) = 76
 // cycles, x 4 SIMDs = 304 per CU and candidate-quad against the measured 290 -- so the record reads are a third of it.
-template <bool TRACE, int SC, bool REGS>
+// ROWS: every view's ten gradient components are one row of `row_len` floats per Gaussian (the fused path's scratch rows:
+// conic xx, xy, yy, depth | mean2D x, y | colour r, g, b | opacity at columns 0..9 of dL_dcov3D's array): the atomic's
+// address is  row array + (g * row_len + column) * 4  -- one scalar multiply and one vector add instead of a 24-bit
+// multiply, a sign extension and a 64-bit shift-add per candidate.
+template <bool TRACE, int SC, bool REGS, bool ROWS>
 __global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
     render_bwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ WaveSharedBwd<REGS ? 1 : SC> sh;
@@ -802,6 +814,12 @@ __global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
   else if (rk < 9) { red_base = dL_dcolors + (rk - 6); red_stride = bv.col_stride; }
   else { red_base = dL_dcov3D + 3; red_stride = cov_stride; }
   const bool red_writer = (rk < 10u) && (rpart == 0);
+  // row mode: column of this lane's component inside the Gaussian's row (see ROWS above)
+  const uint32_t red_col4 = 4u * (rk < 2 ? 4u + rk : (rk < 5 ? rk - 2u : (rk == 5 ? 9u : (rk < 9 ? rk : 3u))));
+  const uint32_t row_bytes = 4u * cov_stride;
+  char* const row0 = reinterpret_cast<char*>(dL_dcov3D);
+#undef B3GS_RED_ADDR
+#define B3GS_RED_ADDR(g) (ROWS ? reinterpret_cast<float*>(row0 + ((g) * row_bytes + red_col4)) : red_base + __umul24((g), red_stride))
   float* const red = sh.red;
   const uint32_t red_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)red);
   const float4* const red_rd = reinterpret_cast<const float4*>(red + (rk < 10 ? rk : 0) * RED_STRIDE + rpart * 16);
@@ -910,6 +928,7 @@ __global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
 #undef B3GS_BWD_CANDIDATE
 #undef B3GS_ROW_WRITES
 #undef B3GS_RETIRE_PENDING
+#undef B3GS_RED_ADDR
 
 #ifndef B3GS_FWD_CHUNK
 #define B3GS_FWD_CHUNK 256
@@ -1051,9 +1070,17 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   static const char* which = getenv("B3GS_BWD_KERNEL");
   const bool tile_wg = which && !strcmp(which, "tile"), wave_lds = which && !strcmp(which, "wave");
   if (!tile_wg) {
-    if (trace) hipLaunchKernelGGL((render_bwd_kernel<true, 64, true>), dim3(total * 4), dim3(64), 0, s, batch, trace);
-    else if (wave_lds) hipLaunchKernelGGL((render_bwd_kernel<false, 64, false>), dim3(total * 4), dim3(64), 0, s, batch, trace);
-    else hipLaunchKernelGGL((render_bwd_kernel<false, 64, true>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    bool rows = true;   // every view: one row per Gaussian holding the ten components at the scratch-row columns
+    for (int k = 0; k < batch.n; k++) {
+      const BlendView& v = batch.v[k];
+      rows = rows && v.m2d_stride == v.cov_stride && v.col_stride == v.cov_stride && v.op_stride == v.cov_stride &&
+             v.dL_dmeans2D == v.dL_dcov3D + 4 && v.dL_dcolors == v.dL_dcov3D + 6 && v.dL_dopacity == v.dL_dcov3D + 9 &&
+             (uint64_t)v.cov_stride * 4u * (uint64_t)(v.idx_mask == 0xFFFFFFFFu ? 0x7FFFFFFFu : v.idx_mask) < 0xFFFFFFFFull;
+    }
+    if (trace) hipLaunchKernelGGL((render_bwd_kernel<true, 64, true, false>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    else if (wave_lds) hipLaunchKernelGGL((render_bwd_kernel<false, 64, false, false>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    else if (rows) hipLaunchKernelGGL((render_bwd_kernel<false, 64, true, true>), dim3(total * 4), dim3(64), 0, s, batch, trace);
+    else hipLaunchKernelGGL((render_bwd_kernel<false, 64, true, false>), dim3(total * 4), dim3(64), 0, s, batch, trace);
     return;
   }
   if (trace) hipLaunchKernelGGL((render_bwd_tile_kernel<64, true>), dim3(total), dim3(256), 0, s, batch, trace);

@@ -43,7 +43,7 @@ def classify(seg):
 
 
 def main():
-    wanted = sys.argv[1:] or ["render_bwd_kernelILb0ELi64ELb1", "render_fwd_kernelILi256ELb0"]
+    wanted = sys.argv[1:] or ["render_bwd_kernelILb0ELi64ELb1ELb1", "render_fwd_kernelILi256ELb0"]
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "render.s")
         subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-S", "--cuda-device-only", os.path.join(ROOT, "binocular3dgs_amd/csrc/render.hip"),
