@@ -310,13 +310,24 @@ class Job:
         self.restore()
 
     def timed(self, steps):
-        """K steps between barriers; returns max-over-ranks seconds."""
-        self.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.run()
-        self.barrier()
-        elapsed = time.perf_counter() - t0
+        """K steps between barriers; returns max-over-ranks seconds.  The interpreter's cyclic garbage collector is kept
+        out of the timed loop the way `timeit` keeps it out (collected before, disabled inside): a generation-2 collection
+        is one 50-80 ms pause, i.e. most of a 5-step eager measurement (seen: the drop-in extra at 52 instead of 313 iters/s
+        in one run of three)."""
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.run()
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            if was_enabled:
+                gc.enable()
         if self.fused is not None and self.fused.check_overflow():
             raise SystemExit("binning capacity overflow inside the timed region: result invalid")
         if self.dp:
