@@ -730,9 +730,9 @@ def pmc_passes(args, result):
         roof["valu"] = {"bound": "valu issue slots: 256 CUs x 4 SIMDs, one plain fp32 wave64 instruction per 2 cycles "
                                  "(tools/ubench/valu_rate.hip); transcendental / DPP / LDS-path instructions occupy 8",
                         "isa_cross_check": "static count of the hot loops (tools/isa_count.py -> profiles/r03_final_isa_counts.txt): "
-                                           "backward (one wave per tile quadrant, records through the scalar cache) 74 VALU + "
-                                           "14 LDS + 26 SALU/SMEM per candidate, forward 30 VALU + 3 LDS + 15 SALU; x the "
-                                           "candidates per launch of tools/bwd_trace_batched.py (4.98M) = 369M of the ~385M "
+                                           "backward (one wave per tile quadrant, records through the scalar cache) 70 VALU + "
+                                           "14 LDS + 27 SALU/SMEM per candidate, forward 30 VALU + 3 LDS + 15 SALU; x the "
+                                           "candidates per launch of tools/bwd_trace_batched.py (4.98M) = 349M of the ~364M "
                                            "SQ_INSTS_VALU measured for the backward (the rest is staging)",
                         "frac": vd.get(roof["kernel"], {}).get("issue_frac"), "kernels": vd}
 
