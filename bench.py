@@ -272,8 +272,13 @@ class Job:
                 body()
             torch.cuda.current_stream().wait_stream(sg)
             graph = torch.cuda.CUDAGraph()
+            # With a process group alive its watchdog thread polls events while this thread captures: in the default
+            # ("global") capture mode such a call from ANOTHER thread fails there and aborts the process (seen once in
+            # ~12 runs of the 1-rank RCCL test: rc -6 out of ProcessGroupNCCL::Watchdog).  "thread_local" confines the
+            # capture's restrictions to the capturing thread.
+            mode = dict(capture_error_mode="thread_local") if self.dp else {}
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     body()
             except Exception as exc:
                 if not whole:
@@ -285,7 +290,7 @@ class Job:
                 torch.cuda.synchronize(self.dev)
                 body = lambda: st.compute_grads(**self.step_kw)   # noqa: E731
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     body()
             self.dp_graph = whole
             if self.dp and whole:
