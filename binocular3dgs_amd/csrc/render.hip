@@ -481,6 +481,16 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   p[9] = wgt * px.dD;
 }
 
+// sensitivity probes (tools only, like B3GS_FWD_SENS): four extra independent instructions of one kind per candidate
+#if defined(B3GS_BWD_SENS_SALU)
+#define B3GS_BWD_SENS asm volatile("s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1\n s_add_u32 s2, s2, 1" ::: "s2", "scc")
+#elif defined(B3GS_BWD_SENS_VALU)
+#define B3GS_BWD_SENS asm volatile("v_add_u32 v60, v60, 1\n v_add_u32 v61, v61, 1\n v_add_u32 v62, v62, 1\n v_add_u32 v63, v63, 1" ::: "v60", "v61", "v62", "v63")
+#elif defined(B3GS_BWD_SENS_LDS)
+#define B3GS_BWD_SENS asm volatile("ds_read_b128 v[60:63], %0\n s_waitcnt lgkmcnt(0)" :: "v"(0) : "v60", "v61", "v62", "v63", "memory")
+#else
+#define B3GS_BWD_SENS do { } while (0)
+#endif
 // where the reduced component of Gaussian g goes (redefined by the quadrant kernel's row mode)
 #define B3GS_RED_ADDR(g) (red_base + __umul24((g), red_stride))
 // ---- the candidate step of the blend backward, shared by the tile-workgroup kernel and the quadrant-wave kernel below.
@@ -504,6 +514,7 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
   // one candidate: evaluate, and if any pixel of the quadrant is touched, reduce + queue its partials
 #define B3GS_BWD_CANDIDATE(A, B, Cc, J)                                                          \
   do {                                                                                           \
+    B3GS_BWD_SENS;                                                                               \
     const float dx_ = A.x - px.fpx, dy_ = A.y - px.fpy;                                          \
     const float u_ = A.z * dx_, v_ = B.x * dy_, nw_ = -A.w * dx_;                                \
     /* == blend_power(): same products, same order (the forward must agree on every skip decision) */ \
