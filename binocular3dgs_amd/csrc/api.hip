@@ -295,6 +295,11 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
                                radii, device_num_rendered, 3, (hipStream_t)stream);
 }
 
+static int env_tight() {
+  static const int v = getenv("B3GS_NO_TIGHT") ? 0 : 1;   // (A/B switch, read once per process)
+  return v;
+}
+
 int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
                      int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
                      int32_t* radii, int32_t* device_num_rendered, int phases, b3gs_stream_t stream) {
@@ -304,7 +309,7 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
   sx.sc = *view;
   sx.raw = *params;
   sx.raw_mode = 1;
-  sx.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
+  sx.tight = env_tight();
   return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
                                device_num_rendered, phases, (hipStream_t)stream);
 }
@@ -321,7 +326,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   bb.cls_size = 0;
   pb.n = bb.n = nviews;
   pb.raw_mode = 1;
-  pb.tight = getenv("B3GS_NO_TIGHT") ? 0 : 1;
+  pb.tight = env_tight();
   for (int k = 0; k < nviews; k++) {
     const B3gsForwardView& fv = views[k];
     int rc = check_raw(fv.view, params);
@@ -336,6 +341,8 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     if (fv.depth_order_from != -1 &&
         (fv.depth_order_from < 0 || fv.depth_order_from >= nviews || views[fv.depth_order_from].depth_order_from != -1))
       return fail(B3GS_ERR_ARG, "%s", "depth_order_from must name a view of the batch that sorts its own keys");
+    if (fv.depth_order_hint && (fv.depth_order_from != -1 || !fv.hint_mismatch || fv.depth_order_hint == fv.geometry))
+      return fail(B3GS_ERR_ARG, "%s", "depth_order_hint needs depth_order_from == -1, a hint_mismatch word and another buffer");
     GeomView g;
     ImgView im;
     BinView b;
@@ -346,6 +353,15 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
     jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr,
                      nullptr, 1, 0, fv.high_water, fv.overflow_flag};
+    if (fv.depth_order_hint && sc.P > 0) {   // ABI 7: an earlier forward's depth order, adopted while every key is equal
+      GeomView hg;
+      b3gs_geom_view(const_cast<char*>(fv.depth_order_hint), sc.P, &hg);
+      pb.out[k].hint_key = hg.depth_key;
+      pb.out[k].hint_word = fv.hint_mismatch;
+      jobs[k].hint_sval = hg.sval[0];
+      jobs[k].hint_skey = hg.skey[0];
+      jobs[k].hint_word = fv.hint_mismatch;
+    }
     bb.v[k] = b3gs_blend_view(sc, g, b, im);
     bb.v[k].open_rows = im.open_rows;
     bb.v[k].out_color = fv.out_color;
@@ -379,7 +395,8 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   int32_t K1 = 0;
   {
     float frac = views[0].seg1_fraction;
-    if (const char* e = getenv("B3GS_SEG1_FRAC")) frac = (float)atof(e);
+    static const char* const frac_env = getenv("B3GS_SEG1_FRAC");   // (A/B switches: read once per process)
+    if (frac_env) frac = (float)atof(frac_env);
     if (frac > 0.0f && frac < 1.0f && P > 1 && !views[0].fresh_image) {
       K1 = (int32_t)((double)frac * (double)P + 0.999999);
       K1 = K1 < 1 ? 1 : K1;
@@ -392,7 +409,8 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     }
   }
   // three-pass depth sort on 27-bit keys: only with the caller's overflow word to report a key outside the span to
-  bool key27 = getenv("B3GS_NO_KEY27") == nullptr;   // (A/B switch)
+  static const bool key27_env = getenv("B3GS_NO_KEY27") == nullptr;   // (A/B switch)
+  bool key27 = key27_env;
   for (int k = 0; k < nviews; k++)
     key27 = key27 && views[k].depth_key_bits == 27 && views[k].overflow_flag != nullptr && !views[k].view->prefiltered;
   for (int k = 0; k < nviews; k++) {

@@ -243,6 +243,10 @@ struct PreOut {
                                    //   (rotated from pred_next by the previous forward's last kernel, render.hip)
   unsigned long long* pflag;       //   ... and where the per-Gaussian "reaches a predicted tile" bits go (GeomView::pflag)
   int32_t ntiles, nrowwords;
+  // ABI 7 (B3gsForwardView::depth_order_hint): the depth keys an earlier forward stored; a key of this view that differs
+  // sets *hint_word (then this view's own depth sort runs instead of adopting that forward's order)
+  const uint32_t* hint_key = nullptr;
+  int32_t* hint_word = nullptr;
 };
 struct PreBatch {
   int32_t n, raw_mode, tight;
@@ -291,6 +295,11 @@ struct BinJob {
   // 27: every visible depth key lies within 2^27 of the float bits of B3GS_NEAR (checked by the projection, which raises
   // bit 1 of overflow_flag otherwise): three 9-bit passes instead of four 8-bit ones.  0 / 32: the full 32-bit sort.
   int32_t key_bits = 0;
+  // ABI 7: depth order (sval[0]) and sorted keys (skey[0]) of an earlier forward, adopted while *hint_word == 0; the
+  // sort launches of this view exit at once then (order_from must be -1)
+  const uint32_t* hint_sval = nullptr;
+  const uint32_t* hint_skey = nullptr;
+  const int32_t* hint_word = nullptr;
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,

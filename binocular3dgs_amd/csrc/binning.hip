@@ -81,7 +81,13 @@ struct SortJob {
   // depth sort of a two-round forward: one bit per element (bit i of word i / 64) that the FIRST pass -- the one that
   // creates the values -- puts into bits 30 / 31 of the value, so that the flag travels with the order (ORDER_* below)
   const unsigned long long* flag[2];
+  // ABI 7 (depth sort of a view with a depth_order_hint): the job's launches run only when this word is non-zero (a depth
+  // key differed from the hinted forward's); while it is zero they exit at once and adopt_order_kernel copies the order
+  const int32_t* gate = nullptr;
 };
+__device__ __forceinline__ bool sort_job_idle(const SortJob& job) {
+  return job.gate && __builtin_nontemporal_load(job.gate) == 0;
+}
 // A depth order's words: Gaussian index | flags.  The flags say "the rect of this Gaussian reaches a tile that is predicted
 // open" for the view that owns the order (A) and for its binocular partner (B): the scan behind segment 1 reads them with
 // the order itself instead of gathering GeomView::pflag at a random index per lane (measured: that gather -- 6M separate L2
@@ -555,7 +561,7 @@ __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix_hist(Sor
   const SortJob& job = sb.j[blockIdx.y];
   const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
   const uint32_t blk0 = blockIdx.x * HIST_TILES;
-  if (blk0 >= job.nblk) return;
+  if (blk0 >= job.nblk || sort_job_idle(job)) return;
   const int shift = pass_shift + job.shift_base;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t* __restrict__ keys = job.kin + off;
@@ -578,6 +584,7 @@ __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix_hist(Sor
 
 __device__ __forceinline__ void radix_rowscan_body(const SortBatch& sb, uint32_t bx, uint32_t by, uint32_t* tmp) {
   const SortJob& job = sb.j[by];
+  if (sort_job_idle(job)) return;
   const uint32_t nblk = job.nblk;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
@@ -624,7 +631,7 @@ __device__ __forceinline__ void radix_scatter_body(const SortBatch& sb, int pass
   uint32_t (&s_val)[HAS_VAL ? B3GS_SORT_TILE : 1] = sh.s_val;
 
   const SortJob& job = sb.j[by];
-  if (bx >= job.nblk) return;
+  if (bx >= job.nblk || sort_job_idle(job)) return;
   const int shift = pass_shift + job.shift_base;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t* __restrict__ keys_in = job.kin + off;
@@ -758,7 +765,7 @@ __global__ void __launch_bounds__(HIST_TILES * B3GS_SORT_THREADS) radix9_hist(So
   const uint32_t sub = threadIdx.x >> 8, t = threadIdx.x & 255u;
   const uint32_t blk0 = blockIdx.x * HIST_TILES;
   const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
-  if (blk0 >= nblk) return;
+  if (blk0 >= nblk || sort_job_idle(job)) return;
   const uint32_t* __restrict__ keys = job.kin;
   const uint32_t n = job.n_cap;
   if ((uint64_t)blk0 * TILE >= n) return;
@@ -789,6 +796,7 @@ __global__ void __launch_bounds__(256) radix9_rowscan(SortBatch sb) {
   __shared__ uint32_t tmp[8];
   constexpr uint32_t TILE = ITEMS * B3GS_SORT_THREADS;
   const SortJob& job = sb.j[blockIdx.y];
+  if (sort_job_idle(job)) return;
   const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
   const uint32_t used = nblk;
   uint32_t* row = job.hist + (size_t)blockIdx.x * hist_stride(nblk);
@@ -815,7 +823,7 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
   __shared__ uint32_t s_val[TILE];
   const SortJob& job = sb.j[blockIdx.y];
   const uint32_t nblk = (job.n_cap + TILE - 1) / TILE;
-  if (blockIdx.x >= nblk) return;
+  if (blockIdx.x >= nblk || sort_job_idle(job)) return;
   const uint32_t* __restrict__ keys_in = job.kin;
   const uint32_t* __restrict__ vals_in = job.vin;
   uint32_t* __restrict__ keys_out = job.kout;
@@ -909,6 +917,50 @@ __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix9_scatter(SortBatch sb
       const uint32_t dst = gbase[d] + (p - blk_start[d]);
       keys_out[dst] = kk;
       vals_out[dst] = s_val[p];
+    }
+  }
+}
+
+// ABI 7: a view whose depth keys all equal those of an earlier forward (B3gsForwardView::depth_order_hint) takes that
+// forward's depth order instead of sorting: order words and sorted keys are copied (8 bytes read + 8 written per Gaussian,
+// ~4 us at 1M); in a two-round forward the predicted-tile flags of THIS view (and of its scan partner) replace the ones the
+// words carried.  Runs behind the gated sort launches; does nothing when the keys differed (the sort ran).
+struct AdoptJob {
+  const uint32_t* src_val;
+  const uint32_t* src_key;
+  uint32_t* dst_val;
+  uint32_t* dst_key;
+  const int32_t* word;                 // adopt while *word == 0
+  const unsigned long long* flag[2];   // null: no flags (one-round forward)
+  uint32_t n;
+};
+struct AdoptBatch {
+  int32_t n;
+  AdoptJob j[B3GS_MAX_FUSED_VIEWS];
+};
+__global__ void __launch_bounds__(256) adopt_order_kernel(AdoptBatch ab) {
+  const AdoptJob& job = ab.j[blockIdx.y];
+  if (__builtin_nontemporal_load(job.word) != 0) return;
+  const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (i >= job.n) return;
+  if (i + 4u <= job.n) {
+    uint4 v = *reinterpret_cast<const uint4*>(job.src_val + i);
+    const uint4 k = *reinterpret_cast<const uint4*>(job.src_key + i);
+    uint32_t w[4] = {v.x & ORDER_IDX, v.y & ORDER_IDX, v.z & ORDER_IDX, v.w & ORDER_IDX};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      if (job.flag[0] && ((job.flag[0][w[c] >> 6] >> (w[c] & 63u)) & 1ull)) w[c] |= ORDER_A;
+      if (job.flag[1] && ((job.flag[1][(w[c] & ORDER_IDX) >> 6] >> (w[c] & 63u)) & 1ull)) w[c] |= ORDER_B;
+    }
+    *reinterpret_cast<uint4*>(job.dst_val + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<uint4*>(job.dst_key + i) = k;
+  } else {
+    for (uint32_t e = i; e < job.n; e++) {
+      uint32_t w = job.src_val[e] & ORDER_IDX;
+      if (job.flag[0] && ((job.flag[0][w >> 6] >> (w & 63u)) & 1ull)) w |= ORDER_A;
+      if (job.flag[1] && ((job.flag[1][(w & ORDER_IDX) >> 6] >> (w & 63u)) & 1ull)) w |= ORDER_B;
+      job.dst_val[e] = w;
+      job.dst_key[e] = job.src_key[e];
     }
   }
 }
@@ -1320,6 +1372,8 @@ __global__ void __launch_bounds__(256) tile_ranges(RangeBatch rb) {
 // ---------------------------------------------------------------------------------------------
 constexpr int REPAIR_GRID = 256;
 struct RepairArgs {
+  int32_t* overflow[B3GS_MAX_FUSED_VIEWS];   // every view's sticky overflow word (may be null): bit 2 <- barrier time-out
+  uint32_t spin_limit;                       // polls of one barrier before the launch gives up
   Scan2Batch sc;
   EmitBatch eb;
   SortBatch tb[2];          // tile-split passes (in / out already swapped for pass 1; ranges set on the last one)
@@ -1328,7 +1382,11 @@ struct RepairArgs {
   uint32_t* barrier;        // [2] arrival counter (zeroed by scan_chunk_offsets of the same forward) | status (bit 0: time-out)
 };
 
-__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target) {
+// counter[0] = arrivals of this forward's launch (reset by the forward's first scan); its top bit is raised by the
+// workgroup that gives up: every workgroup still polling -- or arriving later, when the grid was not co-resident -- then
+// leaves at once instead of waiting out its own limit
+constexpr uint32_t BARRIER_GAVE_UP = 0x80000000u;
+__device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target, uint32_t spin_limit) {
   __shared__ uint32_t s_ok;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1336,9 +1394,16 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* counter, uint32_t target)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0, ok = 1;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    for (;;) {
+      const uint32_t c = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c & BARRIER_GAVE_UP) { ok = 0; break; }
+      if (c >= target) break;
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 22)) { ok = 0; break; }   // seconds: a workgroup of the grid never became resident
+      if (++spins > spin_limit) {   // ~1 s at the default limit: a workgroup of the grid never became resident
+        __hip_atomic_fetch_or(counter, BARRIER_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
@@ -1390,11 +1455,19 @@ __global__ void __launch_bounds__(256) repair_kernel(RepairArgs ra) {
   uint32_t phase = 0;
   bool ok = true;
   if (wg == 0 && threadIdx.x == 0) ra.barrier[2] += 1u;   // forwards whose prediction missed (the host watches the rate)
+  // A time-out leaves the repaired tiles of this forward wrong: besides the status word (read by the host at its next
+  // check) every view's sticky overflow word gets bit 2, so that b3gs_adam_step(skip_if_nonzero) and the densification
+  // statistics drop this step ON THE DEVICE like a step rendered from truncated lists.
+  if (__hip_atomic_load(ra.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & BARRIER_GAVE_UP) return;   // a late workgroup of a grid that gave up
 #define REPAIR_SYNC()                                                   \
   do {                                                                  \
-    ok = ok && grid_barrier(ra.barrier, ++phase * G);                   \
+    ok = ok && grid_barrier(ra.barrier, ++phase * G, ra.spin_limit);    \
     if (!ok) {                                                          \
-      if (threadIdx.x == 0) atomicOr(ra.barrier + 1, 1u);               \
+      if (threadIdx.x == 0) {                                           \
+        atomicOr(ra.barrier + 1, 1u);                                   \
+        for (int v = 0; v < ra.sc.n; v++)                               \
+          if (ra.overflow[v]) atomicOr(ra.overflow[v], 4);              \
+      }                                                                 \
       return;                                                           \
     }                                                                   \
   } while (0)
@@ -1509,6 +1582,8 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   //         the 27-bit key span (BinJob::key_bits == 27) -- 3 passes of 9 bits  depth_key -> [0] -> [1] -> [0]
   SortBatch db;
   db.n = 0;
+  AdoptBatch adopt;
+  adopt.n = 0;
   const uint32_t pblk = b3gs_sort_blocks((int64_t)P);
   bool span27 = true;
   for (int v = 0; v < nviews; v++) span27 = span27 && jobs[v].key_bits == 27;
@@ -1526,6 +1601,12 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
       sj.flag[0] = g.pflag;
       sj.flag[1] = pv >= 0 ? jobs[pv].g.pflag : nullptr;
     }
+    if (jobs[v].hint_sval && jobs[v].hint_word) {   // adopt an earlier forward's order while the keys are equal
+      sj.gate = jobs[v].hint_word;
+      AdoptJob& aj = adopt.j[adopt.n++];
+      aj = AdoptJob{jobs[v].hint_sval, jobs[v].hint_skey, g.sval[0], g.skey[0], jobs[v].hint_word, {sj.flag[0], sj.flag[1]},
+                    (uint32_t)P};
+    }
   }
   for (int pass = 0; pass < npass; pass++) {
     if (span27) radix9_pass(db, 9 * pass, pass == 0, s);
@@ -1542,6 +1623,8 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
       j.vout = g.sval[src ^ 1];
     }
   }
+  if (adopt.n > 0)
+    hipLaunchKernelGGL(adopt_order_kernel, dim3((P + 1023) / 1024, adopt.n), dim3(256), 0, s, adopt);
 
   // ---- 2. scan of tiles_touched in depth order -> soffs, N, V (segment 1 = the first K1 Gaussians of the order)
   const int total_tiles = (P + SCAN_TILE - 1) / SCAN_TILE;
@@ -1671,6 +1754,35 @@ void b3gs_launch_tile_lists_batch(int32_t P, int nviews, const BinJob* jobs, hip
   if (passes == 0) hipLaunchKernelGGL(tile_ranges, dim3((max_cap + 255) / 256, nviews), dim3(256), 0, s, rb);
 }
 
+// The persistent repair launch needs ALL its workgroups resident at once (software grid barrier).  Its size is what the
+// device this process sees can hold -- the runtime's occupancy answer for the kernel times the CU count of the current
+// device (a partitioned or CU-masked MI355X reports fewer CUs) -- capped at one workgroup per CU of a whole part; 0 = the
+// barrier cannot be used here (the multi-launch round runs instead).  Co-resident kernels of OTHER streams or processes
+// (RCCL's persistent kernels, a second rank sharing the GPU) are not visible to that query: the barrier's bounded spin and
+// the sticky time-out word (bit 2 of the overflow word) cover them.  B3GS_REPAIR_GRID / B3GS_REPAIR_SPINS: test overrides.
+static int repair_grid(bool has_val) {
+  static int cached[2][16] = {};   // [has_val][device] : 0 = not asked yet, -1 = unusable
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return REPAIR_GRID;
+  int& c = cached[has_val ? 1 : 0][dev];
+  if (c == 0) {
+    static const char* force = getenv("B3GS_REPAIR_GRID");
+    int per_cu = 0, cus = 0;
+    hipError_t e = has_val ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, repair_kernel<true>, 256, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, repair_kernel<false>, 256, 0);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 1; cus = REPAIR_GRID; }
+    const long resident = (long)per_cu * (long)cus;
+    c = resident >= 32 ? (int)(resident < REPAIR_GRID ? resident : REPAIR_GRID) : -1;
+    if (force && atoi(force) > 0) c = atoi(force);
+  }
+  return c;
+}
+static uint32_t repair_spin_limit() {
+  static const uint32_t v = getenv("B3GS_REPAIR_SPINS") ? (uint32_t)strtoul(getenv("B3GS_REPAIR_SPINS"), nullptr, 10) : (1u << 22);
+  return v;
+}
+
 void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s) {
   if (nviews <= 0 || P <= 0) return;
   const int K1 = b3gs_seg1_count(jobs[0], P);
@@ -1694,7 +1806,12 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
                        (uint32_t)(jb.n_bound > 0 ? (jb.n_bound < 0xFFFFFFFFll ? jb.n_bound : 0xFFFFFFFFll) : 0)};
   }
   static const bool legacy = getenv("B3GS_ROUND2_LEGACY") != nullptr;
-  const bool one_launch = !legacy && passes >= 1 && passes <= 2 && jobs[0].im.header != nullptr;
+  bool one_launch = !legacy && passes >= 1 && passes <= 2 && jobs[0].im.header != nullptr;
+  if (one_launch) {   // (the value-carrying variant is the larger kernel: if it fits, the other one does)
+    bool two_words = false;
+    for (int v = 0; v < nviews; v++) two_words = two_words || b3gs_packed_idx_bits(P, jobs[v].W, jobs[v].H) < 0;
+    one_launch = repair_grid(two_words) > 0;
+  }
   if (!one_launch) {
     hipLaunchKernelGGL(scan2_chunk_sums, dim3(sc.nchunks, nviews), dim3(SCAN_THREADS), 0, s, sc);
     hipLaunchKernelGGL(scan2_chunk_offsets, dim3(nviews), dim3(SCAN_THREADS), 0, s, sc);
@@ -1768,9 +1885,12 @@ void b3gs_launch_round2_batch(int32_t P, int nviews, const BinJob* jobs, hipStre
       }
     }
     ra.barrier = jobs[0].im.header + B3GS_HDR_REPAIR_BARRIER;
+    for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++) ra.overflow[v] = v < nviews ? jobs[v].overflow_flag : nullptr;
+    ra.spin_limit = repair_spin_limit();
     static_assert(sizeof(RepairArgs) <= 4000, "kernel arguments of the repair kernel");
-    if (any_val) hipLaunchKernelGGL(repair_kernel<true>, dim3(REPAIR_GRID), dim3(256), 0, s, ra);
-    else hipLaunchKernelGGL(repair_kernel<false>, dim3(REPAIR_GRID), dim3(256), 0, s, ra);
+    const int grid = repair_grid(any_val);
+    if (any_val) hipLaunchKernelGGL(repair_kernel<true>, dim3(grid), dim3(256), 0, s, ra);
+    else hipLaunchKernelGGL(repair_kernel<false>, dim3(grid), dim3(256), 0, s, ra);
     return;
   }
   hipLaunchKernelGGL(emit_instances<true>, dim3((rest + 255) / 256, nviews), dim3(256), 0, s, eb);

@@ -993,7 +993,8 @@ void b3gs_launch_blend_forward(BlendBatch batch, hipStream_t s) {
                        batch, total);
     return;
   }
-  if (getenv("B3GS_FWD_TRACE"))  // debug: per-wave cycle trace (tools/bwd_trace.py fwd)
+  static const bool fwd_trace = getenv("B3GS_FWD_TRACE") != nullptr;   // (debug switches: read once per process)
+  if (fwd_trace)  // debug: per-wave cycle trace (tools/bwd_trace.py fwd)
     hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, true>), dim3(total), dim3(256), 0, s, batch, trace_buffer(total));
   else
     hipLaunchKernelGGL((render_fwd_kernel<FWD_CHUNK, false>), dim3(total), dim3(256), 0, s, batch, nullptr);
@@ -1073,7 +1074,8 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
     batch.order = order;
   }
   // B3GS_BWD_TRACE=1: per-wave {cycles, wall start|end, iterations, live iterations} (tools/bwd_trace.py)
-  unsigned long long* trace = getenv("B3GS_BWD_TRACE") ? trace_buffer(total) : nullptr;
+  static const bool bwd_trace = getenv("B3GS_BWD_TRACE") != nullptr;
+  unsigned long long* trace = bwd_trace ? trace_buffer(total) : nullptr;
   // B3GS_BWD_CHUNK (64/128/256) is a tuning knob for experiments; 64 measured best on MI355X
   static const int bwd_chunk = getenv("B3GS_BWD_CHUNK") ? atoi(getenv("B3GS_BWD_CHUNK")) : BWD_CHUNK;
   // default: one wave per workgroup (quadrant), records through the scalar cache; B3GS_BWD_KERNEL=tile selects the

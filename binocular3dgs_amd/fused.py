@@ -222,7 +222,7 @@ class FusedRasterizer:
                     arr[k].seg1_fraction = self.seg1_fraction
                     arr[k].high_water = self.high_water[sp["slot"]:sp["slot"] + 1].data_ptr()
                     arr[k].overflow_flag = self.overflow_flag.data_ptr()
-                    arr[k].depth_key_bits = self.depth_key_bits
+                    arr[k].depth_key_bits = sp.get("key_bits", self.depth_key_bits)
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
@@ -310,14 +310,19 @@ class FusedRasterizer:
         return self.render_batch([(viewpoint_camera, slot)], bg_color, scaling_modifier, debug)[0]
 
     def render_batch(self, views: Sequence, bg_color: torch.Tensor, scaling_modifier: float = 1.0,
-                     debug: bool = False) -> List[dict]:
+                     debug: bool = False, _span_checked: bool = False) -> List[dict]:
         """Render [(camera, slot[, densify_stats]), ...]: binning concurrently (one stream per slot), then
         one blend launch; the outputs live on the current stream.  Views with densify_stats=True feed
         the model's densification statistics (init_densification_stats), as the primary view does at
         train.py:178-179.  All views of the call form ONE autograd node."""
         m = self.model
+        # The three-pass depth sort rests on a CHECKED key span whose verdict sits in the overflow word until somebody reads
+        # it (check_overflow(): the training step's protocol).  A render nobody will differentiate -- evaluation, a viewer --
+        # has no such reader: it sorts all 32 key bits (fit_capacity() reads the word itself and keeps the three passes).
+        key_bits = self.depth_key_bits if (torch.is_grad_enabled() or _span_checked) else 0
         specs = tuple({"cam": v[0], "slot": int(v[1]), "densify_stats": bool(v[2]) if len(v) > 2 else False,
-                       "bg": bg_color, "scaling_modifier": scaling_modifier, "debug": debug} for v in views)
+                       "bg": bg_color, "scaling_modifier": scaling_modifier, "debug": debug, "key_bits": key_bits}
+                      for v in views)
         assert len({sp["slot"] for sp in specs}) == len(specs), "each view of a batch needs its own slot"
         flat = _RasterizeBatch.apply(m._xyz, m._features_dc, m._features_rest, m._scaling, m._rotation, m._opacity,
                                      self, specs)
@@ -395,12 +400,19 @@ class FusedRasterizer:
         hw = int(self.high_water.max().item())
         flag = int(self.overflow_flag.item())
         self.high_water.zero_()
-        self._check_repair_status()
-        if hw <= self.capacity and not flag:
+        timed_out = self._check_repair_status()
+        if hw <= self.capacity and not flag and not timed_out:
             return 0
         self.overflow_flag.zero_()
         if flag & 2:                    # a depth key outside the 27-bit span: sort all 32 bits from now on
             self.depth_key_bits = 0
+        if (flag & 4) or timed_out:
+            # the second binning round's persistent launch timed out at its grid barrier (its workgroups were not resident
+            # together: a shared / partitioned device, co-resident persistent kernels): the repaired tiles of that forward
+            # were wrong and the step was dropped on the device (bit 2 of the overflow word); one round from now on
+            self.seg1_fraction = 0.0
+            self._seg1_auto = False
+            self.two_round_disabled = "grid-barrier time-out of the second binning round"
         if hw > self.capacity or (flag & 1):
             self.grow(need=hw)
         return max(hw, 1)
@@ -416,9 +428,10 @@ class FusedRasterizer:
 
     def _check_repair_status(self):
         """Word 9 of slot 0's image header: bit 0 is set when a grid barrier of the second binning round's persistent
-        kernel timed out (a workgroup of its grid never became resident) -- that forward's repaired tiles are wrong."""
+        kernel timed out (a workgroup of its grid never became resident) -- that forward's repaired tiles are wrong; the
+        kernel also raised bit 2 of the overflow word, so the step was dropped on the device.  Returns that bit (cleared)."""
         if self.seg1_fraction <= 0.0 or not self.slots:
-            return
+            return False
         # the rule's safety net: two rounds pay only while the prediction holds (the repair round's slow path costs about
         # twice what the second round of one-launch-per-stage binning did).  Cameras that change too much from one forward
         # of a slot to the next make it miss; when more than `two_round_max_miss_rate` of the forwards since the last check
@@ -431,8 +444,7 @@ class FusedRasterizer:
         st = int(self.slots[0].img[:48].view(torch.int32)[9].item())
         if st:
             self.slots[0].img[:48].view(torch.int32)[9] = 0
-            raise _lib.B3gsError("B3GS_ERR_HIP: the second binning round's grid barrier timed out; repeat the steps since "
-                                 "the last check (FusedRasterizer(seg1_fraction=0) selects one-round binning)")
+        return bool(st)
 
     def fit_capacity(self, views: Sequence, bg_color: torch.Tensor, margin: float = 1.3) -> int:
         """Size the persistent binning buffers from the actual N of `views` ([(camera, slot), ...]): one forward without
@@ -440,7 +452,7 @@ class FusedRasterizer:
         capacity follows the scene the way the reference's per-render allocation does."""
         frac, self.seg1_fraction = self.seg1_fraction, 0.0      # one round: the N of the complete lists
         with torch.no_grad():
-            self.render_batch([(v[0], v[1]) for v in views], bg_color)
+            self.render_batch([(v[0], v[1]) for v in views], bg_color, _span_checked=True)
         need = max(self.num_rendered())
         self.high_water.zero_()
         if int(self.overflow_flag.item()) & 2:     # a depth key outside the 27-bit span: sort all 32 bits from now on
@@ -454,6 +466,6 @@ class FusedRasterizer:
                               else min(0.125, max(0.02, 0.75e6 / need))) if self._seg1_auto else frac
         if self.seg1_fraction > 0.0:
             with torch.no_grad():     # one forward settles the open-tile prediction (the first one repairs many tiles)
-                self.render_batch([(v[0], v[1]) for v in views], bg_color)
+                self.render_batch([(v[0], v[1]) for v in views], bg_color, _span_checked=True)
             self.high_water.zero_()
         return self.capacity

@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import atexit
 import os
+import weakref
 from typing import NamedTuple, Optional
 
 import torch
@@ -391,8 +392,16 @@ class _RasterizeGaussians(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------------
 # render() handed a GaussianModel: one autograd node on the RAW parameters
 # ---------------------------------------------------------------------------------------------------------------
+# B3GS_DROPIN_INPLACE_GRADS=0: the node always returns its gradients to autograd (no self-accumulation, no batching of
+# the backward of several renders); B3GS_DROPIN_ORDER_HINT=0: every render sorts its own depth keys
 _INPLACE_GRADS = os.environ.get("B3GS_DROPIN_INPLACE_GRADS", "1") != "0"
-_raw_scratch = {}     # (device index, P) -> zeroed [P * 10] floats, left clean by every backward (b3gs_backward_raw_accumulate)
+_ORDER_HINT = os.environ.get("B3GS_DROPIN_ORDER_HINT", "1") != "0"
+_raw_scratch = {}     # (device index, P) -> list of zeroed [P * 10] float buffers, one per view of a batched backward; left
+                      #                      clean by every backward (b3gs_backward_raw_accumulate)
+_zero_m2d = {}        # (device index, P) -> zeros [P, 3]: storage behind every render's `viewspace_points` leaf
+_order_hint = {}      # device index -> the last raw forward: dict(P, key_bits, geom, xyz_ptr, xyz_version)
+_last_raw_ctx = {}    # device index -> weakref of the last DIFFERENTIATED raw forward's node (+ what it rendered)
+_stats = {"hinted": 0, "deferred": 0, "batched_views": 0, "launches": 0}   # (tests / bench read these)
 
 
 def raw_model_ok(pc) -> bool:
@@ -409,19 +418,191 @@ def raw_model_ok(pc) -> bool:
         return False
 
 
-_word_ring = {}       # device index -> [zeroed int32 ring, next pair]
+_word_ring = {}       # device index -> [zeroed int32 ring, next slot]
+
+
+def _dev_index(dev) -> int:
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def _zero_words(dev):
-    """Two zeroed int32 words on `dev` without a fill kernel per render: pairs of a ring that is zeroed once per lap (a
-    pair handed out is read by the host long before the ring comes round: 4096 renders later)."""
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    """Four zeroed int32 words on `dev` without a fill kernel per render ([N, overflow word, depth-key mismatch, spare]):
+    slots of a ring that is zeroed once per lap (a slot handed out is read by the host long before the ring comes round:
+    4096 renders later)."""
+    idx = _dev_index(dev)
     ent = _word_ring.get(idx)
     if ent is None or ent[1] >= ent[0].shape[0]:
-        ent = _word_ring[idx] = [torch.zeros((4096, 2), dtype=torch.int32, device=dev), 0]
+        ent = _word_ring[idx] = [torch.zeros((4096, 4), dtype=torch.int32, device=dev), 0]
     w = ent[0][ent[1]]
     ent[1] += 1
     return w
+
+
+def viewspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
+    """render()'s `screenspace_points` (gaussian_renderer/__init__.py:26-30: zeros whose .grad receives the screen-space
+    gradient): a fresh LEAF per render over one shared block of zeros per (device, P) -- its values are never read or
+    written by anybody, so the 12 bytes per Gaussian are not filled again for every render."""
+    key = (_dev_index(xyz.device), xyz.shape[0])
+    z = _zero_m2d.get(key)
+    if z is None:
+        if len(_zero_m2d) > 4:
+            _zero_m2d.clear()
+        z = _zero_m2d[key] = torch.zeros((xyz.shape[0], 3), dtype=torch.float32, device=xyz.device)
+    return z.detach().requires_grad_(True)
+
+
+class _RawJob:
+    """One render's backward, ready to be launched: its node, what the node saved, its pixel gradients."""
+    __slots__ = ("ctx", "saved", "gc", "gd", "ga", "stream", "needs_m2d", "m2d_leaf")
+
+    def __init__(self, ctx, gc, gd, ga):
+        self.ctx, self.saved, self.gc, self.gd, self.ga = ctx, ctx.saved_tensors, gc, gd, ga
+        self.stream = torch.cuda.current_stream(gc.device)
+        self.needs_m2d = bool(ctx.needs_input_grad[6])
+        self.m2d_leaf = ctx.m2d_leaf
+
+
+def _leaf_accumulates(node, t) -> bool:
+    """Will the engine run `t`'s AccumulateGrad in THIS backward, with nothing hooked to the gradient?  (False under
+    torch.autograd.grad(), for an input left out of backward(inputs=...), for a non-leaf, for hooked tensors.)"""
+    if node is None or type(node).__name__ != "AccumulateGrad" or getattr(node, "variable", None) is not t:
+        return False
+    try:
+        if not torch._C._will_engine_execute_node(node):
+            return False
+    except RuntimeError:      # "a leaf node was passed ... but we are currently running autograd.grad()"
+        return False
+    if t._backward_hooks or getattr(t, "_post_accumulate_grad_hooks", None):
+        return False
+    g = t.grad
+    return g is None or (g.dtype == torch.float32 and g.shape == t.shape and g.is_contiguous() and g.device == t.device
+                         and g.layout == torch.strided and not g.requires_grad)
+
+
+def _self_accumulate_ok(ctx, params) -> bool:
+    """May this node add its gradients to `.grad` itself (what the six AccumulateGrad nodes behind it would do, minus one
+    pass over 92 bytes per Gaussian per render -- and the precondition for launching the backward of several renders as
+    one batch)?  Only inside a plain accumulating backward(): every parameter a leaf whose AccumulateGrad the engine is
+    going to execute in this graph task, no hooks, no create_graph.  torch.autograd.grad(), backward(inputs=[...]) without
+    all six, hooked parameters, double backward: the gradients are RETURNED to autograd like the reference's."""
+    if not _INPLACE_GRADS or torch.is_grad_enabled() or not all(ctx.needs_input_grad[:6]):
+        return False
+    nf = ctx.next_functions
+    if not all(_leaf_accumulates(nf[i][0], t) for i, t in enumerate(params)):
+        return False
+    return (not ctx.needs_input_grad[6]) or _leaf_accumulates(nf[6][0], ctx.m2d_leaf)
+
+
+_task_cb = {"task": None, "streams": [], "flush": []}
+
+
+def _end_of_backward():
+    """Final callback of the graph task (runs on the caller's ambient streams, after the engine has synchronised them with
+    the streams of the leaves IT accumulated): launch what is still deferred -- a node that was expected to run in this
+    backward and did not -- and make the caller's stream wait for the streams this module wrote `.grad` on."""
+    flush, streams = _task_cb["flush"], _task_cb["streams"]
+    _task_cb["task"], _task_cb["flush"], _task_cb["streams"] = None, [], []
+    for ref in flush:
+        node = ref()
+        jobs = getattr(node, "pending", None) if node is not None else None
+        if jobs:
+            node.pending = []
+            _launch_backward(jobs, True)
+    for st in streams:
+        cur = torch.cuda.current_stream(st.device)
+        if cur != st:
+            cur.wait_stream(st)
+
+
+def _register_task(stream=None, flush_ref=None):
+    task = torch._C._current_graph_task_id()
+    if _task_cb["task"] != task:
+        _task_cb["task"], _task_cb["streams"], _task_cb["flush"] = task, [], []
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+    if stream is not None and stream not in _task_cb["streams"]:
+        _task_cb["streams"].append(stream)
+    if flush_ref is not None:
+        _task_cb["flush"].append(flush_ref)
+
+
+def _launch_backward(jobs, self_acc):
+    """Blend backward + per-Gaussian chain rule of `jobs` (renders of the SAME parameter tensors), at most 8 views per
+    launch.  self_acc: the gradients are added to (or become) `.grad` of the parameters and of every render's
+    `viewspace_points` leaf, nothing is returned; otherwise (one job) fresh tensors are returned for autograd."""
+    L = _lib.lib()
+    ctx0 = jobs[0].ctx
+    params = jobs[-1].saved[:6]
+    dev, P = params[0].device, params[0].shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    skey = (_dev_index(dev), P)
+    pool = _raw_scratch.get(skey)
+    if pool is None:
+        if len(_raw_scratch) > 4:
+            _raw_scratch.clear()
+        pool = _raw_scratch[skey] = []
+    cur = torch.cuda.current_stream(dev)
+    for j in jobs:
+        if j.stream != cur:
+            cur.wait_stream(j.stream)       # pixel gradients produced on another stream (deferred from another node)
+    if self_acc:
+        missing = [t.grad is None for t in params]
+        overwrite = all(missing)
+        grads = []
+        for t, m in zip(params, missing):
+            if m:
+                t.grad = torch.empty_like(t) if overwrite else torch.zeros_like(t)
+            grads.append(t.grad)
+        _register_task(stream=cur)
+    else:
+        assert len(jobs) == 1
+        overwrite = True
+        grads = [torch.empty_like(t) for t in params]
+    gr = _lib.B3gsRawGrads()
+    gr.xyz, gr.features_dc = grads[0].data_ptr(), grads[1].data_ptr()
+    gr.features_rest = grads[2].data_ptr() if grads[2].numel() else None
+    gr.scaling, gr.rotation, gr.opacity = grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr()
+    gr.touched_rows = None
+    m2d_out = []
+    with torch.cuda.device(dev):
+        s = _stream(dev)
+        for c0 in range(0, len(jobs), 8):
+            chunk = jobs[c0:c0 + 8]
+            n = len(chunk)
+            while len(pool) < n:
+                pool.append(torch.zeros((max(L.b3gs_backward_scratch_floats(P), 1),), **f32))
+            bv = (_lib.B3gsBlendView * n)()
+            av = (_lib.B3gsFusedView * n)()
+            for k, j in enumerate(chunk):
+                radii, geom, binning, img = j.saved[6:10]
+                g_m2d = torch.empty((P, 3), **f32) if j.needs_m2d else None
+                m2d_out.append(g_m2d)
+                bv[k].view = C.pointer(j.ctx.sc)
+                bv[k].geometry, bv[k].binning, bv[k].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
+                bv[k].dL_dcolor = j.gc.data_ptr()
+                bv[k].dL_ddepth = None if j.gd is None else j.gd.data_ptr()
+                bv[k].dL_dalpha = None if j.ga is None else j.ga.data_ptr()
+                bv[k].scratch, bv[k].binning_capacity = pool[k].data_ptr(), j.ctx.cap
+                av[k].view = C.pointer(j.ctx.sc)
+                av[k].radii, av[k].geometry, av[k].scratch = radii.data_ptr(), geom.data_ptr(), pool[k].data_ptr()
+                av[k].dL_dmeans2D = None if g_m2d is None else g_m2d.data_ptr()
+                av[k].densify_stats = 0
+            _lib.check(L.b3gs_blend_backward_batch(n, bv, s), "b3gs_blend_backward_batch")
+            # overwrite mode: every row of every gradient tensor is stored (zeros for Gaussians without a contribution);
+            # accumulate mode: only the rows that received something are touched
+            _lib.check(L.b3gs_backward_raw_accumulate(n, av, C.byref(ctx0.rp), C.byref(gr), 1 if (overwrite and c0 == 0) else 0,
+                                                      None, s), "b3gs_backward_raw_accumulate")
+            _stats["launches"] += 1
+            _stats["batched_views"] += n
+    if self_acc:
+        for j, g in zip(jobs, m2d_out):
+            if g is not None:
+                leaf = j.m2d_leaf
+                if leaf.grad is None:
+                    leaf.grad = g
+                else:
+                    leaf.grad += g
+        return None
+    return grads, m2d_out[0]
 
 
 class _RasterizeRaw(torch.autograd.Function):
@@ -429,8 +610,17 @@ class _RasterizeRaw(torch.autograd.Function):
     get_features: ~30 PyTorch kernels with their autograd per render) run inside the projection and chain-rule kernels
     (b3gs_forward_raw_batch / b3gs_backward_raw_accumulate), the depth sort takes three passes, and the Gaussians are
     binned into the tiles their alpha >= 1/255 footprint reaches (same images; `_C.rasterize_gaussians` keeps the
-    reference's binning rule and bit-exact lists).  Gradients are RETURNED to autograd (they land in `.grad` of the six
-    parameters and of the `means2D` dummy exactly like the reference's), not written behind its back."""
+    reference's binning rule and bit-exact lists).
+
+    What an unchanged train.py:100,128 gets on top of that (the input view and its shifted partner are two render()
+    calls of one iteration):
+      * forward -- the second render adopts the depth order of the first: its view matrix has the same z row (the shift
+        is along the camera x axis, scene/__init__.py:96-115), so every depth key is equal; the library CHECKS that on the
+        device (B3gsForwardView::depth_order_hint) and sorts itself when a key differs, so the answer never depends on it;
+      * backward -- inside a plain accumulating `loss.backward()` the nodes of renders of the same parameters hand their
+        work down the chain (the engine runs the later render first) and the earliest one launches ONE blend backward and
+        ONE chain-rule pass for all of them, adding into `.grad` what the AccumulateGrad nodes would have added.  Under
+        torch.autograd.grad(), backward(inputs=...), hooks, create_graph the gradients are returned per node."""
 
     @staticmethod
     def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, means2D, cfg):
@@ -448,7 +638,8 @@ class _RasterizeRaw(torch.autograd.Function):
         rp.scaling, rp.rotation, rp.opacity = scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr()
         u8 = dict(dtype=torch.uint8, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        key = ("raw", dev.index if dev.index is not None else torch.cuda.current_device(), P, W, H)
+        di = _dev_index(dev)
+        key = ("raw", di, P, W, H)
         lazy = bool(cfg["differentiated"]) and _lazy.enabled and not cfg["debug"]
         if lazy:
             _lazy.poll()
@@ -459,9 +650,16 @@ class _RasterizeRaw(torch.autograd.Function):
         color, depth, alpha = torch.empty((3, H, W), **f32), torch.empty((1, H, W), **f32), torch.empty((1, H, W), **f32)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         cap = _lazy.capacity.get(key) or max(1 << 20, 12 * P)
+        # the previous raw forward of the same position tensor (same storage, same version counter): probably the same
+        # Gaussians -- its depth order is offered to the library, which verifies key by key
+        hint = _order_hint.get(di) if _ORDER_HINT else None
+        stream_id = _stream(dev)
+        if hint is not None and not (hint["P"] == P and hint["key_bits"] == _lazy.key_bits and hint["stream"] == stream_id and
+                                     hint["xyz"] == (xyz.data_ptr(), xyz._version) and hint["geom"].numel() == geom.numel()):
+            hint = None
         while True:
             binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
-            words = _zero_words(dev)                                       # [N, overflow word], zero
+            words = _zero_words(dev)                                       # [N, overflow word, key mismatch, spare], zero
             fv = (_lib.B3gsForwardView * 1)()
             fv[0].view = C.pointer(sc)
             fv[0].geometry, fv[0].binning, fv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
@@ -472,84 +670,77 @@ class _RasterizeRaw(torch.autograd.Function):
             fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
             fv[0].depth_key_bits = _lazy.key_bits
             fv[0].fresh_image = 1
+            if hint is not None and P > 0:
+                fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
+                _stats["hinted"] += 1
             with torch.cuda.device(dev):
                 _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
             if lazy and key in _lazy.capacity:
-                ctx.lazy_token = _lazy.track(key, cap, words)
+                ctx.lazy_token = _lazy.track(key, cap, words[:2])
                 break
-            n, flag = (int(v) for v in words.tolist())                    # exact render: one read-back
+            n, flag = (int(v) for v in words[:2].tolist())                # exact render: one read-back
             _lazy.note(key, n)
             if flag & 2:
                 _lazy.key_bits = 0
+                hint = None
             ctx.lazy_token = None
             if n <= cap and not (flag & 2):
                 break
             cap = max(cap, _lazy.capacity[key])                           # repeat with what it needs
+        if _ORDER_HINT:
+            _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version), words=words,
+                                   stream=stream_id)
         ctx.cfg, ctx.sc, ctx.rp = cfg, sc, rp
         ctx.save_for_backward(xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img)
         ctx.cap = cap
+        ctx.m2d_leaf = means2D
         ctx.mark_non_differentiable(radii)
+        # the chain of this iteration's renders of these parameters (see backward)
+        ctx.batch_key = (di, P, K, int(cfg["sh_degree"]), float(cfg["scale_modifier"]), bool(cfg["debug"]),
+                         tuple(t.data_ptr() for t in (xyz, f_dc, f_rest, scaling, rotation, opacity)))
+        ctx.partner = None
+        ctx.pending = []
+        ctx.done_task = None
+        if cfg["differentiated"]:
+            prev = _last_raw_ctx.get(di)
+            if prev is not None and prev[1] == ctx.batch_key and prev[0]() is not None:
+                ctx.partner = prev[0]
+            _last_raw_ctx[di] = (weakref.ref(ctx), ctx.batch_key)
         return color, radii, depth, alpha
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         _lazy.confirm(ctx.lazy_token)     # truncated lists / key span: raises before any gradient exists
-        L = _lib.lib()
-        xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img = ctx.saved_tensors
-        cfg, sc, dev, P = ctx.cfg, ctx.sc, xyz.device, xyz.shape[0]
-        W, H = cfg["W"], cfg["H"]
-        f32 = dict(dtype=torch.float32, device=dev)
+        saved = ctx.saved_tensors
+        params = saved[:6]
+        dev = params[0].device
+        cfg = ctx.cfg
         if grad_color is None:
-            grad_color = torch.zeros((3, H, W), **f32)
-        gc = _dev_f32(grad_color, "dL_dout_color")
-        gd = None if grad_depth is None else _dev_f32(grad_depth, "dL_dout_depth")
-        ga = None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha")
-        skey = (dev.index if dev.index is not None else torch.cuda.current_device(), P)
-        scratch = _raw_scratch.get(skey)
-        if scratch is None:
-            if len(_raw_scratch) > 4:
-                _raw_scratch.clear()
-            scratch = _raw_scratch[skey] = torch.zeros((max(L.b3gs_backward_scratch_floats(P), 1),), **f32)
-        bv = (_lib.B3gsBlendView * 1)()
-        bv[0].view = C.pointer(sc)
-        bv[0].geometry, bv[0].binning, bv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
-        bv[0].dL_dcolor = gc.data_ptr()
-        bv[0].dL_ddepth = None if gd is None else gd.data_ptr()
-        bv[0].dL_dalpha = None if ga is None else ga.data_ptr()
-        bv[0].scratch, bv[0].binning_capacity = scratch.data_ptr(), ctx.cap
-        # Where the six gradients go.  Default: fresh tensors, RETURNED to autograd (AccumulateGrad keeps the first one a
-        # parameter receives and adds the later ones: one more pass over 92 B per Gaussian per render).  When every
-        # parameter is a plain leaf that already holds a dense fp32 `.grad` of its own shape and nothing hooks into its
-        # gradient, the chain-rule kernel adds into `.grad` directly (`+=`, what AccumulateGrad would do) and the node
-        # returns None for them -- same values, one pass less.  B3GS_DROPIN_INPLACE_GRADS=0 disables it.
-        params = (xyz, f_dc, f_rest, scaling, rotation, opacity)
-        inplace = _INPLACE_GRADS and all(
-            (not ctx.needs_input_grad[i]) or
-            (t.is_leaf and t.grad is not None and t.grad.dtype == torch.float32 and t.grad.shape == t.shape and
-             t.grad.is_contiguous() and t.grad.device == t.device and not t._backward_hooks and
-             not getattr(t, "_post_accumulate_grad_hooks", None))
-            for i, t in enumerate(params)) and all(ctx.needs_input_grad[:6])
-        grads = [t.grad if inplace else torch.empty_like(t) for t in params]
-        g_m2d = torch.empty((P, 3), **f32)
-        gr = _lib.B3gsRawGrads()
-        gr.xyz, gr.features_dc = grads[0].data_ptr(), grads[1].data_ptr()
-        gr.features_rest = grads[2].data_ptr() if grads[2].numel() else None
-        gr.scaling, gr.rotation, gr.opacity = grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr()
-        gr.touched_rows = None
-        av = (_lib.B3gsFusedView * 1)()
-        av[0].view = C.pointer(sc)
-        av[0].radii, av[0].geometry, av[0].scratch = radii.data_ptr(), geom.data_ptr(), scratch.data_ptr()
-        av[0].dL_dmeans2D, av[0].densify_stats = g_m2d.data_ptr(), 0
-        with torch.cuda.device(dev):
-            s = _stream(dev)
-            _lib.check(L.b3gs_blend_backward_batch(1, bv, s), "b3gs_blend_backward_batch")
-            # overwrite mode: every row of every gradient tensor is stored (zeros for Gaussians without a contribution);
-            # accumulate mode (in place): only the rows that received something are touched
-            _lib.check(L.b3gs_backward_raw_accumulate(1, av, C.byref(ctx.rp), C.byref(gr), 0 if inplace else 1, None, s),
-                       "b3gs_backward_raw_accumulate")
+            grad_color = torch.zeros((3, cfg["H"], cfg["W"]), dtype=torch.float32, device=dev)
+        job = _RawJob(ctx, _dev_f32(grad_color, "dL_dout_color"),
+                      None if grad_depth is None else _dev_f32(grad_depth, "dL_dout_depth"),
+                      None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha"))
+        task = torch._C._current_graph_task_id()
+        ctx.done_task = task
+        pending, ctx.pending = ctx.pending, []
         needs = ctx.needs_input_grad
-        out = [None if (inplace or not needs[i]) else g for i, g in enumerate(grads)]
-        return (*out, g_m2d if needs[6] else None, None)
+        if not _self_accumulate_ok(ctx, params):
+            if pending:                      # (deferred by nodes for which self-accumulation was fine: launch them so)
+                _launch_backward(pending, True)
+            grads, g_m2d = _launch_backward([job], False)
+            return (*[g if needs[i] else None for i, g in enumerate(grads)], g_m2d if needs[6] else None, None)
+        jobs = pending + [job]
+        partner = ctx.partner() if ctx.partner is not None else None
+        if (partner is not None and partner.done_task != task and partner.batch_key == ctx.batch_key
+                and not cfg["debug"] and torch._C._will_engine_execute_node(partner)):
+            # an earlier render of the same parameters runs its backward later in THIS graph task: it launches ours with its
+            # own (one blend backward, one chain-rule pass for all of them)
+            partner.pending = partner.pending + jobs
+            _register_task(flush_ref=weakref.ref(partner))
+            _stats["deferred"] += len(jobs)
+            return (None,) * 8
+        _launch_backward(jobs, True)
+        return (None,) * 8
 
 
 def rasterize_raw(pc, means2D, raster_settings):

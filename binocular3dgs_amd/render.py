@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_raw, raw_model_ok
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_raw, raw_model_ok, viewspace_leaf
 
 _HipRasterizer = GaussianRasterizer                            # (tests swap `GaussianRasterizer` for recording stubs)
 _FUSED_NODE = os.environ.get("B3GS_DROPIN_FUSED", "1") != "0"  # render() of a raw-parameter model as ONE autograd node
@@ -54,38 +54,6 @@ class PipelineParams:
         self.debug = debug
 
 
-class _LazyVisibility(dict):
-    """render()'s dict whose `visibility_filter` (= radii > 0, gaussian_renderer/__init__.py:99) is computed on first
-    access (one elementwise kernel per render that the training loop reads for the input view only).  The key is present
-    from the start (iteration, `in`, len() see the reference's six keys); every way of reading it materialises it."""
-
-    def __init__(self, d):
-        super().__init__(d)
-        super().__setitem__("visibility_filter", None)
-
-    def _fill(self):
-        if super().__getitem__("visibility_filter") is None:
-            super().__setitem__("visibility_filter", super().__getitem__("radii") > 0)
-
-    def __getitem__(self, key):
-        if key == "visibility_filter":
-            self._fill()
-        return super().__getitem__(key)
-
-    def get(self, key, default=None):
-        if key == "visibility_filter":
-            self._fill()
-        return super().get(key, default)
-
-    def items(self):
-        self._fill()
-        return super().items()
-
-    def values(self):
-        self._fill()
-        return super().values()
-
-
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene; `bg_color` must live on the GPU (as in the reference)."""
     xyz = pc.get_xyz
@@ -96,8 +64,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                   and GaussianRasterizer is _HipRasterizer and xyz.shape[0] > 0 and raw_model_ok(pc))
     if fused_node:
         # (a leaf instead of the reference's `zeros + 0`: its .grad then IS the node's screen-space gradient tensor,
-        # where retain_grad() on a non-leaf clones it -- 12 B per Gaussian per render)
-        screenspace_points = torch.zeros_like(xyz, requires_grad=True)
+        # where retain_grad() on a non-leaf clones it -- 12 B per Gaussian per render; all renders of a (device, P) share
+        # one block of zeros behind their leaves: nobody reads or writes the values)
+        screenspace_points = viewspace_leaf(xyz)
     else:
         # zero tensor whose .grad receives the screen-space mean gradients (densification statistic)
         screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -124,9 +93,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
     if fused_node:
         rendered_image, radii, depth, alpha = rasterize_raw(pc, screenspace_points, raster_settings)
-        # (`visibility_filter` = radii > 0 is materialised when somebody reads it)
-        return _LazyVisibility({"render": rendered_image, "viewspace_points": screenspace_points, "radii": radii,
-                                "rendered_depth": depth, "rendered_alpha": alpha})
+        return {"render": rendered_image,
+                "viewspace_points": screenspace_points,
+                "visibility_filter": radii > 0,
+                "radii": radii,
+                "rendered_depth": depth,
+                "rendered_alpha": alpha}
 
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:

@@ -82,6 +82,13 @@ def _step_words(dev):
     return torch.zeros(2, dtype=torch.int32, device=dev)
 
 
+def _bump_versions(params):
+    """The HIP optimiser writes the parameters through raw pointers: tell autograd's version counters (saved-tensor checks
+    of graphs that outlive the step; the depth-order hint of rasterizer._RasterizeRaw keys on them)."""
+    for p in params:
+        torch.autograd.graph.increment_version(p)
+
+
 def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, decay_first, bump, dev, row_mask=None,
                  skip_flag=None):
     """One b3gs_adam_step launch over [(param_ptr, grad_ptr, m_ptr, v_ptr, count, lr[, row_len, first_row]), ...] (at
@@ -143,6 +150,8 @@ class FusedAdam:
             off += p.numel()
         _adam_launch(segs, self.step_count, self.betas, self.eps, self.opacity_decay, self.opacity_index,
                      self.decay_first, last, self.params[0].device, row_mask, self.skip_flag)
+        if last:
+            _bump_versions(self.params)
 
     def zero_grad(self, set_to_none: bool = False):
         for p in self.params:
@@ -258,13 +267,16 @@ class ShardedAdam:
                          self.lrs[k]))
         decay = self.opacity_decay if opacity_seg >= 0 else 0.0
         if self.adam_impl is not None:
-            self.adam_impl(segs, self.step_count, self.betas, self.eps, decay, opacity_seg, self.decay_first)
+            # (host-logic tests: the stand-in honours the skip word the way the HIP launch does on the device)
+            if self.skip_flag is None or int(self.skip_flag.item()) == 0:
+                self.adam_impl(segs, self.step_count, self.betas, self.eps, decay, opacity_seg, self.decay_first)
         else:
             P = max(self.params[0].shape[0], 1)
             widths = [self.params[k].numel() // P for k, _, _ in self.my_segments()]
             _adam_launch([(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, w, 0)
                           for (p, gg, m, v, lr), w in zip(segs, widths)], self.step_count, self.betas, self.eps, decay,
                          opacity_seg, self.decay_first, True, self.pflat.device, row_mask, self.skip_flag)
+        _bump_versions(self.params)
         if collective:
             if ev:
                 ev[2].record()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 6
+#define B3GS_ABI_VERSION 7
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -185,7 +185,11 @@ typedef struct B3gsForwardView {
    * overflow_flag <- 1 (sticky) when N > binning_capacity, i.e. this view was rendered from truncated tile lists.
    * b3gs_adam_step(skip_if_nonzero = overflow_flag) and B3gsDensifyStats::skip_if_nonzero then turn every step from
    * the overflowing one on into a no-op for the parameters, the Adam state and the statistics, until the host has read
-   * the flag, grown the buffers and cleared it: the steps since the last check can really be repeated. */
+   * the flag, grown the buffers and cleared it: the steps since the last check can really be repeated.
+   * Bits of the word: 0 = capacity, 1 = a depth key outside the 27-bit span (depth_key_bits), 2 (ABI 7) = the second
+   * binning round's persistent launch timed out at its grid barrier (its workgroups were not co-resident: a shared or
+   * partitioned device) -- the repaired tiles of that forward are wrong, the step is dropped like an overflowing one and
+   * the caller goes back to one round (seg1_fraction = 0). */
   int32_t* high_water;
   int32_t* overflow_flag;
   /* 27: the caller vouches that every visible Gaussian's depth key (float bits of view z > 0.2) lies within 2^27 of the
@@ -198,6 +202,18 @@ typedef struct B3gsForwardView {
    * open-tile prediction (two-round binning is then off).  A caller that re-uses image buffers across forwards zeroes a
    * new one ONCE and passes 0.  All views of a batch use views[0]'s value. */
   int32_t fresh_image;
+  /* ABI 7 -- depth order of an EARLIER forward, checked on the device.  depth_order_hint (may be NULL) is the geometry
+   * buffer of a completed earlier b3gs_forward_raw_batch() of the same P Gaussians (same depth_key_bits) on this stream;
+   * it must stay alive until this forward has run.  The projection compares every depth key of this view with the key that
+   * forward stored (keys are a function of the Gaussian's position and the z row of the view matrix only: the binocular
+   * partner of train.py:124-128 differs from its input view by a translation along the camera x axis, so all keys are
+   * equal); any difference -- another camera, moved Gaussians, a different near-plane cull -- sets *hint_mismatch
+   * (device int32, must be ZERO on entry, required when a hint is given) and this view's own depth sort runs as usual.
+   * While the word stays zero the sort launches exit at once and the earlier order is adopted: same lists bit for bit,
+   * ~60 us less per view at 1M Gaussians.  The answer never depends on the caller being right about the hint.
+   * Only for views that sort their own keys (depth_order_from == -1). */
+  const char* depth_order_hint;
+  int32_t* hint_mismatch;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);

@@ -1,0 +1,333 @@
+"""GPU: what an UNCHANGED train.py:100,128 gets from render() -- the input view and its shifted partner as two render()
+calls of one iteration: the second render adopts the first one's depth order (checked on the device, ABI 7), the
+backward of both runs as one batch (one blend backward, one chain-rule pass) inside a plain loss.backward().
+
+Everything is compared with the same renders done one by one (B3GS_DROPIN_ORDER_HINT / _INPLACE_GRADS switched off):
+tile lists bit for bit, gradients up to the order of fp32 atomics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(P=30000, W=208, H=144, seed=7):
+    from binocular3dgs_amd import synth
+    return synth.synth_model(P, seed=seed, device="cuda", width=W, height=H)
+
+
+def _state(pkg, W, H):
+    """Tile lists of a raw-node render, from what its autograd node saved."""
+    from binocular3dgs_amd import debug
+    node = pkg["render"].grad_fn
+    saved = node.saved_tensors
+    radii, geom, binning, img = saved[6:10]
+    P = radii.shape[0]
+    n = int(debug.state_views(P, W, H, 0, geom, None, img)["counts"][0].item())
+    v = debug.state_views(P, W, H, n, geom, binning, img)
+    return n, v
+
+
+class _Cam:
+    """A camera as the REFERENCE builds it: the matrices of tests/golden/cameras.npz (G3 / G4: scene/cameras.py and
+    Scene.getShiftedCamera run in the build container by tests/golden/make_golden.py)."""
+
+    def __init__(self, g, wvt, full, center, fov, uid=0):
+        fx, fy, w, h = fov
+        self.FoVx, self.FoVy, self.image_width, self.image_height = float(fx), float(fy), int(w), int(h)
+        self.world_view_transform = torch.from_numpy(np.ascontiguousarray(wvt)).cuda()
+        self.full_proj_transform = torch.from_numpy(np.ascontiguousarray(full)).cuda()
+        self.camera_center = torch.from_numpy(np.ascontiguousarray(center)).cuda()
+        self.uid = uid
+
+
+def _golden_pairs():
+    g = np.load(os.path.join(GOLDEN, "cameras.npz"))
+    out = []
+    for i in range(int(g["n"])):
+        cam = _Cam(g, g[f"wvt{i}"], g[f"full{i}"], g[f"center{i}"], g[f"fov{i}"], uid=i)
+        for j in range(4):
+            out.append((cam, _Cam(g, g[f"shift{i}_{j}_wvt"], g[f"shift{i}_{j}_full"], g[f"shift{i}_{j}_center"], g[f"fov{i}"], uid=i)))
+    return out
+
+
+def _render_pair(model, cam, scam, bg, hint, inplace):
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd.render import PipelineParams, render
+    R._ORDER_HINT, R._INPLACE_GRADS = hint, inplace
+    R._order_hint.clear()
+    R._last_raw_ctx.clear()
+    try:
+        a = render(cam, model, PipelineParams(), bg)
+        b = render(scam, model, PipelineParams(), bg)
+    finally:
+        R._ORDER_HINT, R._INPLACE_GRADS = True, True
+    return a, b
+
+
+def test_shifted_render_adopts_the_depth_order_lists_bit_identical():
+    """Own cameras (Camera.shifted) and the REFERENCE-built pairs of G4: the second render of a pair takes the first one's
+    depth order -- its key-mismatch word stays zero -- and its tile lists, ranges and images equal a render that sorted its
+    own keys, bit for bit."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.tensor([0.1, 0.0, 0.2], device="cuda")
+    pairs = [(c, s) for c, s, _ in synth.synth_view_set(W, H, device="cuda")]
+    for cam, scam in pairs:
+        before = R._stats["hinted"]
+        a1, b1 = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+        assert R._stats["hinted"] == before + 1
+        words = R._order_hint[0]["words"]
+        assert int(words[2].item()) == 0, "the shifted camera must have the z row of its input view"
+        a0, b0 = _render_pair(model, cam, scam, bg, hint=False, inplace=True)
+        for x, y in ((a1, a0), (b1, b0)):
+            nx, vx = _state(x, W, H)
+            ny, vy = _state(y, W, H)
+            assert nx == ny and nx > 0
+            for k in ("point_list", "tile_ids", "ranges", "n_contrib", "tiles_touched", "depth_bits"):
+                assert torch.equal(vx[k], vy[k]), k
+            for k in ("render", "rendered_depth", "rendered_alpha", "radii"):
+                assert torch.equal(x[k], y[k]), k
+
+
+def test_reference_built_shifted_cameras_share_the_order_when_the_z_row_survives():
+    """G4: the pairs the reference's own Scene.getShiftedCamera produced (two host-side float64 matrix inversions, then a
+    cast to fp32).  In 16 of the 20 golden pairs the z row of the shifted view matrix equals the input view's bit for bit
+    and the order is adopted; in the other 4 the translation entry comes out one ulp off, every depth key moves, the
+    mismatch word goes up and the render sorts its own keys -- what the reference would do.  Lists equal the per-view sort
+    in both cases."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    pairs = _golden_pairs()
+    assert len(pairs) == 20
+    adopted = same_row = 0
+    for cam, scam in pairs:
+        W, H = cam.image_width, cam.image_height
+        # Gaussians in front of THIS camera: the synthetic cloud lives in the view frustum of the identity camera
+        model = synth.synth_model(6000, seed=3, device="cuda", width=W, height=H)
+        with torch.no_grad():
+            c2w = torch.linalg.inv(cam.world_view_transform)            # row-vector convention
+            xyz1 = torch.cat([model._xyz, torch.ones_like(model._xyz[:, :1])], 1) @ c2w
+            model._xyz.copy_(xyz1[:, :3])
+        bg = torch.zeros(3, device="cuda")
+        a1, b1 = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+        row_equal = bool(torch.equal(cam.world_view_transform[:, 2], scam.world_view_transform[:, 2]))
+        took = int(R._order_hint[0]["words"][2].item()) == 0
+        assert took == row_equal, (took, row_equal)
+        adopted += took
+        same_row += row_equal
+        a0, b0 = _render_pair(model, cam, scam, bg, hint=False, inplace=True)
+        n1, v1 = _state(b1, W, H)
+        n0, v0 = _state(b0, W, H)
+        assert n1 == n0 and int((a1["radii"] > 0).sum()) > 100
+        if n1:
+            assert torch.equal(v1["point_list"], v0["point_list"]) and torch.equal(v1["ranges"], v0["ranges"])
+        assert torch.equal(b1["render"], b0["render"])
+    assert adopted == same_row == 16, (adopted, same_row)
+
+
+def test_a_different_camera_or_moved_gaussians_fall_back_to_their_own_sort():
+    """The hint is only a guess: another camera (different z row) raises the mismatch word and the render sorts itself;
+    Gaussians moved behind autograd's back (same storage, same version counter) are caught by the same key comparison."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    (c0, _, _), (c1, _, _) = synth.synth_view_set(W, H, device="cuda")[:2]
+    R._order_hint.clear()
+    render(c0, model, PipelineParams(), bg)
+    other = render(c1, model, PipelineParams(), bg)                     # different yaw: every key differs
+    assert int(R._order_hint[0]["words"][2].item()) == 1
+    R._ORDER_HINT = False
+    try:
+        want = render(c1, model, PipelineParams(), bg)
+    finally:
+        R._ORDER_HINT = True
+    n1, v1 = _state(other, W, H)
+    n0, v0 = _state(want, W, H)
+    assert n1 == n0 and torch.equal(v1["point_list"], v0["point_list"]) and torch.equal(other["render"], want["render"])
+    # same camera, positions changed through .data (no version bump)
+    R._order_hint.clear()
+    render(c0, model, PipelineParams(), bg)
+    model._xyz.data[:, 2] += 0.37 * torch.rand(model._xyz.shape[0], device="cuda")
+    moved = render(c0, model, PipelineParams(), bg)
+    assert int(R._order_hint[0]["words"][2].item()) == 1
+    R._ORDER_HINT = False
+    try:
+        want = render(c0, model, PipelineParams(), bg)
+    finally:
+        R._ORDER_HINT = True
+    n1, v1 = _state(moved, W, H)
+    n0, v0 = _state(want, W, H)
+    assert n1 == n0 and torch.equal(v1["point_list"], v0["point_list"]) and torch.equal(moved["render"], want["render"])
+
+
+def _loss(a, b, gc, gd, ga):
+    return (a["render"] * gc).sum() + (a["rendered_depth"] * gd).sum() + (a["rendered_alpha"] * ga).sum() + \
+        (b["render"] * gc.flip(-1)).sum()
+
+
+def test_pair_backward_runs_as_one_batch_and_equals_per_node_gradients():
+    """loss.backward() over an (input, shifted) pair: the later render's node defers to the earlier one, which launches ONE
+    blend backward + ONE chain-rule pass for both and adds into .grad; parameter gradients and both `viewspace_points`
+    gradients equal the per-node path (gradients returned to autograd) -- with .grad unset, preset (accumulation) and
+    under retain_graph (second backward of the same graph)."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[1]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=5, device="cuda")
+    # reference: per node, gradients returned to autograd
+    for p in model.parameters():
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=False, inplace=False)
+    R._INPLACE_GRADS = False
+    try:
+        _loss(a, b, gc, gd, ga).backward()
+    finally:
+        R._INPLACE_GRADS = True
+    ref = [p.grad.clone() for p in model.parameters()]
+    ref_m2d = (a["viewspace_points"].grad.clone(), b["viewspace_points"].grad.clone())
+    assert float(ref_m2d[1].abs().max()) > 0
+    for preset in (False, True):
+        for p in model.parameters():
+            p.grad = torch.ones_like(p) if preset else None
+        a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+        s0 = dict(R._stats)
+        _loss(a, b, gc, gd, ga).backward(retain_graph=True)
+        assert R._stats["deferred"] == s0["deferred"] + 1 and R._stats["launches"] == s0["launches"] + 1
+        assert R._stats["batched_views"] == s0["batched_views"] + 2
+        for n, p, r in zip("xyz f_dc f_rest scaling rotation opacity".split(), model.parameters(), ref):
+            want = r + 1.0 if preset else r
+            assert rel_l2(p.grad.cpu().numpy(), want.cpu().numpy()) < 2e-5, (n, preset)
+        for got, want in zip((a["viewspace_points"].grad, b["viewspace_points"].grad), ref_m2d):
+            assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 2e-5
+        # the same graph again: accumulates a second time
+        _loss(a, b, gc, gd, ga).backward()
+        for p, r in zip(model.parameters(), ref):
+            want = 2.0 * r + (1.0 if preset else 0.0)
+            assert rel_l2(p.grad.cpu().numpy(), want.cpu().numpy()) < 5e-5       # (two runs of fp32 atomics against one)
+    for pool in R._raw_scratch.values():
+        for s in pool:
+            assert float(s.abs().max()) == 0.0, "scratch rows must be left clean"
+
+
+def test_six_renders_of_an_iteration_run_their_backward_as_one_launch():
+    from binocular3dgs_amd import synth
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 160, 120
+    model = _model(P=12000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=2, device="cuda")
+    cams = [c for cam, scam, _ in synth.synth_view_set(W, H, device="cuda") for c in (cam, scam)]
+
+    def run(inplace):
+        R._INPLACE_GRADS = inplace
+        try:
+            for p in model.parameters():
+                p.grad = None
+            pk = [render(c, model, PipelineParams(), bg) for c in cams]
+            outs, grads = [], []
+            for k, o in enumerate(pk):
+                outs += [o["render"]] + ([o["rendered_depth"], o["rendered_alpha"]] if k % 2 == 0 else [])
+                grads += [gc] + ([gd, ga] if k % 2 == 0 else [])
+            torch.autograd.backward(outs, grads)
+        finally:
+            R._INPLACE_GRADS = True
+        return [p.grad.clone() for p in model.parameters()], [o["viewspace_points"].grad.clone() for o in pk]
+
+    ref, ref_m = run(False)
+    s0 = dict(R._stats)
+    got, got_m = run(True)
+    assert R._stats["launches"] == s0["launches"] + 1 and R._stats["batched_views"] == s0["batched_views"] + 6
+    assert R._stats["hinted"] >= s0["hinted"] + 3
+    for g, r in zip(got + got_m, ref + ref_m):
+        assert rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 2e-5
+
+
+def test_autograd_grad_and_partial_backward_leave_dot_grad_alone():
+    """torch.autograd.grad(loss, params) must RETURN the gradients and must not touch .grad; backward(inputs=[one
+    parameter]) must fill only that one; a hooked parameter sees its hook."""
+    from binocular3dgs_amd import synth
+    import binocular3dgs_amd.rasterizer as R
+    W, H = 160, 120
+    model = _model(P=8000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+    params = model.parameters()
+    for p in params:
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    _loss(a, b, gc, gd, ga).backward()
+    ref = [p.grad.clone() for p in params]
+    # autograd.grad: returned, .grad untouched (preset to a sentinel)
+    for p in params:
+        p.grad = torch.full_like(p, 3.0)
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    s0 = dict(R._stats)
+    got = torch.autograd.grad(_loss(a, b, gc, gd, ga), params)
+    assert R._stats["deferred"] == s0["deferred"]
+    for g, r, p in zip(got, ref, params):
+        assert g is not None and rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 2e-5
+        assert torch.equal(p.grad, torch.full_like(p, 3.0))
+    # backward(inputs=[xyz]): only xyz receives
+    for p in params:
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    _loss(a, b, gc, gd, ga).backward(inputs=[model._xyz])
+    assert rel_l2(model._xyz.grad.cpu().numpy(), ref[0].cpu().numpy()) < 2e-5
+    assert all(p.grad is None for p in params[1:])
+    # a tensor hook on one parameter is honoured (gradients go through autograd)
+    seen = []
+    h = model._opacity.register_hook(lambda g: seen.append(float(g.abs().sum())))
+    try:
+        for p in params:
+            p.grad = None
+        a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+        _loss(a, b, gc, gd, ga).backward()
+    finally:
+        h.remove()
+    assert len(seen) >= 1 and sum(seen) > 0
+    for p, r in zip(params, ref):
+        assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 2e-5
+
+
+def test_only_the_shifted_loss_backpropagated_still_delivers():
+    """A backward that reaches only the LATER render (its partner is not part of the graph task): nothing is deferred."""
+    from binocular3dgs_amd import synth
+    import binocular3dgs_amd.rasterizer as R
+    W, H = 160, 120
+    model = _model(P=8000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    gc, _, _ = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+    for p in model.parameters():
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    s0 = dict(R._stats)
+    (b["render"] * gc).sum().backward()
+    assert R._stats["deferred"] == s0["deferred"] and R._stats["launches"] == s0["launches"] + 1
+    got = model._xyz.grad.clone()
+    R._INPLACE_GRADS = False
+    try:
+        for p in model.parameters():
+            p.grad = None
+        a, b = _render_pair(model, cam, scam, bg, hint=False, inplace=False)
+        R._INPLACE_GRADS = False
+        (b["render"] * gc).sum().backward()
+    finally:
+        R._INPLACE_GRADS = True
+    assert rel_l2(got.cpu().numpy(), model._xyz.grad.cpu().numpy()) < 2e-5

@@ -711,7 +711,7 @@ def test_three_pass_depth_sort_equals_four_pass(P, W, H):
         fr = FusedRasterizer(model, W, H, num_slots=3, seg1_fraction=0.0)
         fr.depth_key_bits = bits
         with torch.no_grad():
-            outs = fr.render_batch(views, bg)
+            outs = fr.render_batch(views, bg, _span_checked=True)    # (the span verdict is read right below)
         torch.cuda.synchronize()
         assert int(fr.overflow_flag.item()) == 0
         res.append(([o["render"].clone() for o in outs], _lists(fr, P, W, H, (0, 1, 2))))
@@ -743,7 +743,11 @@ def test_depth_key_outside_the_27_bit_span_is_detected_and_falls_back():
     fr = FusedRasterizer(model, W, H, num_slots=1, seg1_fraction=0.0)
     assert fr.depth_key_bits == 27
     with torch.no_grad():
-        fr.render_batch(views, bg)
+        # a render nobody will differentiate (evaluation) has no reader of the span verdict: it sorts all 32 bits and is
+        # right without any check
+        got_eval = fr.render_batch(views, bg)[0]["render"].clone()
+    assert torch.equal(got_eval, want) and int(fr.overflow_flag.item()) == 0
+    fr.render_batch(views, bg)            # a training render: three passes on the checked span
     torch.cuda.synchronize()
     assert int(fr.overflow_flag.item()) & 2
     assert fr.check_overflow() and fr.depth_key_bits == 0 and int(fr.overflow_flag.item()) == 0
