@@ -386,13 +386,38 @@ class Job:
         return ms, (sum(inst) / len(inst) if inst else None)
 
 
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE): become the launcher -- re-run this
+    command line as N ranks under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and hand its exit
+    code back.  Without this the script would silently measure ONE rank and label it n_gpus = 1."""
+    import socket
+    if torch.cuda.device_count() < args.gpus and not os.environ.get("B3GS_BENCH_SINGLE_DEVICE"):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.inner:
+        _spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # the driver launches `torch.distributed.run --nproc-per-node N bench.py --gpus N`: a mismatch means the numbers
+        # would be labelled with a GPU count that did not run
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the rasterizer)")
+    if world > 1 and torch.cuda.device_count() < world and not os.environ.get("B3GS_BENCH_SINGLE_DEVICE"):
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible (one process per GPU)")
     # test hooks (tests/test_gpu_bench_contract.py): several ranks sharing ONE GPU over gloo exercise the N > 1 control flow
     # of this script on a 1-GPU box (RCCL needs one GPU per rank); never set in a measurement
     backend = os.environ.get("B3GS_BENCH_BACKEND", "nccl")
@@ -426,6 +451,8 @@ def main():
     exchange = None
     if dp:
         exchange = measure_exchange(job, min(args.steps, 10))
+        if exchange["rccl_ranks"] != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {exchange['rccl_ranks']} rank(s), --gpus says {args.gpus}")
 
     # workload statistics of this rank's primary view 0 through the reference-shaped C ABI surface (V, the reference-rule N)
     from binocular3dgs_amd import _C

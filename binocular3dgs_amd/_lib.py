@@ -57,7 +57,8 @@ class B3gsForwardView(C.Structure):
                 ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p), ("radii", C.c_void_p),
                 ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32), ("seg1_fraction", C.c_float),
                 ("high_water", C.c_void_p), ("overflow_flag", C.c_void_p), ("depth_key_bits", C.c_int32),
-                ("fresh_image", C.c_int32), ("depth_order_hint", C.c_void_p), ("hint_mismatch", C.c_void_p)]
+                ("fresh_image", C.c_int32), ("depth_order_hint", C.c_void_p), ("hint_mismatch", C.c_void_p),
+                ("hint_trusted", C.c_int32)]
 
 
 class B3gsLossIO(C.Structure):

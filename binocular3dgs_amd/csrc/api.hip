@@ -341,8 +341,10 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     if (fv.depth_order_from != -1 &&
         (fv.depth_order_from < 0 || fv.depth_order_from >= nviews || views[fv.depth_order_from].depth_order_from != -1))
       return fail(B3GS_ERR_ARG, "%s", "depth_order_from must name a view of the batch that sorts its own keys");
-    if (fv.depth_order_hint && (fv.depth_order_from != -1 || !fv.hint_mismatch || fv.depth_order_hint == fv.geometry))
-      return fail(B3GS_ERR_ARG, "%s", "depth_order_hint needs depth_order_from == -1, a hint_mismatch word and another buffer");
+    if (fv.depth_order_hint && (fv.depth_order_from != -1 || !fv.hint_mismatch || fv.depth_order_hint == fv.geometry ||
+                                (fv.hint_trusted && !fv.overflow_flag)))
+      return fail(B3GS_ERR_ARG, "%s", "depth_order_hint needs depth_order_from == -1, a hint_mismatch word, another buffer "
+                                      "(and an overflow word when trusted)");
     GeomView g;
     ImgView im;
     BinView b;
@@ -361,6 +363,8 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
       jobs[k].hint_sval = hg.sval[0];
       jobs[k].hint_skey = hg.skey[0];
       jobs[k].hint_word = fv.hint_mismatch;
+      jobs[k].hint_trusted = fv.hint_trusted ? 1 : 0;
+      pb.out[k].hint_fatal = fv.hint_trusted ? fv.overflow_flag : nullptr;
     }
     bb.v[k] = b3gs_blend_view(sc, g, b, im);
     bb.v[k].open_rows = im.open_rows;

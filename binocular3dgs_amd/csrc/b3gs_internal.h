@@ -247,6 +247,7 @@ struct PreOut {
   // sets *hint_word (then this view's own depth sort runs instead of adopting that forward's order)
   const uint32_t* hint_key = nullptr;
   int32_t* hint_word = nullptr;
+  int32_t* hint_fatal = nullptr;   // trusted hint (no sort launched): a differing key also raises bit 3 of this overflow word
 };
 struct PreBatch {
   int32_t n, raw_mode, tight;
@@ -300,6 +301,7 @@ struct BinJob {
   const uint32_t* hint_sval = nullptr;
   const uint32_t* hint_skey = nullptr;
   const int32_t* hint_word = nullptr;
+  int32_t hint_trusted = 0;        // != 0: the sort is not launched at all (the projection flags a differing key as fatal)
 };
 void b3gs_launch_binning_batch(int32_t P, int nviews, const BinJob* jobs, hipStream_t s);
 void b3gs_launch_sort_u32_index(const uint32_t* keys, uint32_t* const skey[2], uint32_t* const sval[2], uint32_t n,

@@ -930,7 +930,7 @@ struct AdoptJob {
   const uint32_t* src_key;
   uint32_t* dst_val;
   uint32_t* dst_key;
-  const int32_t* word;                 // adopt while *word == 0
+  const int32_t* word;                 // adopt while *word == 0 (null: always -- a trusted hint, no sort was launched)
   const unsigned long long* flag[2];   // null: no flags (one-round forward)
   uint32_t n;
 };
@@ -940,7 +940,7 @@ struct AdoptBatch {
 };
 __global__ void __launch_bounds__(256) adopt_order_kernel(AdoptBatch ab) {
   const AdoptJob& job = ab.j[blockIdx.y];
-  if (__builtin_nontemporal_load(job.word) != 0) return;
+  if (job.word && __builtin_nontemporal_load(job.word) != 0) return;
   const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
   if (i >= job.n) return;
   if (i + 4u <= job.n) {
@@ -1584,6 +1584,7 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   db.n = 0;
   AdoptBatch adopt;
   adopt.n = 0;
+  int sorted_view[B3GS_MAX_FUSED_VIEWS];
   const uint32_t pblk = b3gs_sort_blocks((int64_t)P);
   bool span27 = true;
   for (int v = 0; v < nviews; v++) span27 = span27 && jobs[v].key_bits == 27;
@@ -1593,30 +1594,30 @@ void b3gs_launch_depth_order_batch(int32_t P, int nviews, const BinJob* jobs, hi
   for (int v = 0; v < nviews; v++) {
     if (jobs[v].order_from != -1) continue;
     const GeomView& g = jobs[v].g;
-    SortJob& sj = db.j[db.n++];
-    sj = SortJob{g.depth_key, nullptr, g.skey[first_dst], g.sval[first_dst], nullptr, (uint32_t)P, pblk, 0, g.hist,
-                 nullptr, nullptr, {nullptr, nullptr}};
+    const unsigned long long* flag[2] = {nullptr, nullptr};
     if (K1 < P) {   // two rounds: the predicted-tile flags of this view and of its scan partner travel with the order
       const int pv = scan_partner_of(jobs, nviews, v);
-      sj.flag[0] = g.pflag;
-      sj.flag[1] = pv >= 0 ? jobs[pv].g.pflag : nullptr;
+      flag[0] = g.pflag;
+      flag[1] = pv >= 0 ? jobs[pv].g.pflag : nullptr;
     }
-    if (jobs[v].hint_sval && jobs[v].hint_word) {   // adopt an earlier forward's order while the keys are equal
-      sj.gate = jobs[v].hint_word;
-      AdoptJob& aj = adopt.j[adopt.n++];
-      aj = AdoptJob{jobs[v].hint_sval, jobs[v].hint_skey, g.sval[0], g.skey[0], jobs[v].hint_word, {sj.flag[0], sj.flag[1]},
-                    (uint32_t)P};
-    }
+    const bool hinted = jobs[v].hint_sval && jobs[v].hint_word;
+    if (hinted)     // adopt an earlier forward's order while the keys are equal (trusted: always, the sort is not launched)
+      adopt.j[adopt.n++] = AdoptJob{jobs[v].hint_sval, jobs[v].hint_skey, g.sval[0], g.skey[0],
+                                    jobs[v].hint_trusted ? nullptr : jobs[v].hint_word, {flag[0], flag[1]}, (uint32_t)P};
+    if (hinted && jobs[v].hint_trusted) continue;
+    sorted_view[db.n] = v;
+    SortJob& sj = db.j[db.n++];
+    sj = SortJob{g.depth_key, nullptr, g.skey[first_dst], g.sval[first_dst], nullptr, (uint32_t)P, pblk, 0, g.hist,
+                 nullptr, nullptr, {flag[0], flag[1]}};
+    if (hinted) sj.gate = jobs[v].hint_word;
   }
   for (int pass = 0; pass < npass; pass++) {
     if (span27) radix9_pass(db, 9 * pass, pass == 0, s);
     else radix_pass(db, 8 * pass, s);
-    int k = 0;
-    for (int v = 0; v < nviews; v++) {
-      if (jobs[v].order_from != -1) continue;
-      const GeomView& g = jobs[v].g;
+    for (int k = 0; k < db.n; k++) {
+      const GeomView& g = jobs[sorted_view[k]].g;
       const int src = (first_dst + pass) & 1;   // where this pass wrote: the next one reads it and writes the other
-      SortJob& j = db.j[k++];
+      SortJob& j = db.j[k];
       j.kin = g.skey[src];
       j.vin = g.sval[src];
       j.kout = g.skey[src ^ 1];

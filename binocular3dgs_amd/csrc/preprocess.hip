@@ -399,7 +399,10 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
   // the depth order of an earlier forward is adopted only while every key equals the key that forward sorted
-  if (g.hint_key && g.hint_key[i] != dkey) *g.hint_word = 1;
+  if (g.hint_key && g.hint_key[i] != dkey) {
+    *g.hint_word = 1;
+    if (g.hint_fatal) atomicOr(g.hint_fatal, 8);   // trusted hint: no sort was launched for this view
+  }
   // the three-pass depth sort assumes every visible key within 2^27 of the float bits of the near plane (binning.hip):
   // say so when one is not (z > ~13107, or a prefiltered Gaussian in front of the near plane)
   if (g.span_flag && dkey != 0xFFFFFFFFu && (dkey <= 0x3E4CCCCDu || dkey - 0x3E4CCCCDu >= (1u << 27) - 2u))

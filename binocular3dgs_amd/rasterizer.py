@@ -116,9 +116,12 @@ class _LazyN:
     loops, render.py-style scripts -- they get the exact, synchronous forward).  Later differentiated renders of the shape
     run b3gs_forward_capacity with a binning buffer of twice the largest N seen; N stays on the device and travels to
     pinned host memory behind the kernels.  It is looked at
-      * at the entry of that render's BACKWARD (the loss sits between the two, so the copy has long completed): an N
-        above the capacity -- the image and the loss were computed from truncated tile lists -- raises B3gsError there,
-        i.e. before any gradient exists and before `optimizer.step()` of train.py:149-197 can consume it;
+      * in that render's BACKWARD: an N above the capacity -- the image and the loss were computed from truncated tile
+        lists -- raises B3gsError out of `loss.backward()`, i.e. before `optimizer.step()` of train.py:149-197 can consume
+        anything (`_C.rasterize_gaussians` / GaussianRasterizer: at the entry of the node, before any gradient exists; the
+        render() node of a raw-parameter model: as the last act of that backward(), behind its launches, so that the wait
+        for the read-back does not drain the device's queue between forward and backward -- whatever the interrupted
+        backward() left in `.grad` is to be discarded, as after any backward() that raised);
       * at the next render (capacity grown while N is still inside it; renders whose backward never ran are checked here);
       * at interpreter exit (a warning for anything still unchecked).
     P changes at every densification, so each new Gaussian set starts with an exact, synchronous render.
@@ -132,6 +135,7 @@ class _LazyN:
         self.slot = 0
         self.enabled = os.environ.get("B3GS_DROPIN_SYNC", "0") != "1"
         self.key_bits = 27     # fused render() node: depth sort on 27-bit keys until a render reports a key outside the span
+        self.trust_hints = True    # ... and host-side knowledge of equal z rows is trusted until the device contradicts it
 
     def note(self, key, n):
         self.capacity[key] = max(self.capacity.get(key, 0), int(n * self.HEADROOM), 1 << 16)
@@ -144,6 +148,10 @@ class _LazyN:
         n = int(host[0])
         if n > cap * self.REGROW_AT:
             self.note(key, n)
+        if host.numel() > 1 and int(host[1]) & 8:     # fused render() node: a trusted depth-order hint was wrong
+            self.trust_hints = False
+            return (n, cap, "the depth order of another view although its keys differ (the camera's matrices are not what "
+                            "its R / T / trans say); depth-order hints are verified before use from now on")
         if host.numel() > 1 and int(host[1]) & 2:     # fused render() node: a depth key outside the 27-bit span
             self.key_bits = 0
             return (n, cap, "a depth key outside the 27-bit span of the three-pass sort (z > ~13107); the full 32-bit "
@@ -401,7 +409,7 @@ _raw_scratch = {}     # (device index, P) -> list of zeroed [P * 10] float buffe
 _zero_m2d = {}        # (device index, P) -> zeros [P, 3]: storage behind every render's `viewspace_points` leaf
 _order_hint = {}      # device index -> the last raw forward: dict(P, key_bits, geom, xyz_ptr, xyz_version)
 _last_raw_ctx = {}    # device index -> weakref of the last DIFFERENTIATED raw forward's node (+ what it rendered)
-_stats = {"hinted": 0, "deferred": 0, "batched_views": 0, "launches": 0}   # (tests / bench read these)
+_stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0}   # (tests / bench read these)
 
 
 def raw_model_ok(pc) -> bool:
@@ -436,6 +444,35 @@ def _zero_words(dev):
     w = ent[0][ent[1]]
     ent[1] += 1
     return w
+
+
+def camera_depth_key(cam):
+    """What the HOST knows about the z row of a camera's view matrix (every depth key is a function of it and of the
+    positions): bytes that are equal for two cameras exactly when their z rows are the same bits, or False when it cannot
+    tell.  camera.Camera.shifted() keeps its parent's row by construction (`same_depth_as`); a camera that carries the
+    reference's constructor arguments (scene/cameras.py:17-58: R, T, trans, scale) gets the row re-derived the way that
+    constructor derived the matrix (utils/graphics_utils.py:38-49 = camera.world_to_view, bit-equal per golden G3) -- the
+    reference's getShiftedCamera (scene/__init__.py:96-115) lands on its input view's row in ~4 of 5 draws, one ulp beside
+    it in the others (golden G4).  Cached on the camera object.  Only ever used to decide whether a depth sort is LAUNCHED;
+    the device checks the keys themselves."""
+    k = getattr(cam, "_b3gs_zkey", None)
+    if k is not None:
+        return k
+    donor = getattr(cam, "same_depth_as", None)
+    if donor is not None:
+        k = camera_depth_key(donor)
+    else:
+        try:
+            from .camera import world_to_view
+            import numpy as np
+            k = world_to_view(cam.R, cam.T, getattr(cam, "trans", np.zeros(3)), getattr(cam, "scale", 1.0))[2, :].tobytes()
+        except Exception:
+            k = False
+    try:
+        cam._b3gs_zkey = k
+    except Exception:
+        pass
+    return k
 
 
 def viewspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
@@ -488,20 +525,34 @@ def _self_accumulate_ok(ctx, params) -> bool:
     if not _INPLACE_GRADS or torch.is_grad_enabled() or not all(ctx.needs_input_grad[:6]):
         return False
     nf = ctx.next_functions
-    if not all(_leaf_accumulates(nf[i][0], t) for i, t in enumerate(params)):
+    # (the answer for the six parameters is the same for every node of this graph task that renders them: asked once)
+    task = torch._C._current_graph_task_id()
+    if _acc_cache.get("task") != task:
+        _acc_cache.clear()
+        _acc_cache["task"] = task
+    ok = _acc_cache.get(ctx.batch_key)
+    if ok is None:
+        ok = _acc_cache[ctx.batch_key] = all(_leaf_accumulates(nf[i][0], t) for i, t in enumerate(params))
+    if not ok:
         return False
     return (not ctx.needs_input_grad[6]) or _leaf_accumulates(nf[6][0], ctx.m2d_leaf)
 
 
-_task_cb = {"task": None, "streams": [], "flush": []}
+_task_cb = {"task": None, "streams": [], "flush": [], "tokens": []}
+_acc_cache = {}
 
 
 def _end_of_backward():
     """Final callback of the graph task (runs on the caller's ambient streams, after the engine has synchronised them with
-    the streams of the leaves IT accumulated): launch what is still deferred -- a node that was expected to run in this
-    backward and did not -- and make the caller's stream wait for the streams this module wrote `.grad` on."""
-    flush, streams = _task_cb["flush"], _task_cb["streams"]
-    _task_cb["task"], _task_cb["flush"], _task_cb["streams"] = None, [], []
+    the streams of the leaves IT accumulated), i.e. the last thing `loss.backward()` does before it returns:
+      * launch what is still deferred -- a node that was expected to run in this backward and did not;
+      * make the caller's stream wait for the streams this module wrote `.grad` on;
+      * check the N of every sync-free forward differentiated in this backward (_LazyN): truncated tile lists raise HERE, out
+        of backward() and therefore before `optimizer.step()` of train.py:196-198 -- but behind the backward's launches, so
+        the host waits for the forwards' read-backs while the device still has the whole backward queued (checking at the
+        entry of the first node drained the queue between forward and backward of every iteration: ~0.2 ms of idle device)."""
+    flush, streams, tokens = _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"]
+    _task_cb["task"], _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"] = None, [], [], []
     for ref in flush:
         node = ref()
         jobs = getattr(node, "pending", None) if node is not None else None
@@ -512,17 +563,27 @@ def _end_of_backward():
         cur = torch.cuda.current_stream(st.device)
         if cur != st:
             cur.wait_stream(st)
+    err = None
+    for tok in tokens:
+        try:
+            _lazy.confirm(tok)
+        except _lib.B3gsError as exc:      # (every token is resolved -- capacities grow -- before the first error leaves)
+            err = err or exc
+    if err is not None:
+        raise err
 
 
-def _register_task(stream=None, flush_ref=None):
+def _register_task(stream=None, flush_ref=None, token=None):
     task = torch._C._current_graph_task_id()
     if _task_cb["task"] != task:
-        _task_cb["task"], _task_cb["streams"], _task_cb["flush"] = task, [], []
+        _task_cb["task"], _task_cb["streams"], _task_cb["flush"], _task_cb["tokens"] = task, [], [], []
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
     if stream is not None and stream not in _task_cb["streams"]:
         _task_cb["streams"].append(stream)
     if flush_ref is not None:
         _task_cb["flush"].append(flush_ref)
+    if token is not None:
+        _task_cb["tokens"].append(token)
 
 
 def _launch_backward(jobs, self_acc):
@@ -657,6 +718,14 @@ class _RasterizeRaw(torch.autograd.Function):
         if hint is not None and not (hint["P"] == P and hint["key_bits"] == _lazy.key_bits and hint["stream"] == stream_id and
                                      hint["xyz"] == (xyz.data_ptr(), xyz._version) and hint["geom"].numel() == geom.numel()):
             hint = None
+        # ... and when the host knows both z rows (camera_depth_key) the sort is either not launched at all (same row:
+        # `hint_trusted`, still verified key by key -- a wrong guess drops the step) or launched without a hint
+        zkey, trusted = cfg.get("zkey", False), False
+        if hint is not None and zkey and hint["zkey"] and _lazy.trust_hints:
+            if zkey == hint["zkey"]:
+                trusted = True
+            else:
+                hint = None
         while True:
             binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
             words = _zero_words(dev)                                       # [N, overflow word, key mismatch, spare], zero
@@ -672,7 +741,9 @@ class _RasterizeRaw(torch.autograd.Function):
             fv[0].fresh_image = 1
             if hint is not None and P > 0:
                 fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
+                fv[0].hint_trusted = int(trusted)
                 _stats["hinted"] += 1
+                _stats["trusted"] += int(trusted)
             with torch.cuda.device(dev):
                 _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
             if lazy and key in _lazy.capacity:
@@ -683,18 +754,23 @@ class _RasterizeRaw(torch.autograd.Function):
             if flag & 2:
                 _lazy.key_bits = 0
                 hint = None
+            if flag & 8:
+                _lazy.trust_hints, trusted = False, False
             ctx.lazy_token = None
-            if n <= cap and not (flag & 2):
+            if n <= cap and not (flag & 10):
                 break
             cap = max(cap, _lazy.capacity[key])                           # repeat with what it needs
         if _ORDER_HINT:
-            _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version), words=words,
+            _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version), words=words, zkey=zkey,
                                    stream=stream_id)
         ctx.cfg, ctx.sc, ctx.rp = cfg, sc, rp
         ctx.save_for_backward(xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img)
         ctx.cap = cap
         ctx.m2d_leaf = means2D
         ctx.mark_non_differentiable(radii)
+        # an output nobody differentiates (depth / alpha of the shifted render, train.py:128-129) arrives as None in the
+        # backward, not as an image of zeros the blend backward would have to read
+        ctx.set_materialize_grads(False)
         # the chain of this iteration's renders of these parameters (see backward)
         ctx.batch_key = (di, P, K, int(cfg["sh_degree"]), float(cfg["scale_modifier"]), bool(cfg["debug"]),
                          tuple(t.data_ptr() for t in (xyz, f_dc, f_rest, scaling, rotation, opacity)))
@@ -710,7 +786,8 @@ class _RasterizeRaw(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        _lazy.confirm(ctx.lazy_token)     # truncated lists / key span: raises before any gradient exists
+        if ctx.lazy_token is not None and not ctx.lazy_token[4]:
+            _register_task(token=ctx.lazy_token)    # truncated lists / key span: raised at the end of THIS backward()
         saved = ctx.saved_tensors
         params = saved[:6]
         dev = params[0].device
@@ -743,8 +820,9 @@ class _RasterizeRaw(torch.autograd.Function):
         return (None,) * 8
 
 
-def rasterize_raw(pc, means2D, raster_settings):
-    """render()'s fast path: `pc` = a model raw_model_ok() accepts.  -> (color, radii, depth, alpha)."""
+def rasterize_raw(pc, means2D, raster_settings, camera=None):
+    """render()'s fast path: `pc` = a model raw_model_ok() accepts.  -> (color, radii, depth, alpha).  `camera` (optional):
+    the object the matrices of `raster_settings` came from, for camera_depth_key()."""
     rs = raster_settings
     dev = pc._xyz.device
     t = [_dev_f32(x, n).reshape(-1) for x, n in ((rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"), (rs.projmatrix, "projmatrix"),
@@ -754,7 +832,7 @@ def rasterize_raw(pc, means2D, raster_settings):
     params = (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)
     cfg = dict(W=int(rs.image_width), H=int(rs.image_height), tanfovx=rs.tanfovx, tanfovy=rs.tanfovy, bg=t[0],
                scale_modifier=rs.scale_modifier, viewmatrix=t[1], projmatrix=t[2], campos=t[3], sh_degree=rs.sh_degree,
-               debug=rs.debug,
+               debug=rs.debug, zkey=camera_depth_key(camera) if (camera is not None and _ORDER_HINT) else False,
                differentiated=torch.is_grad_enabled() and any(p.requires_grad for p in params + (means2D,)))
     del dev
     return _RasterizeRaw.apply(*params, means2D, cfg)

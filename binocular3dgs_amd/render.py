@@ -92,7 +92,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     if fused_node:
-        rendered_image, radii, depth, alpha = rasterize_raw(pc, screenspace_points, raster_settings)
+        rendered_image, radii, depth, alpha = rasterize_raw(pc, screenspace_points, raster_settings, viewpoint_camera)
         return {"render": rendered_image,
                 "viewspace_points": screenspace_points,
                 "visibility_filter": radii > 0,

@@ -189,7 +189,8 @@ typedef struct B3gsForwardView {
    * Bits of the word: 0 = capacity, 1 = a depth key outside the 27-bit span (depth_key_bits), 2 (ABI 7) = the second
    * binning round's persistent launch timed out at its grid barrier (its workgroups were not co-resident: a shared or
    * partitioned device) -- the repaired tiles of that forward are wrong, the step is dropped like an overflowing one and
-   * the caller goes back to one round (seg1_fraction = 0). */
+   * the caller goes back to one round (seg1_fraction = 0); 3 (ABI 7) = a TRUSTED depth-order hint was wrong
+   * (hint_trusted): the view was rendered from another view's depth order. */
   int32_t* high_water;
   int32_t* overflow_flag;
   /* 27: the caller vouches that every visible Gaussian's depth key (float bits of view z > 0.2) lies within 2^27 of the
@@ -214,6 +215,11 @@ typedef struct B3gsForwardView {
    * Only for views that sort their own keys (depth_order_from == -1). */
   const char* depth_order_hint;
   int32_t* hint_mismatch;
+  /* != 0: the caller KNOWS the keys are equal (it built both view matrices and their z rows are the same bits): the depth
+   * sort is not even launched (an idle launch is ~5 us on this part, nine of them per view).  Still checked: a key that
+   * differs sets *hint_mismatch and raises bit 3 of *overflow_flag (required non-NULL then) -- that view was rendered from
+   * a wrong depth order, the step is dropped like an overflowing one and the caller stops trusting its knowledge. */
+  int32_t hint_trusted;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);

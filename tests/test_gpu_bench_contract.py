@@ -96,3 +96,24 @@ def test_rccl_call_signatures_on_a_one_rank_nccl_group(extra):
     assert x["views_per_rank"] == [8 if "--views" in extra else 6]
     if "--dp-graph" in extra:
         assert x["dp_graph"] is True, "the RCCL collectives must be capturable in the HIP graph"
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks_itself():
+    """`python bench.py --gpus 2` (the form the driver uses for N = 1) must not silently measure one rank: with no
+    WORLD_SIZE around it the script becomes the launcher (torch.distributed.run, one process per GPU -- here both ranks on
+    cuda:0 over gloo, the test hooks); a launcher whose rank count differs from --gpus is refused."""
+    env = dict(os.environ, B3GS_BENCH_BACKEND="gloo", B3GS_BENCH_SINGLE_DEVICE="1", B3GS_BENCH_SMALL_EXTRAS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--gaussians", "30000",
+           "--width", "208", "--height", "144", "--no-extras"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange"]["rccl_ranks"] == 2 and d["config"]["global_views"] == 12
+    # a launcher that started ONE rank for --gpus 2
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env1)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
