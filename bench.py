@@ -72,9 +72,10 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # a PMC pass of this script over itself
     ap.add_argument("--no-optimizer", action="store_true")
-    ap.add_argument("--optimizer", choices=("sharded", "b3gs", "torch"), default="sharded",
+    ap.add_argument("--optimizer", choices=("sharded", "b3gs", "torch"), default=None,
                     help="sharded: reduce-scatter -> one-launch Adam on 1/N -> all-gather (step.ShardedAdam; = the fused "
-                         "Adam on flat buffers at N=1); b3gs: all-reduce + replicated one-launch Adam; torch: "
+                         "Adam on flat buffers at N=1; the default on one rank); b3gs: all-reduce + replicated one-launch "
+                         "Adam (the default for N > 1, with the range-pipelined tail: --pipeline-ranges); torch: "
                          "torch.optim.Adam(fused=True), 12 launches")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dense-grad-rows", action="store_true",
@@ -84,8 +85,10 @@ def parse():
                     help="fused: b3gs_forward_raw_batch / backward (activations in-kernel, persistent scratch, no host "
                          "sync); dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
     ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched")
-    ap.add_argument("--pipeline-ranges", type=int, default=0,
-                    help="(--optimizer b3gs) cut the chain-rule / all-reduce / Adam tail into this many Gaussian ranges")
+    ap.add_argument("--pipeline-ranges", type=int, default=-1,
+                    help="(--optimizer b3gs) cut the chain-rule / all-reduce / Adam tail into this many Gaussian ranges: the "
+                         "all-reduce of range r overlaps the chain rule of range r+1 and the Adam of range r-1 (-1: 4 when a "
+                         "collective runs, else 0 = one all-reduce)")
     ap.add_argument("--loss", choices=("synthetic", "fused", "torch"), default="synthetic",
                     help="synthetic: fixed pixel gradients (the metric's definition); fused / torch: the loss block of "
                          "train.py:123-148 through b3gs_binocular_loss / through PyTorch ops")
@@ -98,6 +101,17 @@ def parse():
                     help="N > 1: capture the RCCL reduce-scatter / all-gather and the Adam launch in the iteration's HIP graph "
                          "too (default: graph for the rendering part, eager exchange)")
     return ap.parse_args()
+
+
+def resolve_defaults(args, world):
+    """N > 1: the gradient sum is the range-pipelined all-reduce behind a replicated one-launch Adam (same link bytes as
+    reduce-scatter + all-gather; the collectives hide behind the chain rule and the Adam of the neighbouring ranges, DESIGN
+    section 6); one rank: Adam on flat buffers with sparse gradient rows."""
+    if args.optimizer is None:
+        args.optimizer = "b3gs" if world > 1 else "sharded"
+    if args.pipeline_ranges < 0:
+        args.pipeline_ranges = 4 if (args.optimizer == "b3gs" and (world > 1 or args.dp_path)) else 0
+    return args
 
 
 def byte_model(P, V, N, HW, Tn, K=4):
@@ -118,6 +132,7 @@ class Job:
         from binocular3dgs_amd import synth
         from binocular3dgs_amd.render import PipelineParams
         from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
+        resolve_defaults(args, world)
         self.args, self.dev, self.rank, self.world, self.dp = args, dev, rank, world, dp
         self.P, self.W, self.H, self.fov, self.scaling, self.path = P, W, H, fov, scaling, path
         self.model = model = synth.synth_model(P, seed=args.seed, device=dev, width=W, height=H, fovx_deg=fov,
@@ -410,6 +425,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    resolve_defaults(args, world)
     if world != args.gpus:
         # the driver launches `torch.distributed.run --nproc-per-node N bench.py --gpus N`: a mismatch means the numbers
         # would be labelled with a GPU count that did not run
@@ -672,7 +688,33 @@ def measure_exchange(job, steps):
     per_rank = [None] * dist.get_world_size()
     dist.all_gather_object(per_rank, int(job.local_views))
     out["views_per_rank"] = per_rank
-    if isinstance(opt, ShardedAdam) and opt.collective():
+    st = job.stepper
+    if st.range_slab is not None:
+        # the pipelined tail: chain rule of range r+1 | all-reduce of range r | Adam of range r-1.  Stamps on the compute
+        # stream: `issued[r]` behind the chain rule of range r (= when its all-reduce may start), `reduced[r]` behind the wait
+        # for it, start / end around the whole tail.  overlap = sum of the per-range windows / the span they cover.
+        st.tail_events = []
+        for _ in range(steps):
+            job.eager_step()
+        torch.cuda.synchronize(job.dev)
+        evs, st.tail_events = st.tail_events, None
+        K = st.range_slab.K
+        tail = sum(e["start"].elapsed_time(e["end"]) for e in evs) / max(len(evs), 1)
+        chain = sum(e["start"].elapsed_time(e["issued"][K - 1]) for e in evs) / max(len(evs), 1)
+        win = [sum(e["issued"][r].elapsed_time(e["reduced"][r]) for e in evs) / max(len(evs), 1) for r in range(K)]
+        span = sum(e["issued"][0].elapsed_time(e["reduced"][K - 1]) for e in evs) / max(len(evs), 1)
+        t = torch.tensor([tail, chain, span] + win, dtype=torch.float64, device=job.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        w = dist.get_world_size()
+        out.update(tail_ms=round(float(t[0]), 4), chain_rule_ms=round(float(t[1]), 4), all_reduce_span_ms=round(float(t[2]), 4),
+                   all_reduce_window_ms=[round(float(x), 4) for x in t[3:]], ranges=K,
+                   exchange_bytes_per_rank=int(2 * (w - 1) / max(w, 1) * st.range_slab.flat.numel() * 4),
+                   what="pipelined tail (step.ViewShardedStep._reduce_and_update_pipelined): per Gaussian range, chain rule -> "
+                        "async all-reduce -> Adam; all_reduce_window_ms[r] = issue of range r's all-reduce (behind its chain "
+                        "rule) to the point the compute stream has waited for it, all_reduce_span_ms = first issue to last "
+                        "wait: windows that add up to more than the span ran concurrently with the chain rule / Adam of "
+                        "other ranges; link bytes per rank = 2 (N-1)/N of the slab")
+    elif isinstance(opt, ShardedAdam) and opt.collective():
         opt.record_events, opt.events = True, []
         for _ in range(steps):
             job.eager_step()

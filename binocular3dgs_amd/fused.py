@@ -350,6 +350,17 @@ class FusedRasterizer:
         Call it for disjoint ranges covering all Gaussians."""
         self._accumulate(pend, overwrite, grads, first, count)
 
+    def finish_views(self, pend, overwrite: bool = True):
+        """Per-Gaussian chain rule of the views in `pend` (from take_deferred()) for ALL Gaussians into the parameters'
+        `.grad`, dense rows -- the un-pipelined data-parallel tail (step.ViewShardedStep.reduce_and_update)."""
+        if not pend:
+            if overwrite:
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+            return
+        self._accumulate(pend, overwrite)
+
     def finish_deferred(self, overwrite: bool = True, touched_rows: Optional[torch.Tensor] = None):
         """overwrite=True stores the gradients (no zero-fill of the slab needed), False adds to them.  With
         `touched_rows` (int64 bitmap, one bit per Gaussian) the rows of Gaussians that received nothing are not stored

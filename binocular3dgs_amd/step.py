@@ -442,6 +442,8 @@ class ViewShardedStep:
         self.sparse_grad_rows = bool(sparse_grad_rows)
         self.touched_rows = None
         self._row_mask = None             # bitmap of the gradients now in the slab (None = dense)
+        self._pending_views = None        # views whose chain rule reduce_and_update() still has to run (data parallel)
+        self.tail_events = None           # bench: list that receives the HIP events of every pipelined tail
 
     @classmethod
     def from_global(cls, model, global_pairs, bg, rank: Optional[int] = None, world: Optional[int] = None, **kw):
@@ -513,11 +515,26 @@ class ViewShardedStep:
             self.touched_rows = torch.zeros(words, dtype=torch.int64, device=self.bg.device)
         return self.touched_rows
 
+    def _collective(self, group=None) -> bool:
+        group = group if group is not None else self.group
+        return _dist_on() and (dist.get_world_size(group) > 1 or self.slab.force_collective)
+
+    def _chain_rule_after_agreement(self) -> bool:
+        """Data parallel + fused path: compute_grads() stops behind the blend backward and reduce_and_update() runs the
+        per-Gaussian chain rule AFTER the ranks have agreed on the overflow word -- the chain-rule pass is what folds the
+        densification statistics in, and a rank that did not overflow itself must not count a step the others drop
+        (the statistics of the replicas diverged by exactly those steps)."""
+        return self.fused is not None and (self.range_slab is not None or self._collective())
+
     def reduce_and_update(self):
-        """The exchange step of the data-parallel path (one collective over the flat slab) + optimiser."""
+        """The exchange step of the data-parallel path (collectives over the gradient slab) + optimiser."""
         self._agree_on_overflow()
         if self.range_slab is not None:
             return self._reduce_and_update_pipelined()
+        if self._pending_views is not None:          # chain rule of this rank's views, now that the overflow word is agreed
+            # (the list is NOT cleared: a HIP graph that captured compute_grads() is replayed without re-running its Python)
+            self.slab.rebind()
+            self.fused.finish_views(self._pending_views, overwrite=True)
         mask, self._row_mask = self._row_mask, None
         if isinstance(self.optimizer, ShardedAdam):
             self.slab.rebind()
@@ -565,10 +582,18 @@ class ViewShardedStep:
         return newP
 
     def _reduce_and_update_pipelined(self, group=None):
+        """Chain rule of range r+1 overlaps the all-reduce of range r; Adam of range r overlaps the all-reduce of range r+1
+        (the collectives run on the backend's own stream: an async all-reduce waits for what the compute stream had queued
+        when it was issued, and `wait()` makes the compute stream wait for that one collective only)."""
         from . import _lib
         rs, fr, opt = self.range_slab, self.fused, self.optimizer
         group = group if group is not None else self.group
-        collective = _dist_on() and (dist.get_world_size(group) > 1 or self.slab.force_collective)
+        collective = self._collective(group)
+        ev = None
+        if self.tail_events is not None:     # bench: issue / completion stamps of every range on the compute stream
+            mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+            ev = {"start": mk(), "issued": [mk() for _ in range(rs.K)], "reduced": [mk() for _ in range(rs.K)], "end": mk()}
+            ev["start"].record()
         works = []
         for r in range(rs.K):
             first, count = rs.rows(r)
@@ -578,14 +603,21 @@ class ViewShardedStep:
                 setattr(gr, name, (ptr - 4 * w * first) if w else None)     # indexed by the GLOBAL Gaussian index
             if self._pending_views:
                 fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True)
+            if ev:
+                ev["issued"][r].record()
             works.append(dist.all_reduce(rs.chunk(r), op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None)
         for r in range(rs.K):
             if works[r] is not None:
                 works[r].wait()                     # the compute stream waits for that range's all-reduce only
+            if ev:
+                ev["reduced"][r].record()
             if self.average and collective:
                 rs.chunk(r).div_(dist.get_world_size(group))
             first, count = rs.rows(r)
             opt.step_rows(first, count, rs.grad_ptrs(r), last=(r == rs.K - 1))
+        if ev:
+            ev["end"].record()
+            self.tail_events.append(ev)
 
     def sync_densify_stats(self, group=None):
         """Make the densification statistics identical on every replica before a densify/prune decision
@@ -623,6 +655,7 @@ class ViewShardedStep:
         if not self.views:
             # a rank without views (more ranks than views) contributes zeros to the collective
             self.slab.zero()
+            self._pending_views = None
             if self.range_slab is not None:
                 self.range_slab.flat.zero_()
                 self._pending_views = []
@@ -652,10 +685,11 @@ class ViewShardedStep:
         if self.fused is None:
             self._update_densify_stats(pkgs)
         if self.fused is not None:
-            if self.range_slab is None:
+            if not self._chain_rule_after_agreement():
+                self._pending_views = None
                 self._row_mask = self._sparse_rows()
                 self.fused.finish_deferred(overwrite=True, touched_rows=self._row_mask)
-            else:   # reduce_and_update() runs the chain rule range by range
+            else:   # reduce_and_update() runs the chain rule (range by range when the tail is pipelined)
                 self._pending_views = self.fused.take_deferred()
         self.last_stats = {"views": len(self.views)}
         return len(self.views)

@@ -78,7 +78,38 @@ def test_ranks_sharing_the_gpu_run_the_multi_gpu_control_flow(world):
     assert ex["config5_2M_1600x1600_8_views"]["views_per_rank"] == ([4, 4] if world == 2 else [1] * 8)
     x = d["exchange"]          # what the SCALE record is checked against: the group, every rank's views, the collectives' time
     assert x["backend"] == "gloo" and x["rccl_ranks"] == world and x["views_per_rank"] == [6] * world
-    assert x["reduce_scatter_ms"] > 0 and x["all_gather_ms"] > 0 and x["exchange_bytes_per_rank"] > 0
+    # N > 1 default: replicated one-launch Adam behind the range-pipelined all-reduce tail
+    assert x["optimizer"] == "FusedAdam" and x["ranges"] == 4 and d["config"]["dp_tail_ranges"] == 4
+    assert x["tail_ms"] > 0 and len(x["all_reduce_window_ms"]) == 4 and x["exchange_bytes_per_rank"] > 0
+
+
+def test_sharded_adam_stays_selectable_for_n_ranks():
+    """--optimizer sharded at N > 1: reduce-scatter -> Adam on 1/N -> all-gather, with the chain rule behind the overflow
+    agreement (two ranks on cuda:0 over gloo)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, B3GS_BENCH_BACKEND="gloo", B3GS_BENCH_SINGLE_DEVICE="1", B3GS_BENCH_SMALL_EXTRAS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--gaussians", "30000", "--width", "208", "--height", "144", "--no-extras", "--optimizer", "sharded"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    x = d["exchange"]
+    assert x["optimizer"] == "ShardedAdam" and x["reduce_scatter_ms"] > 0 and x["all_gather_ms"] > 0
+
+
+def test_pipelined_tail_on_a_one_rank_nccl_group():
+    """The N > 1 default (--optimizer b3gs, four ranges) on the REAL backend: async all_reduce per range + wait(), issued
+    with the arguments an 8-GPU run issues them with; the exchange record carries the overlapped schedule."""
+    d = _run("--dp-path", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--optimizer", "b3gs")
+    x = d["exchange"]
+    assert x["backend"] == "nccl" and x["rccl_ranks"] == 1 and x["optimizer"] == "FusedAdam" and x["ranges"] == 4
+    assert d["config"]["dp_tail_ranges"] == 4 and x["tail_ms"] > 0 and x["chain_rule_ms"] > 0
+    assert len(x["all_reduce_window_ms"]) == 4 and x["all_reduce_span_ms"] > 0
 
 
 @pytest.mark.parametrize("extra", [pytest.param(("--scaling", "strong", "--views", "8"), id="strong_8_views"),
@@ -88,7 +119,7 @@ def test_rccl_call_signatures_on_a_one_rank_nccl_group(extra):
     group, so that reduce_scatter_tensor / all_gather_into_tensor / all_reduce / barrier are issued with exactly the
     arguments an 8-GPU run issues them with (every other N > 1 test uses gloo).  strong_8_views: configs[4]'s view-granular
     sharding; weak_collectives_in_graph: the collectives and the Adam launch captured in the iteration's HIP graph."""
-    d = _run("--dp-path", "--no-extras", "--no-pmc", "--no-cpu-baseline", *extra)
+    d = _run("--dp-path", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--optimizer", "sharded", *extra)
     assert d["value"] > 0 and d["n_gpus"] == 1
     x = d["exchange"]
     assert x["backend"] == "nccl" and x["rccl_ranks"] == 1 and x["optimizer"] == "ShardedAdam"
