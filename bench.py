@@ -641,10 +641,21 @@ def main():
             j.prepare(2)
             el = j.timed_best(5)
             extras["dropin_iters_per_s"] = round(5 / el, 2)
-            extras["dropin_what"] = ("the same iteration through the reference-shaped surface: render() -> "
-                                     "GaussianRasterizer -> _C.rasterize_gaussians per view, PyTorch activations; "
-                                     "num_rendered read back for the first render of a shape only (rasterizer._LazyN)")
+            extras["dropin_what"] = ("the same 6-view iteration through the zero-change surface: render() per view (one "
+                                     "autograd node on the raw parameters each, rasterizer._RasterizeRaw) + torch.autograd."
+                                     "backward + one-launch Adam.  Behind that surface the shifted view of every pair adopts its "
+                                     "input view's depth order (device-checked, ABI 7) and the six nodes of the backward launch "
+                                     "ONE blend backward + ONE chain-rule pass (engine-checked self-accumulation); the forward of "
+                                     "each view stays a single-view pipeline: render() must return finished tensors")
+            from binocular3dgs_amd import rasterizer as _R
+            extras["dropin_stats"] = dict(_R._stats)
             del j
+            torch.cuda.empty_cache()
+            # the reference's own iteration shape (one random input view + one random shifted partner, cameras changing every
+            # step): launch-latency-bound, the regime the round-3 verdict asked to see measured on every surface
+            import bench_ref_schedule
+            extras["reference_schedule"] = bench_ref_schedule.table(dev, args.fov, args.seed,
+                                                                    steps=20 if os.environ.get("B3GS_BENCH_SMALL_EXTRAS") else 40)
             torch.cuda.empty_cache()
     if rank == 0:
         if extras:

@@ -191,6 +191,17 @@ def restore(model, model_args: tuple, optimizer=None, optimizer_factory=None):
     if optimizer is None:
         return None
     if isinstance(optimizer, torch.optim.Optimizer):
+        # the optimiser must own THESE parameter tensors: when the checkpoint's shapes differed from the model's, fresh
+        # Parameters were just installed and an optimiser built before that still holds the old ones -- load_state_dict()
+        # validates no shapes, so the moments would be attached to stale tensors and the restored parameters never stepped
+        # (the reference rebuilds its optimiser in training_setup() before load_state_dict, scene/gaussian_model.py:90-93)
+        owned = [p for g in optimizer.param_groups for p in g["params"]]
+        mine = list(model.parameters())
+        if not (len(owned) == len(mine) and {p.data_ptr() for p in owned if p.numel()} == {p.data_ptr() for p in mine if p.numel()}
+                and sorted(tuple(p.shape) for p in owned) == sorted(tuple(p.shape) for p in mine)):
+            raise ValueError("restore(): the torch optimizer does not own the model's (restored) parameter tensors -- the "
+                             "checkpoint changed their shapes; pass optimizer_factory=lambda model: <build the optimizer> "
+                             "instead of an optimizer built for the old Gaussian count")
         optimizer.load_state_dict(_by_group_name(optimizer, opt_dict))
         model.optimizer = optimizer
         return optimizer

@@ -801,15 +801,15 @@ struct MultiViews {
 //           one LDS atomic per wave;
 //   phase 2 (compute, compacted): lane = list entry; the view loop runs only over the entry's touched views
 //           (row read + reset, chain rule, 23 gradients in registers), gradients written once.
-#ifndef B3GS_ACC_PER_THREAD
-#define B3GS_ACC_PER_THREAD 4
-#endif
-constexpr int ACC_PER_THREAD = B3GS_ACC_PER_THREAD;
-constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
-
+// ACC_PER_THREAD Gaussians per thread = 1024 per workgroup for big calls (1M Gaussians: 977 workgroups); calls over fewer
+// Gaussians -- a 100k scene, one range of the pipelined data-parallel tail -- take ONE per thread: with 1024 per workgroup
+// they were a quarter of a workgroup per CU and pure latency (100k Gaussians, 2 views: 76 us in the chain-rule kernel;
+// a 250k-Gaussian range of the headline scene: 86 us per call whatever the range held)
+template <int ACC_PER_THREAD>
 __global__ void __launch_bounds__(256, 8)
     accumulate_scan_kernel(B3gsScene base, MultiViews mv, B3gsRawGrads rg, int overwrite, int first, int count,
                            B3gsDensifyStats ds, uint32_t* __restrict__ g_list, uint32_t* __restrict__ g_count) {
+  constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
   __shared__ uint32_t s_list[ACC_BLOCK];
   __shared__ uint32_t s_count;
   if (threadIdx.x == 0) s_count = 0;
@@ -912,9 +912,11 @@ struct ShPairReg {
 // (sigmoid chain of the opacity) and stores it.
 constexpr int CH_GROUP = 256;
 constexpr int CH_ROW = 25;      // 23 gradients per Gaussian, odd row stride: conflict-free column access
+template <int ACC_PER_THREAD>
 __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
     accumulate_chain_kernel(B3gsScene base, B3gsRawParams raw, MultiViews mv, B3gsRawGrads rg, int overwrite, int first,
                             const uint32_t* __restrict__ g_list, const uint32_t* __restrict__ g_count) {
+  constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
   __shared__ float s_acc[CH_GROUP][CH_ROW];
   __shared__ uint8_t s_idx[B3GS_MAX_FUSED_VIEWS][CH_GROUP];   // (view, position) -> entry of the group
   __shared__ uint32_t s_wcnt[B3GS_MAX_FUSED_VIEWS][4];
@@ -1110,9 +1112,17 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   const B3gsDensifyStats ds = stats ? *stats : B3gsDensifyStats{nullptr, nullptr, nullptr, nullptr};
   // scratch of the two-kernel pass: the depth-sort ping-pong arrays of view 0's geometry buffer (P words each) are idle
   // once the forward has built its tile lists
-  const dim3 grid((count + ACC_BLOCK - 1) / ACC_BLOCK);
-  hipLaunchKernelGGL(accumulate_scan_kernel, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
-  hipLaunchKernelGGL(accumulate_chain_kernel, grid, dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
+  static const int force = getenv("B3GS_ACC_PER_THREAD") ? atoi(getenv("B3GS_ACC_PER_THREAD")) : 0;   // (A/B switch)
+  const bool big = force ? force >= 4 : count >= (1 << 19) + (1 << 18);   // from 768k Gaussians: 1024 per workgroup
+  if (big) {
+    const dim3 grid((count + 1023) / 1024);
+    hipLaunchKernelGGL(accumulate_scan_kernel<4>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
+    hipLaunchKernelGGL(accumulate_chain_kernel<4>, grid, dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
+  } else {
+    const dim3 grid((count + 255) / 256);
+    hipLaunchKernelGGL(accumulate_scan_kernel<1>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
+    hipLaunchKernelGGL(accumulate_chain_kernel<1>, grid, dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
+  }
 }
 
 void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, uint8_t* present,

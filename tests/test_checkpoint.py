@@ -161,6 +161,28 @@ def test_restore_into_a_torch_optimizer_in_model_order_pairs_groups_by_name():
         np.testing.assert_allclose(p.detach().numpy(), z[f"after_{n}"], rtol=1e-6, atol=1e-9)
 
 
+def test_restore_refuses_a_torch_optimizer_built_for_another_gaussian_count():
+    """a checkpoint with other shapes installs fresh Parameters; a torch optimiser built before that owns the old
+    tensors and load_state_dict() would attach the moments to them silently.  restore() raises; optimizer_factory works."""
+    z, st = gold()
+    m = model_from_gold(z)
+    opt = FusedAdam(m.parameters(), lrs_model_order(st), eps=st["group_eps"])
+    load_moments(opt, z)
+    tup = m.capture(opt)
+    m3 = GaussianModel.from_tensors(*[torch.zeros((5,) + tuple(p.shape[1:])) for p in m.parameters()], sh_degree=1)
+    stale = torch.optim.Adam([{"params": [p], "lr": 0.5, "name": n} for p, n in zip(m3.parameters(), MODEL_ORDER)], lr=0.0, eps=1e-15)
+    with pytest.raises(ValueError, match="optimizer_factory"):
+        m3.restore(tup, None, optimizer=stale)
+
+    def factory(model):
+        return torch.optim.Adam([{"params": [p], "lr": 0.5, "name": n} for p, n in zip(model.parameters(), MODEL_ORDER)],
+                                lr=0.0, eps=1e-15)
+    m4 = GaussianModel.from_tensors(*[torch.zeros((5,) + tuple(p.shape[1:])) for p in m.parameters()], sh_degree=1)
+    topt = m4.restore(tup, None, optimizer_factory=factory)
+    for p, n in zip(m4.parameters(), MODEL_ORDER):
+        assert p.shape[0] == m.get_xyz.shape[0] and np.array_equal(topt.state[p]["exp_avg"].numpy(), z[f"m_{n}"]), n
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scene"), reason="the reference tree exists in the build container only")
 def test_reference_restore_consumes_our_tuple():
     """Live check (build container): the reference's own GaussianModel.restore() takes the tuple this build captured and
