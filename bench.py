@@ -461,6 +461,12 @@ def main():
     value = iters / elapsed
     mpix = views_per_iter * W * H * args.steps / elapsed / 1e6
 
+    if args.inner:      # a counter pass of this script over itself: the timed region is the last thing that runs
+        torch.cuda.synchronize(dev)
+        if dp:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ms, inst_per_launch = ({k: 0.0 for k in ("preprocess", "sort", "render_fwd", "render_bwd", "preprocess_bwd")}, None)
     if job.local_views:
         ms, inst_per_launch = job.kernel_times(min(args.steps, 20))
@@ -744,6 +750,7 @@ def measure_exchange(job, steps):
 
 
 # ---- rocprofv3 counter passes over a short copy of the same workload (MI355X_MICROARCH.md, HBM / PMC sections) ------
+PMC_STEPS = 3
 FWD_KERNELS = re.compile(r"preprocess_fwd|radix|scan_chunk|emit_instances|tile_ranges|render_fwd|repair_kernel")
 
 
@@ -753,20 +760,29 @@ def _pmc_pass(args, counters, tag):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     out = tempfile.mkdtemp(prefix=f"b3gs_pmc_{tag}_", dir="/tmp")
     cmd = [exe, "--kernel-trace", "--pmc", *counters.split(), "--output-format", "csv", "-d", out, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--inner", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--steps", "3",
-           "--warmup", "1", "--gaussians", str(args.gaussians), "--width", str(args.width), "--height", str(args.height),
-           "--seed", str(args.seed), "--optimizer", args.optimizer, "--schedule", args.schedule]
+           os.path.join(ROOT, "bench.py"), "--inner", "--no-extras", "--no-pmc", "--no-cpu-baseline", "--steps", str(PMC_STEPS),
+           "--warmup", str(args.warmup), "--gaussians", str(args.gaussians), "--width", str(args.width), "--height",
+           str(args.height), "--seed", str(args.seed), "--optimizer", args.optimizer, "--schedule", args.schedule]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
         files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             raise RuntimeError("no counter_collection.csv")
-        acc = {}
+        rows = []
         for r in csv.DictReader(open(files[0])):
             name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
             name = re.sub(r"^void ", "", name).split("(")[0].split("<")[0]
-            acc.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            rows.append((int(r["Dispatch_Id"]), name, r["Counter_Name"], float(r["Counter_Value"])))
+        # Only the launches of the TIMED region count: the same W warm-up steps as the measured run precede it (settled
+        # open-tile prediction: no repair round, the state the wall clock saw), and `--inner` exits right behind its K timed
+        # steps -- so everything after the Adam launch of the last step before them (the K+1-th last) is the timed region.
+        adam = sorted({d for d, n, _c, _v in rows if n == "adam_kernel"})
+        cutoff = adam[-(PMC_STEPS + 1)] if len(adam) > PMC_STEPS else -1
+        acc = {}
+        for d, name, counter, value in rows:
+            if d > cutoff:
+                acc.setdefault(name, {}).setdefault(counter, []).append(value)
         return acc
     finally:
         shutil.rmtree(out, ignore_errors=True)
@@ -789,12 +805,14 @@ def pmc_passes(args, result):
     mean = lambda v: sum(v) / len(v)  # noqa: E731
     per_launch = {k: int((2.0 * mean(c.get("FETCH_SIZE", [0.0])) + mean(write.get(k, {}).get("WRITE_SIZE", [0.0]))) * 1024)
                   for k, c in fetch.items()}
+    read_launch = {k: int(2.0 * mean(c.get("FETCH_SIZE", [0.0])) * 1024) for k, c in fetch.items()}
     n_fwd = len(fetch.get("render_fwd_kernel", {}).get("FETCH_SIZE", [])) or 1
     n_bwd = len(fetch.get("render_bwd_kernel", {}).get("FETCH_SIZE", [])) or 1
-    per_iter = 0.0
+    per_iter = read_iter = 0.0
     for k, c in fetch.items():
         n = len(c.get("FETCH_SIZE", []))
         per_iter += per_launch[k] * n / (n_fwd if FWD_KERNELS.search(k) else n_bwd)
+        read_iter += read_launch[k] * n / (n_fwd if FWD_KERNELS.search(k) else n_bwd)
     roof["traffic"] = per_launch.get(roof["kernel"])
     if roof["traffic"] and roof["avg_launch_ms"] > 0:
         roof["traffic_GBps"] = round(roof["traffic"] / (roof["avg_launch_ms"] / 1e3) / 1e9, 1)
@@ -803,9 +821,13 @@ def pmc_passes(args, result):
     result["hbm_measured"] = {
         "bytes_per_iter": int(per_iter), "GBps": round(per_iter / (result["ms_per_step"] / 1e3) / 1e9, 1),
         "frac_of_peak": round(per_iter / (result["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+        # north_star's figure is the READ side: 2 x FETCH_SIZE only
+        "read_bytes_per_iter": int(read_iter), "read_GBps": round(read_iter / (result["ms_per_step"] / 1e3) / 1e9, 1),
+        "read_frac_of_peak": round(read_iter / (result["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
         "method": "rocprofv3 --kernel-trace --pmc, separate passes for FETCH_SIZE / WRITE_SIZE over `bench.py --inner "
-                  "--steps 3 --warmup 1` (same workload); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, summed over one "
-                  "iteration's launches",
+                  f"--steps {PMC_STEPS} --warmup W` (same workload, same W warm-up steps as this run, only the launches of "
+                  "its timed steps counted); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, summed over one iteration's "
+                  "launches; read_* = the 2 x FETCH_SIZE part alone",
         # 28 B per parameter float when every Gaussian has a gradient; with the sparse-row slab (one rank) the gradient
         # of an untouched Gaussian is not read: between 24 and 28 B
         "calibration_adam_bytes": per_launch.get("adam_kernel"), "calibration_adam_expected": [24 * n_par, 28 * n_par],
@@ -889,13 +911,40 @@ def cpu_baseline(P, W, H, seed):
             bwd_s += t2 - t1
             nviews += 1
     it_s = fwd_s + bwd_s
-    return {"value": round(1.0 / it_s, 5), "unit": "iters/s", "cores": threads, "physical_cores": physical,
+    direct = {"value": round(1.0 / it_s, 5), "ms_per_view": round(it_s / nviews * 1e3, 1),
+              "sample": f"1 full iteration = {nviews} views fwd+bwd at full size: fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; "
+                        f"oracle/tile_ref.c called directly on torch-activated inputs, per-view gradients NOT summed, NO "
+                        f"optimiser step (the kernel-only figure earlier rounds reported: it flatters the CPU)"}
+    # SURVEY 8(d)'s definition: the reference's CPU render PATH -- render() with convert_SHs_python / compute_cov3D_python
+    # (SH -> RGB and the 3D covariance as PyTorch-CPU ops with their autograd, gaussian_renderer/__init__.py:59-83) around
+    # the rasterizer call, one backward per view accumulating into .grad (the gradient sum over the six views), Adam
+    import binocular3dgs_amd.render as R
+    from binocular3dgs_amd.render import PipelineParams, render
+    from oracle.cpu_render import OracleRasterizer
+    model = synth.synth_model(P, seed=seed, device="cpu", width=W, height=H, requires_grad=True)
+    pipe = PipelineParams(convert_SHs_python=True, compute_cov3D_python=True)
+    bg = torch.zeros(3)
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(model.parameters(), LRS)], lr=0.0, eps=1e-15)
+    was = R.GaussianRasterizer
+    R.GaussianRasterizer = OracleRasterizer
+    try:
+        t0 = time.perf_counter()
+        for cam, scam, _t in synth.synth_view_set(W, H):
+            pkg = render(cam, model, pipe, bg)
+            torch.autograd.backward([pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"]], [gc, gd, ga])
+            spkg = render(scam, model, pipe, bg)
+            torch.autograd.backward([spkg["render"]], [gc2])
+        opt.step()
+        path_s = time.perf_counter() - t0
+    finally:
+        R.GaussianRasterizer = was
+    return {"value": round(1.0 / path_s, 5), "unit": "iters/s", "cores": threads, "physical_cores": physical,
             "cpu_model": cpu_model, "kind": "port",
-            "sample": f"1 full iteration = {nviews} views fwd+bwd at full size P={P} {W}x{H}: fwd {fwd_s:.2f}s bwd {bwd_s:.2f}s; "
-                      f"oracle/tile_ref.c called directly on torch-activated inputs (not through render() with the "
-                      f"*_python sub-steps of SURVEY 8d), per-view gradients NOT summed, NO Adam step: it flatters the CPU; "
-                      f"OpenMP {threads} threads ({physical} physical cores, {cpu_model})",
-            "ms_per_view": round(it_s / nviews * 1e3, 1)}
+            "sample": f"1 full iteration at full size P={P} {W}x{H} through the reference-shaped CPU render path: render() per "
+                      f"view with convert_SHs_python + compute_cov3D_python on PyTorch-CPU around oracle/tile_ref.c (OpenMP), "
+                      f"torch autograd, gradients of the {nviews} views summed in .grad, torch.optim.Adam: {path_s:.2f}s; "
+                      f"{threads} threads ({physical} physical cores, {cpu_model})",
+            "ms_per_view": round(path_s / nviews * 1e3, 1), "oracle_kernels_only": direct}
 
 
 if __name__ == "__main__":

@@ -348,7 +348,10 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
 }
 
 template <int CHUNK, bool TRACE>
-__global__ void __launch_bounds__(256) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
+#ifndef B3GS_FWD_WAVES
+#define B3GS_FWD_WAVES 1
+#endif
+__global__ void __launch_bounds__(256, B3GS_FWD_WAVES) render_fwd_kernel(BlendBatch batch, unsigned long long* __restrict__ trace) {
   __shared__ TileShared<CHUNK> sh;
   __shared__ uint32_t s_work[4];
   // longest-tile-first order of the previous backward of this batch shape, if the buffer holds one (BlendBatch::sig)

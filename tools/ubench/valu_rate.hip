@@ -32,6 +32,10 @@ __global__ void __launch_bounds__(256) k(float* out, float seed) {
         a[i] = x.x; a[i + 1] = x.y;
       }
       if (KIND == 8) { int t = __builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x140, 0xF, 0xF, false); a[i] = a[i] + __int_as_float(t); }
+      // a full-wave rotate by one lane (DPP wave_ror:1, gfx9 only): what a systolic walk of pixel states across candidate
+      // lanes would pay per state register and step (round 4, DESIGN Appendix A)
+      if (KIND == 11) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x13C, 0xF, 0xF, false));
+      if (KIND == 12) { int t = __builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x13C, 0xF, 0xF, false); a[i] = __builtin_fmaf(__int_as_float(t), 1.0001f, a[i]); }
     }
   }
   float s = 0;
@@ -62,6 +66,7 @@ int main() {
       run<3>("v_exp_f32", occ, out); run<4>("v_rcp_f32", occ, out); run<5>("v_permlane32_swap", occ, out);
       run<6>("v_min_f32", occ, out); run<7>("v_cmp+v_cndmask", occ, out);
       run<9>("v_pk_fma_f32 (x0.5 instr)", occ, out); run<10>("v_pk_mul_f32 (x0.5 instr)", occ, out);
+      run<11>("v_mov_b32_dpp wave_ror:1", occ, out); run<12>("v_fma_f32_dpp wave_ror:1", occ, out);
     }
   }
   return 0;
