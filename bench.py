@@ -84,7 +84,8 @@ def parse():
     ap.add_argument("--path", choices=["fused", "dropin"], default="fused",
                     help="fused: b3gs_forward_raw_batch / backward (activations in-kernel, persistent scratch, no host "
                          "sync); dropin: the reference-shaped render() -> _C.rasterize_gaussians surface")
-    ap.add_argument("--schedule", choices=("batched", "streams", "serial"), default="batched")
+    ap.add_argument("--schedule", choices=("batched", "groups", "streams", "serial"), default="batched")
+    ap.add_argument("--groups", type=int, default=2, help="(--schedule groups) batches of pairs that run their forward on streams of their own")
     ap.add_argument("--pipeline-ranges", type=int, default=-1,
                     help="(--optimizer b3gs) cut the chain-rule / all-reduce / Adam tail into this many Gaussian ranges: the "
                          "all-reduce of range r overlaps the chain rule of range r+1 and the Adam of range r-1 (-1: 4 when a "
@@ -174,6 +175,7 @@ class Job:
             model.init_densification_stats()
             fused = FusedRasterizer(model, W, H, num_slots=max(local_views, 1), want_means2D=bool(args.viewspace_grads),
                                     schedule="serial" if args.serial_views else args.schedule, seg1_fraction=seg1_fraction)
+            fused.groups = int(getattr(args, "groups", 2))
         self.fused = fused
         pipe_ranges = args.pipeline_ranges if dp and fused is not None and args.optimizer == "b3gs" else 0
         kw = dict(optimizer=opt, fused=fused, pipeline_ranges=pipe_ranges, overflow_check_every=0,

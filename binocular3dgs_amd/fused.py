@@ -106,7 +106,7 @@ class FusedRasterizer:
         #              one depth sort;  "streams": each view's forward on its own stream;  "serial": one stream,
         #              per-view projection + binning, one blend launch
         self.schedule = schedule or ("batched" if concurrent else "serial")
-        assert self.schedule in ("batched", "streams", "serial")
+        assert self.schedule in ("batched", "groups", "streams", "serial")
         self.concurrent = self.schedule == "streams"
         self._want_m2d = want_means2D
         # Two-round binning (schedule "batched"): bin the nearest seg1_fraction of the depth order, blend, bin the rest
@@ -195,7 +195,7 @@ class FusedRasterizer:
 
     def _forward_batch(self, specs):
         self._forward_batch_launch(specs)
-        if self.schedule != "batched":    # (the batched launches update both words inside the binning kernels)
+        if self.schedule not in ("batched", "groups"):    # (the batched launches update both words inside the binning kernels)
             torch.maximum(self.high_water, self._n_all, out=self.high_water)
             self.overflow_flag.bitwise_or_((self._n_all > self.capacity).any().to(torch.int32))
 
@@ -204,9 +204,23 @@ class FusedRasterizer:
         main = torch.cuda.current_stream(self.dev)
         scenes = [self._scene(sp) for sp in specs]
         rp = self._bind_params()
-        if self.schedule == "batched":
-            for c0 in range(0, len(specs), MAX_BATCH):
-                chunk = specs[c0:c0 + MAX_BATCH]
+        if self.schedule in ("batched", "groups"):
+            # "groups" (experiment, round 4): the views are cut into `self.groups` batches that run their whole forward on
+            # streams of their own -- the ~25 launches of a forward are a serial chain of mostly latency-bound kernels, two
+            # independent chains interleave in each other's ramp-up / drain gaps.  Pairs stay together (shared depth sort).
+            if self.schedule == "groups" and len(specs) > 2:
+                per = max(2, 2 * (-(-len(specs) // (2 * getattr(self, "groups", 2)))))
+                bounds = list(range(0, len(specs), per))
+            else:
+                per, bounds = MAX_BATCH, list(range(0, len(specs), MAX_BATCH))
+            streams = [main] + [self.slots[k].stream for k in range(1, len(bounds))] if len(bounds) > 1 and self.schedule == "groups" else None
+            for gi, c0 in enumerate(bounds):
+                chunk = specs[c0:c0 + per]
+                st = main
+                if streams is not None:
+                    st = streams[gi]
+                    if st is not main:
+                        st.wait_stream(main)
                 arr = (_lib.B3gsForwardView * len(chunk))()
                 for k, sp in enumerate(chunk):
                     s = self.slots[sp["slot"]]
@@ -226,8 +240,11 @@ class FusedRasterizer:
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
-                rc = L.b3gs_forward_raw_batch(len(chunk), arr, C.byref(rp), 3, main.cuda_stream)
+                rc = L.b3gs_forward_raw_batch(len(chunk), arr, C.byref(rp), 3, st.cuda_stream)
                 _lib.check(rc, "b3gs_forward_raw_batch")
+            if streams is not None:
+                for st in streams[1:]:
+                    main.wait_stream(st)
             return
         if self.concurrent:
             # Every view runs its whole forward on its own stream.  Measured (1M Gaussians, 6 views): the

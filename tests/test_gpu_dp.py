@@ -135,3 +135,55 @@ def test_view_granular_split_pair_and_sharded_adam_on_one_gpu(tmp_path):
     rel = np.linalg.norm(r0["params"] - ref_params) / np.linalg.norm(ref_params)
     assert rel < 1e-6, rel
     np.testing.assert_array_equal(r0["denom"], ref_denom)
+
+
+def _worker_overflow(rank, world, port, out_dir, pipeline_ranges):
+    """Rank 1 renders from truncated tile lists (its slots claim a tiny capacity); rank 0 does not overflow."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.step import FusedAdam, ViewShardedStep, shard_pairs
+    W, H, P = 160, 120, 9000
+    dev = "cuda"
+    model = synth.synth_model(P, seed=13, device=dev, width=W, height=H)
+    model.init_densification_stats()
+    all_pairs = synth.synth_view_set(W, H, device=dev)
+    mine = shard_pairs(3, rank, world)
+    pairs = [all_pairs[i] for i in mine]
+    bg = torch.zeros(3, device=dev)
+    grads = {i: synth.synth_pixel_grads(W, H, seed=20 + i, device=dev) for i in range(3)}
+    opt = FusedAdam(model.parameters(), LRS, eps=1e-15)
+    fr = FusedRasterizer(model, W, H, num_slots=2 * len(pairs), want_means2D=False)
+    st = ViewShardedStep(model, pairs, bg, optimizer=opt, fused=fr, pipeline_ranges=pipeline_ranges, overflow_check_every=0)
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    if rank == 1:
+        for s in fr.slots:
+            s.capacity = 500           # (the buffers are larger: the kernels clamp to what they are told)
+
+    def fn(k, pkg, spkg):
+        gc, gd, ga = grads[mine[k]]
+        return [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]
+    for _ in range(2):
+        st.step(pair_grad_fn=fn)
+    torch.cuda.synchronize()
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    np.savez(os.path.join(out_dir, f"ovf{rank}.npz"), unchanged=bool(torch.equal(before, after)),
+             denom=float(model.denom.sum()), accum=float(model.xyz_gradient_accum.sum()), flag=int(fr.overflow_flag.item()),
+             step=int(opt.step_count.item()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipeline_ranges", [0, 3])
+def test_an_overflow_on_one_rank_drops_the_step_and_its_statistics_on_every_rank(tmp_path, pipeline_ranges):
+    """the overflow word is agreed (max over the ranks) BEFORE the chain-rule pass that folds the densification
+    statistics in -- a rank that did not overflow itself must not count a step the others drop.  Two ranks on cuda:0 over
+    gloo; rank 1 overflows: parameters, step counter and statistics stay untouched on BOTH."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_overflow, args=(2, _free_port(), str(tmp_path), pipeline_ranges), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "ovf0.npz"), np.load(tmp_path / "ovf1.npz")
+    for r in (r0, r1):
+        assert bool(r["unchanged"]) and int(r["step"]) == 0 and int(r["flag"]) != 0
+        assert float(r["denom"]) == 0.0 and float(r["accum"]) == 0.0
