@@ -10,6 +10,9 @@
 
 namespace {
 
+constexpr uint32_t B3GS_ADAM_SLOTS = 64u, B3GS_ADAM_SLOT_STRIDE = 32u;   // == B3GS_ADAM_STEP_WORDS of the header
+static_assert(2u + B3GS_ADAM_SLOTS * B3GS_ADAM_SLOT_STRIDE == B3GS_ADAM_STEP_WORDS, "step words");
+
 struct AdamSegs {
   int n;
   B3gsAdamSegment s[8];
@@ -108,12 +111,24 @@ __global__ void __launch_bounds__(256)
   }
   // the workgroup that finishes last advances the step counter (every workgroup has read it by then): no second launch.
   // The completion counter is the optimiser's own word next to its step (step_ptr[1], zero between launches).
+  // Two levels (ABI 7): up to 8192 workgroups arriving at ONE address is ~10-18 ns each once they pile up -- 85 us of a
+  // 105-us launch at 500k Gaussians, where the workgroups all finish together (tools/adam_time.py) -- so a workgroup counts
+  // itself in one of B3GS_ADAM_SLOTS counters a cache line apart and only the last of every slot touches the shared one.
   if (bump) {
     __syncthreads();
-    uint32_t* done = reinterpret_cast<uint32_t*>(step_ptr + 1);
-    if (threadIdx.x == 0 && atomicAdd(done, 1u) == gridDim.x - 1u) {
-      *done = 0u;
-      *step_ptr += 1;
+    if (threadIdx.x == 0) {
+      uint32_t* w = reinterpret_cast<uint32_t*>(step_ptr);
+      const uint32_t slot = blockIdx.x & (B3GS_ADAM_SLOTS - 1u);
+      const uint32_t mine = (gridDim.x - slot + B3GS_ADAM_SLOTS - 1u) / B3GS_ADAM_SLOTS;   // workgroups that share this slot
+      uint32_t* cnt = w + 2 + slot * B3GS_ADAM_SLOT_STRIDE;
+      if (atomicAdd(cnt, 1u) == mine - 1u) {
+        *cnt = 0u;
+        const uint32_t nslots = gridDim.x < B3GS_ADAM_SLOTS ? gridDim.x : B3GS_ADAM_SLOTS;
+        if (atomicAdd(w + 1, 1u) == nslots - 1u) {
+          w[1] = 0u;
+          *step_ptr += 1;
+        }
+      }
     }
   }
 }

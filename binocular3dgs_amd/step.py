@@ -76,10 +76,13 @@ class FlatGradSlab:
         return self.flat.numel() * 4
 
 
+ADAM_STEP_WORDS = 2 + 64 * 32     # B3GS_ADAM_STEP_WORDS of include/b3gs_raster.h
+
+
 def _step_words(dev):
-    """{step, completion counter of the in-kernel bump}: the two int32 words b3gs_adam_step's `device_step` points to
-    (ABI 6); `[:1]` of it is the optimiser's `step_count`."""
-    return torch.zeros(2, dtype=torch.int32, device=dev)
+    """{step, completion counter, 64 first-level completion counters a cache line apart}: the int32 words
+    b3gs_adam_step's `device_step` points to (ABI 7); `[:1]` of it is the optimiser's `step_count`."""
+    return torch.zeros(ADAM_STEP_WORDS, dtype=torch.int32, device=dev)
 
 
 def _bump_versions(params):

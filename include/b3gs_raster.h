@@ -318,11 +318,13 @@ typedef struct B3gsAdamSegment {
 /* `row_mask` (may be NULL): the touched_rows bitmap of B3gsRawGrads.  Element e of a segment with row_len > 0 belongs to
  * Gaussian first_row + e / row_len; when that Gaussian's bit is clear the gradient is taken as 0 WITHOUT reading it
  * (moments and parameter still follow Adam: same result as a dense zero gradient, 4 of 28 bytes per float less). */
-/* ABI 6: `device_step` points to TWO int32 words the optimiser owns: {step, workgroup-completion counter of the
- * in-kernel bump (zero between launches)} -- optimisers stepping concurrently on several streams no longer share a
- * module-global counter.  `skip_if_nonzero` (may be NULL): device word; when it is != 0 at launch time the call changes
+/* ABI 7: `device_step` points to B3GS_ADAM_STEP_WORDS int32 words the optimiser owns, ZERO apart from the first:
+ * {step, completion counter, 64 first-level completion counters a cache line apart} -- the workgroup that finishes last
+ * advances the step (no second launch); two levels because thousands of workgroups arriving at one address cost ~15 ns
+ * each (85 us of the launch at 500k Gaussians).  Optimisers stepping concurrently on several streams own their words.  `skip_if_nonzero` (may be NULL): device word; when it is != 0 at launch time the call changes
  * NOTHING (parameters, moments, step counter): the update of a step rendered from truncated tile lists is dropped on the
  * device, without a host round trip (B3gsForwardView::overflow_flag). */
+#define B3GS_ADAM_STEP_WORDS (2 + 64 * 32)
 int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t* device_step, float beta1, float beta2,
                    float eps, float opacity_decay, int32_t opacity_segment, int32_t opacity_decay_first,
                    int32_t bump_step_after, const uint64_t* row_mask, const int32_t* skip_if_nonzero,

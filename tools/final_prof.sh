@@ -5,7 +5,9 @@ tag=$1
 tools/prof.sh ${tag}_default --no-extras --no-pmc > gpurun_out/${tag}_prof_stdout.txt 2>&1
 grep '^{"metric"' gpurun_out/${tag}_default_bench.log | tail -1 > gpurun_out/${tag}_profiled_run_bench_line.json
 python bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric"' | tail -1 > gpurun_out/${tag}_default_bench_line.json
-export PMC_TARGET="bench.py --inner --no-extras --no-pmc --no-cpu-baseline --steps 3 --warmup 1"
+# (same warm-up as the driver's command: settled open-tile prediction; these CSVs average ALL launches of the pass, warm-up
+# included -- bench.py's own passes keep the launches of the timed steps only: `hbm_measured` / `roofline.traffic` in the JSON)
+export PMC_TARGET="bench.py --inner --no-extras --no-pmc --no-cpu-baseline --steps 3 --warmup 5"
 tools/pmc.sh ${tag}_pmc_fetch_size "FETCH_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_f.txt 2>&1
 tools/pmc.sh ${tag}_pmc_write_size "WRITE_SIZE" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_w.txt 2>&1
 tools/pmc.sh ${tag}_pmc_valu "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS" "render|preprocess|radix|emit|scan|accumulate|adam|repair" > gpurun_out/${tag}_pmc_v.txt 2>&1
@@ -15,6 +17,8 @@ python tools/isa_count.py > gpurun_out/${tag}_isa_counts.txt 2>&1
 python tools/bwd_trace_batched.py bwd 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_bwd_trace.txt
 python tools/bwd_trace_batched.py fwd 2>/dev/null | grep -v amdgpu.ids > gpurun_out/${tag}_fwd_trace.txt
 PROF_STEPS=10 PROF_WARMUP=3 tools/prof.sh ${tag}_dropin --path dropin --optimizer b3gs --graph 0 --no-extras --no-pmc > gpurun_out/${tag}_dropin_stdout.txt 2>&1
+# round 4: the reference's own two-view iteration (fused surface), 500k Gaussians
+tools/prof_cmd.sh ${tag}_refsched_fused_500k bench_ref_schedule.py 500000,800,600 --surfaces=fused > gpurun_out/${tag}_refsched_stdout.txt 2>&1
 head -16 gpurun_out/${tag}_default_kernel_stats.csv
 python -c "
 import json
