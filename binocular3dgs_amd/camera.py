@@ -53,6 +53,26 @@ def focal2fov(focal: float, pixels: int) -> float:
     return 2 * math.atan(pixels / (2 * focal))
 
 
+_pinned = {}     # device -> [pinned float32 ring [64, 35], next slot]
+
+
+def _staging(device):
+    """(host tensor, its numpy view): 35 floats the next shifted camera is assembled in.  On a HIP device: a slot of a
+    pinned ring, so that the upload is an asynchronous copy (a pageable source makes the runtime block the host until the
+    stream has drained: ~170 us per iteration of the two-view schedule); a slot is reused 64 cameras later, long after its
+    copy ran."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        row = torch.empty(35, dtype=torch.float32)
+        return row, row.numpy()
+    ent = _pinned.get(device)
+    if ent is None:
+        ent = _pinned[device] = [torch.empty((64, 35), dtype=torch.float32).pin_memory(), 0]
+    row = ent[0][ent[1] % 64]
+    ent[1] += 1
+    return row, row.numpy()
+
+
 class Camera:
     """Holds what render() and the loss block read from a reference Camera (scene/cameras.py:17-70)."""
 
@@ -132,14 +152,14 @@ class Camera:
         # stream time per iteration of the reference's two-view schedule -- bench_ref_schedule.py)
         h = self._host_matrices()
         t = np.float32(trans_dist)
-        buf = np.empty(35, dtype=np.float32)
+        row, buf = _staging(self.device)
         w, f, c = buf[:16].reshape(4, 4), buf[16:32].reshape(4, 4), buf[32:35]
         w[:] = h["wvt"]
         w[3, 0] = w[3, 0] - t
         f[:] = h["full"]
         f[3, :] = w[3, :] @ h["proj"]
         c[:] = h["center"] + t * h["wvt"][:3, 0]
-        dev_buf = torch.from_numpy(buf).to(self.device)
+        dev_buf = row.to(self.device, non_blocking=True) if self.device.type == "cuda" else row
         cam.world_view_transform = dev_buf[:16].view(4, 4)
         cam.full_proj_transform = dev_buf[16:32].view(4, 4)
         cam.camera_center = dev_buf[32:35]

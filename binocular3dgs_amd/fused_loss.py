@@ -65,7 +65,11 @@ class _BinocularLoss(torch.autograd.Function):
     def backward(ctx, g_total, _g_parts):
         b = ctx.buf
         if ctx.unit_grad:   # the loss is the root of the graph (total.backward()): upstream gradient == 1
-            gi, gd, ga, gs = b["g_image"], b["g_depth"], b["g_alpha"], b["g_shifted"]
+            # fresh aliases of the per-slot buffers: when an input is a LEAF (ViewShardedStep forms the loss on detached
+            # leaves of the rendered images), AccumulateGrad keeps an incoming tensor nobody else references instead of
+            # cloning it -- four 2-6 MB device copies per iteration otherwise.  The buffers are rewritten by the next loss
+            # of the same slot: consume the gradients (rasterizer backward) before that, as a step does
+            gi, gd, ga, gs = (b[k].view(b[k].shape) for k in ("g_image", "g_depth", "g_alpha", "g_shifted"))
         else:
             gi, gd, ga, gs = (b[k] * g_total for k in ("g_image", "g_depth", "g_alpha", "g_shifted"))
         return (gi, gd, ga, gs if ctx.has_shift else None) + (None,) * 9
@@ -132,7 +136,8 @@ class _BinocularLossBatch(torch.autograd.Function):
     def backward(ctx, g_total, _g_parts):
         out = []
         for b, hs in zip(ctx.bufs, ctx.has_shift):
-            gs = [b["g_image"], b["g_depth"], b["g_alpha"], b["g_shifted"] if hs else None]
+            gs = [b["g_image"].view(b["g_image"].shape), b["g_depth"].view(b["g_depth"].shape),
+                  b["g_alpha"].view(b["g_alpha"].shape), b["g_shifted"].view(b["g_shifted"].shape) if hs else None]
             if not ctx.unit_grad:
                 gs = [None if g is None else g * g_total for g in gs]
             out += gs
