@@ -752,8 +752,20 @@ class ViewShardedStep:
                 leaves[("remote", k)] = sp
             items.append((v.key, v.cam, lp, sp, v.t))
         if items:
-            total = batch_loss_fn(items) if batch_loss_fn is not None else sum(loss_fn(*it) for it in items)
-            total.backward()
+            if batch_loss_fn is not None:
+                total = batch_loss_fn(items)
+            else:
+                losses = [loss_fn(*it) for it in items]
+                total = losses[0]
+                for extra in losses[1:]:
+                    total = total + extra
+            # (a cached root gradient: `total.backward()` fills a fresh ones_like(total) every iteration -- one more launch
+            # in a two-view iteration that is a chain of ~30 small ones)
+            one = self._one if getattr(self, "_one", None) is not None and self._one.device == total.device and \
+                self._one.dtype == total.dtype and self._one.shape == total.shape else None
+            if one is None:
+                one = self._one = torch.ones_like(total)
+            torch.autograd.backward([total], [one])
         sends, recvs = [], []
         for k, v in enumerate(self.views):
             if v.peer is None:
