@@ -154,7 +154,8 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
         step()
     torch.cuda.synchronize(dev)
     best = None
-    for _ in range(2):                     # (the better of two runs, like every extra of bench.py)
+    for _ in range(3):                     # (the best of three runs: the two-view loop is a few hundred microseconds of
+        #                                     host work per iteration on a host shared with other jobs)
         gc.collect()
         was = gc.isenabled()
         gc.disable()
