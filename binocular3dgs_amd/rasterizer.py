@@ -230,6 +230,15 @@ class _CModule:
         num_rendered to its caller): sync-free forward, see _LazyN -- the returned count is then the CAPACITY of the
         binning buffer (what the backward needs to find its arrays), not N."""
         L = _lib.lib()
+        if means3D.dim() == 2 and means3D.shape[0] == 0:
+            # no Gaussians: the upstream binding skips the rasterizer and returns its zero-initialised images
+            # (`torch::full(..., 0.0)` in rasterize_points.cu: NOT the background), num_rendered 0, empty state
+            dev0 = _dev_f32(means3D, "means3D").device
+            f0 = dict(dtype=torch.float32, device=dev0)
+            H0, W0 = int(image_height), int(image_width)
+            e8 = torch.empty(0, dtype=torch.uint8, device=dev0)
+            return (0, torch.zeros((3, H0, W0), **f0), torch.zeros((1, H0, W0), **f0), torch.zeros((1, H0, W0), **f0),
+                    torch.empty((0,), dtype=torch.int32, device=dev0), e8, e8.clone(), e8.clone())
         sc, keep, dev, P, _ = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
                                      image_width, sh, degree, campos, prefiltered, debug)
@@ -290,6 +299,13 @@ class _CModule:
         L = _lib.lib()
         P = means3D.shape[0]
         dev = means3D.device
+        if P == 0:      # (see rasterize_gaussians: nothing was rendered)
+            f0 = dict(dtype=torch.float32, device=dev)
+            M0 = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
+            has_sr0 = scales is not None and scales.dim() == 2 and scales.shape[1] == 3
+            return (torch.zeros((0, 3), **f0), torch.zeros((0, 3), **f0), torch.zeros((0, 1), **f0), torch.zeros((0, 3), **f0),
+                    torch.zeros((0, 6), **f0), torch.zeros((0, M0, 3), **f0), torch.zeros((0, 3) if has_sr0 else (0, 3), **f0),
+                    torch.zeros((0, 4), **f0))
         if opacities is None:
             opacities = torch.empty((P, 1), dtype=torch.float32, device=dev)  # unused by the backward kernels
         H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
