@@ -171,6 +171,9 @@ __global__ void __launch_bounds__(256) ssim_stats_kernel(LossBatch lb, Win win) 
       maps[(0 * 3 + ch) * hw + p] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
       maps[(1 * 3 + ch) * hw + p] = -S / B2;
       maps[(2 * 3 + ch) * hw + p] = 2.f * A1 * inv;
+      // the warp kernel below ADDS into the gradient of the shifted image (bilinear scatter): this pass, which visits
+      // every (channel, pixel) exactly once, leaves it zero -- no 3 H W memset in front of the four launches
+      if (a.dL_dshifted) a.dL_dshifted[ch * hw + p] = 0.f;
       l1 += fabsf(sin[0][lr + LR][tx + LR] - sin[1][lr + LR][tx + LR]);
     }
   }
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
 
 __global__ void __launch_bounds__(64) loss_finalize_kernel(LossBatch lb) {
   const PairArgs& a = lb.p[blockIdx.x];
-  const float* __restrict__ slots = a.sums;
+  float* __restrict__ slots = a.sums;
   const int W = a.W, H = a.H, has_shift = a.shifted != nullptr;
   const float lambda_dssim = a.lambda_dssim, lambda_smooth = a.lambda_smooth;
   float* __restrict__ parts = a.parts;
@@ -354,6 +357,7 @@ __global__ void __launch_bounds__(64) loss_finalize_kernel(LossBatch lb) {
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     float v = slots[q * SLOTS + threadIdx.x];
+    slots[q * SLOTS + threadIdx.x] = 0.f;   // self-cleaning: zero for the next call (B3gsLossIO::workspace)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     sums[q] = v;
@@ -414,8 +418,9 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
     a.maps = io->workspace + 8 * SLOTS;
     a.dL_dimage = io->dL_dimage; a.dL_ddepth = io->dL_ddepth; a.dL_dalpha = io->dL_dalpha; a.dL_dshifted = io->dL_dshifted;
     a.parts = io->parts;
-    (void)hipMemsetAsync(a.sums, 0, 8 * SLOTS * sizeof(float), s);
-    if (io->shifted_image) (void)hipMemsetAsync(io->dL_dshifted, 0, 3 * hw * sizeof(float), s);
+    // (no memsets: the partial-sum slots are left zero by the previous call's last kernel -- the caller zeroes a NEW
+    // workspace once --, the gradient of the shifted image is zeroed by the SSIM statistics pass)
+    a.dL_dshifted = io->shifted_image ? io->dL_dshifted : nullptr;
     gx = (W + LT - 1) / LT > gx ? (W + LT - 1) / LT : gx;
     gy = (H + LT - 1) / LT > gy ? (H + LT - 1) / LT : gy;
   }

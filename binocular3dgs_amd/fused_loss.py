@@ -24,7 +24,8 @@ class _Workspace:
         if key not in cls._cache:
             f = dict(dtype=torch.float32, device=dev)
             n = _lib.lib().b3gs_loss_workspace_floats(W, H)
-            cls._cache[key] = dict(ws=torch.empty(n, **f), parts=torch.zeros(8, **f), g_image=torch.empty((3, H, W), **f),
+            # (zeroed once: the library keeps the partial-sum slots at the head of the workspace zero between calls)
+            cls._cache[key] = dict(ws=torch.zeros(n, **f), parts=torch.zeros(8, **f), g_image=torch.empty((3, H, W), **f),
                                    g_depth=torch.empty((1, H, W), **f), g_alpha=torch.empty((1, H, W), **f),
                                    g_shifted=torch.empty((3, H, W), **f))
         return cls._cache[key]

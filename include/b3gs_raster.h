@@ -354,7 +354,9 @@ typedef struct B3gsLossIO {
   float* dL_dalpha;            /* [1,H,W] */
   float* dL_dshifted;          /* [3,H,W]; required iff shifted_image */
   float* parts;                /* [8] */
-  float* workspace;            /* b3gs_loss_workspace_floats(W, H) floats */
+  float* workspace;            /* b3gs_loss_workspace_floats(W, H) floats.  ABI 7: its first 512 floats (the partial-sum
+                                * slots) must be ZERO before the first call with this workspace; every call leaves them zero
+                                * (self-cleaning: no memset per call).  One workspace per pair in flight. */
 } B3gsLossIO;
 size_t b3gs_loss_workspace_floats(int32_t W, int32_t H);
 int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream);
