@@ -441,3 +441,34 @@ def test_pair_members_of_different_image_size_and_an_empty_model():
     assert pkg["radii"].numel() == 0 and float(pkg["render"].abs().max()) == 0.0 and pkg["render"].shape == (3, 120, 160)
     pkg["render"].sum().backward()
     assert empty._xyz.grad is None or empty._xyz.grad.numel() == 0
+
+
+def test_forward_on_a_side_stream_backward_called_from_the_default_stream():
+    """The engine runs each node on its forward's stream; the gradients this module writes into `.grad` itself must be visible
+    to the stream `backward()` was called from when it returns (the end-of-backward callback makes it wait)."""
+    from binocular3dgs_amd import synth
+    W, H = 160, 120
+    model = _model(P=9000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=6, device="cuda")
+    for p in model.parameters():
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    _loss(a, b, gc, gd, ga).backward()
+    torch.cuda.synchronize()
+    ref = [p.grad.clone() for p in model.parameters()]
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+            loss = _loss(a, b, gc, gd, ga)
+        torch.cuda.current_stream().wait_stream(side)
+        loss.backward()                                   # called from the default stream
+        got = [p.grad.clone() for p in model.parameters()]   # read on the default stream, no device-wide sync in between
+        torch.cuda.synchronize()
+        for g, r in zip(got, ref):
+            assert rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 1e-4
