@@ -69,7 +69,7 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
     from binocular3dgs_amd.loss import binocular_loss
     from binocular3dgs_amd.render import PipelineParams, render
     from binocular3dgs_amd.step import FusedAdam, ViewShardedStep
-    assert surface in ("fused", "render", "unchanged")
+    assert surface in ("fused", "fused_graph", "render", "unchanged")
     model = synth.synth_model(P, seed=seed, device=dev, width=W, height=H, fovx_deg=fov)
     model.init_densification_stats()
     cams = synth.synth_cameras(W, H, fovx_deg=fov, yaws=synth.YAWS_6, device=dev)[:3]
@@ -105,6 +105,57 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
             cur["gt"] = gts[k]
             st.step(loss_fn=loss_fn)
         extra = lambda: {"binning_rounds": 2 if fused.seg1_fraction > 0 else 1,          # noqa: E731
+                         "two_round_disabled": str(fused.two_round_disabled) if fused.two_round_disabled else None}
+    elif surface == "fused_graph":
+        # the same step as ONE HIP-graph replay per iteration: the pair's cameras live in a static device block rewritten
+        # in place (CameraPairSlots: one pinned upload), the shift and the learning rates are read from device memory
+        # (B3gsLossIO::trans_dist_dev, B3gsAdamSegment::lr_dev), the ground-truth image is copied into a static buffer.
+        # Host work per iteration: two copies and a graph launch -- the eager loop above is ~0.7 ms of host work per
+        # iteration and drops to half its speed when the (shared) host is busy.
+        from binocular3dgs_amd.camera import CameraPairSlots
+        slots = CameraPairSlots(cams[0], 0.1)
+        gt_static = gts[0].clone()
+        lr_dev = torch.tensor(LR, dtype=torch.float32, device=dev)
+        opt = FusedAdam(model.parameters(), LR, eps=1e-15, opacity_decay=OPACITY_DECAY, opacity_index=5, decay_first=True)
+        opt.lr_device = lr_dev
+        fused = FusedRasterizer(model, W, H, num_slots=2, want_means2D=False)
+        st = ViewShardedStep(model, [(slots.cam, slots.shifted, 0.1)], bg, optimizer=opt, fused=fused, overflow_check_every=0)
+
+        def loss_fn(i, cam, pkg, spkg, t):
+            return binocular_loss_fused(pkg["render"], pkg["rendered_depth"], pkg["rendered_alpha"], gt_static,
+                                        shifted_image=spkg["render"], focal_x=cam.get_focal()[0], trans_dist=0.0,
+                                        trans_dist_dev=slots.trans_dist_dev, slot=0, unit_grad=True)
+
+        state = {"graph": None, "frac": None, "n": 0}
+
+        def capture():
+            for _ in range(3):                       # (settles allocations; the graph then replays fixed addresses)
+                st.step(loss_fn=loss_fn)
+            torch.cuda.synchronize(dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                st.step(loss_fn=loss_fn)
+            torch.cuda.current_stream().wait_stream(side)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                st.step(loss_fn=loss_fn)
+            state["graph"], state["frac"] = g_, fused.seg1_fraction
+
+        def step():
+            k, t = draw()
+            slots.set(cams[k], t)
+            gt_static.copy_(gts[k], non_blocking=True)
+            if state["graph"] is None:
+                capture()
+            state["graph"].replay()
+            state["n"] += 1
+            if state["n"] % 32 == 0:                 # the step's own protocol, outside the graph: capacity / key span /
+                if fused.check_overflow():           # two-round rule (it falls back to one round when the prediction keeps
+                    raise SystemExit("reference_schedule: binning capacity overflow")   # missing: re-capture then)
+                if fused.seg1_fraction != state["frac"]:
+                    state["graph"] = None
+        extra = lambda: {"binning_rounds": 2 if fused.seg1_fraction > 0 else 1, "hip_graph": True,   # noqa: E731
                          "two_round_disabled": str(fused.two_round_disabled) if fused.two_round_disabled else None}
     elif surface == "render":
         opt = FusedAdam(model.parameters(), LR, eps=1e-15, opacity_decay=OPACITY_DECAY, opacity_index=5, decay_first=True)
@@ -178,11 +229,12 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
 
 
 def table(dev, fov: float, seed: int, sizes=((500_000, 800, 600), (500_000, 504, 378), (100_000, 800, 600), (100_000, 504, 378)),
-          surfaces=("fused", "render", "unchanged"), steps: int = 40) -> dict:
+          surfaces=("fused", "fused_graph", "render", "unchanged"), steps: int = 40) -> dict:
     res = {"what": "train.py's own iteration shape: ONE random input view + ONE randomly shifted partner per iteration "
                    "(cameras change every step), binocular loss block, opacity decay before the optimiser step, "
                    "densification statistics, Adam; surfaces: fused = FusedRasterizer pair batch + fused loss + one-launch "
-                   "Adam; render = render() per view (reference-built shifted camera) + fused loss + one-launch Adam; "
+                   "Adam, eager launches; fused_graph = the same step as ONE HIP-graph replay per iteration (cameras in a "
+                   "static device block, shift and learning rates read from device memory); render = render() per view (reference-built shifted camera) + fused loss + one-launch Adam; "
                    "unchanged = render() per view + the loss as PyTorch ops + torch.optim.Adam (what an unmodified "
                    "train.py runs around the rasterizer)"}
     for P, W, H in sizes:

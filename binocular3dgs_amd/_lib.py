@@ -67,7 +67,7 @@ class B3gsLossIO(C.Structure):
                 ("focal_x", C.c_float), ("trans_dist", C.c_float), ("lambda_dssim", C.c_float),
                 ("lambda_smooth", C.c_float), ("grad_scale", C.c_float), ("dL_dimage", C.c_void_p),
                 ("dL_ddepth", C.c_void_p), ("dL_dalpha", C.c_void_p), ("dL_dshifted", C.c_void_p),
-                ("parts", C.c_void_p), ("workspace", C.c_void_p)]
+                ("parts", C.c_void_p), ("workspace", C.c_void_p), ("trans_dist_dev", C.c_void_p)]
 
 
 class B3gsDensifyIO(C.Structure):
@@ -79,7 +79,8 @@ class B3gsDensifyIO(C.Structure):
 
 class B3gsAdamSegment(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("count", C.c_int64), ("lr", C.c_float), ("row_len", C.c_int32), ("first_row", C.c_int32)]
+                ("count", C.c_int64), ("lr", C.c_float), ("row_len", C.c_int32), ("first_row", C.c_int32),
+                ("lr_dev", C.c_void_p)]
 
 
 class B3gsDensifyStats(C.Structure):

@@ -150,15 +150,8 @@ class Camera:
         #   wvt'[3,0] = wvt[3,0] - t,   full'[3,:] = wvt'[3,:] @ proj,   centre' = centre + t * wvt[:3,0]  (the camera x axis)
         # (round 3 cloned the view matrix, patched it and re-ran bmm + inverse on the device: ~25 tiny kernels, 54 us of
         # stream time per iteration of the reference's two-view schedule -- bench_ref_schedule.py)
-        h = self._host_matrices()
-        t = np.float32(trans_dist)
         row, buf = _staging(self.device)
-        w, f, c = buf[:16].reshape(4, 4), buf[16:32].reshape(4, 4), buf[32:35]
-        w[:] = h["wvt"]
-        w[3, 0] = w[3, 0] - t
-        f[:] = h["full"]
-        f[3, :] = w[3, :] @ h["proj"]
-        c[:] = h["center"] + t * h["wvt"][:3, 0]
+        _shifted_block(self._host_matrices(), trans_dist, buf)
         dev_buf = row.to(self.device, non_blocking=True) if self.device.type == "cuda" else row
         cam.world_view_transform = dev_buf[:16].view(4, 4)
         cam.full_proj_transform = dev_buf[16:32].view(4, 4)
@@ -168,6 +161,61 @@ class Camera:
         # the pair can share one depth sort (FusedRasterizer, b3gs_forward_raw_batch depth_order_from)
         cam.same_depth_as = getattr(self, "same_depth_as", None) or self
         return cam
+
+
+def _shifted_block(h, trans_dist: float, buf: np.ndarray):
+    """[wvt' (16) | full' (16) | centre' (3)] of the camera `h` (host matrices) moved by trans_dist along its own x axis."""
+    t = np.float32(trans_dist)
+    w, f, c = buf[:16].reshape(4, 4), buf[16:32].reshape(4, 4), buf[32:35]
+    w[:] = h["wvt"]
+    w[3, 0] = w[3, 0] - t
+    f[:] = h["full"]
+    f[3, :] = w[3, :] @ h["proj"]
+    c[:] = h["center"] + t * h["wvt"][:3, 0]
+
+
+class CameraPairSlots:
+    """An (input, shifted) camera pair whose matrices live in ONE static device block that is rewritten in place every
+    iteration -- what an iteration replayed as a HIP graph needs: the reference draws a new input view and a new shift per
+    iteration (train.py:92,125-128), a captured graph only sees fixed addresses.  `set(camera, trans_dist)` assembles
+    [input: wvt, full, centre | shifted: wvt', full', centre' | trans_dist] on the host (the shifted camera in closed form,
+    Camera.shifted) and uploads the 71 floats with one asynchronous copy from a pinned ring.  `cam`, `shifted` are Camera
+    objects over views of the block (same intrinsics and image size as `template`); `trans_dist_dev` is the device float the
+    loss block reads (B3gsLossIO::trans_dist_dev)."""
+
+    def __init__(self, template: Camera, trans_dist: float = 0.1):
+        dev = template.device
+        self.device = dev
+        self.block = torch.zeros(72, dtype=torch.float32, device=dev)
+        self._ring = [torch.empty((64, 72), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty((64, 72)), 0]
+        self.cam, self.shifted = Camera.__new__(Camera), Camera.__new__(Camera)
+        for k, c in enumerate((self.cam, self.shifted)):
+            c.__dict__.update({a: v for a, v in template.__dict__.items() if a not in ("_host", "_b3gs_zkey", "same_depth_as")})
+            b = self.block[35 * k:35 * k + 35]
+            c.world_view_transform, c.full_proj_transform, c.camera_center = b[:16].view(4, 4), b[16:32].view(4, 4), b[32:35]
+            c._host = None
+        self.shifted.original_image, self.shifted.gt_alpha_mask = None, None
+        self.shifted.same_depth_as = self.cam          # by construction: one depth sort per pair
+        self.trans_dist_dev = self.block[70:71]
+        self.set(template, trans_dist)
+
+    def set(self, camera: Camera, trans_dist: float):
+        row = self._ring[0][self._ring[1] % 64]
+        self._ring[1] += 1
+        buf = row.numpy()
+        h = camera._host_matrices()
+        buf[:16] = h["wvt"].reshape(-1)
+        buf[16:32] = h["full"].reshape(-1)
+        buf[32:35] = h["center"]
+        _shifted_block(h, trans_dist, buf[35:70])
+        buf[70] = np.float32(trans_dist)
+        buf[71] = 0.0
+        self.block.copy_(row, non_blocking=True)
+        # (what rasterizer.camera_depth_key derives the z row from follows the pose: its cache is dropped)
+        self.cam.R, self.cam.T, self.cam.trans, self.cam.scale = camera.R, camera.T, camera.trans, camera.scale
+        self.cam.__dict__.pop("_b3gs_zkey", None)
+        self.shifted.__dict__.pop("_b3gs_zkey", None)
+        self.cam.original_image, self.cam.gt_alpha_mask = camera.original_image, camera.gt_alpha_mask
 
 
 def look_at_orbit(yaw_deg: float, pivot=(0.0, 0.0, 6.0)):

@@ -38,6 +38,8 @@ struct PairArgs {
   const float* shifted;       // null: no binocular term
   const float* alpha_weight;  // null: no alpha term
   float k_disp;               // focal_x * (-trans_dist)
+  const float* t_dev;         // non-null: trans_dist lives on the device (B3gsLossIO::trans_dist_dev); k_disp is formed here
+  float focal_x;
   float cS, cL1;              // -lambda_dssim*scale/(3HW), (1-lambda_dssim)*scale/(3HW)
   float c_l1m, c_smooth, c_alpha;   // scale/(3HW), lambda_smooth*scale/((H-2)(W-2)), scale/HW
   float lambda_dssim, lambda_smooth;
@@ -230,7 +232,8 @@ __device__ __forceinline__ Disp disparity_at(const PairArgs& a, int r, int c) {
   Disp o;
   o.d = 0.f; o.m = 0.f;
   if (r < 0 || r >= a.H || c < 0 || c >= a.W) return o;
-  const float d = a.k_disp / (a.depth[(size_t)r * a.W + c] + 1e-5f);
+  const float k_disp = a.t_dev ? a.focal_x * (-(*a.t_dev)) : a.k_disp;   // (the same fp32 product the host forms)
+  const float d = k_disp / (a.depth[(size_t)r * a.W + c] + 1e-5f);
   o.d = d;
   if (!(fabsf(d) < 1.0e6f)) return o;
   const float x0 = floorf(d), x1 = x0 + 1.0f;
@@ -408,6 +411,8 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
     a.image = io->image; a.gt = io->gt_image; a.depth = io->depth; a.alpha = io->alpha;
     a.shifted = io->shifted_image; a.alpha_weight = io->alpha_weight;
     a.k_disp = io->focal_x * (-io->trans_dist);
+    a.t_dev = io->trans_dist_dev;
+    a.focal_x = io->focal_x;
     a.cS = -io->lambda_dssim * scale / (3.f * (float)hw);
     a.cL1 = (1.f - io->lambda_dssim) * scale / (3.f * (float)hw);
     a.c_l1m = scale / (3.f * (float)hw);

@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(256)
     float lr;
     uint32_t base, rl, row0;
     // per-element select of the segment fields (k differs between lanes at segment borders)
+    const float* lr_dev = segs.s[0].lr_dev;
     p = segs.s[0].param; g = segs.s[0].grad; m = segs.s[0].exp_avg; v = segs.s[0].exp_avg_sq; lr = segs.s[0].lr; base = 0;
     rl = (uint32_t)segs.s[0].row_len; row0 = (uint32_t)segs.s[0].first_row;
 #pragma unroll
@@ -70,7 +71,9 @@ __global__ void __launch_bounds__(256)
       if (j == k) {
         p = segs.s[j].param; g = segs.s[j].grad; m = segs.s[j].exp_avg; v = segs.s[j].exp_avg_sq; lr = segs.s[j].lr;
         base = segs.start[j]; rl = (uint32_t)segs.s[j].row_len; row0 = (uint32_t)segs.s[j].first_row;
+        lr_dev = segs.s[j].lr_dev;
       }
+    if (lr_dev) lr = *lr_dev;   // the learning rate of a graph-replayed step (B3gsAdamSegment::lr_dev)
     const uint32_t e = i - base;
     const bool decay = opacity_decay > 0.0f && k == opacity_seg;
     bool live[VEC];

@@ -34,7 +34,7 @@ class _Workspace:
 class _BinocularLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, depth, alpha, shifted, gt, alpha_weight, focal_x, trans_dist, lambda_dssim, lambda_smooth,
-                slot, unit_grad, return_parts):
+                slot, unit_grad, return_parts, trans_dist_dev=None):
         if not image.is_cuda:
             raise _lib.B3gsError("binocular_loss_fused needs device tensors (no CPU fallback)")
         H, W = image.shape[-2:]
@@ -48,6 +48,7 @@ class _BinocularLoss(torch.autograd.Function):
         io.shifted_image = None if sh is None else sh.data_ptr()
         io.alpha_weight = None if aw is None else aw.data_ptr()
         io.focal_x, io.trans_dist = float(focal_x or 0.0), float(trans_dist or 0.0)
+        io.trans_dist_dev = None if trans_dist_dev is None else trans_dist_dev.data_ptr()
         io.lambda_dssim, io.lambda_smooth, io.grad_scale = float(lambda_dssim), float(lambda_smooth), 1.0
         io.dL_dimage, io.dL_ddepth, io.dL_dalpha = buf["g_image"].data_ptr(), buf["g_depth"].data_ptr(), buf["g_alpha"].data_ptr()
         io.dL_dshifted = buf["g_shifted"].data_ptr()
@@ -73,24 +74,26 @@ class _BinocularLoss(torch.autograd.Function):
             gi, gd, ga, gs = (b[k].view(b[k].shape) for k in ("g_image", "g_depth", "g_alpha", "g_shifted"))
         else:
             gi, gd, ga, gs = (b[k] * g_total for k in ("g_image", "g_depth", "g_alpha", "g_shifted"))
-        return (gi, gd, ga, gs if ctx.has_shift else None) + (None,) * 9
+        return (gi, gd, ga, gs if ctx.has_shift else None) + (None,) * 10
 
 
 def binocular_loss_fused(image, depth, alpha, gt_image, *, lambda_dssim: float = 0.2, shifted_image=None,
                          focal_x: Optional[float] = None, trans_dist: Optional[float] = None, gt_alpha_mask=None,
                          bg_mask=None, lambda_smooth: float = 0.05, slot: int = 0, unit_grad: bool = False,
-                         return_parts: bool = False):
+                         return_parts: bool = False, trans_dist_dev: Optional[torch.Tensor] = None):
     """Drop-in for loss.binocular_loss(...)[0].  `slot`: index of the pair inside the iteration (gradient
     buffers are per slot and reused across iterations).  unit_grad=True skips the multiplication by the
     upstream scalar when the caller does `total.backward()` / sums the pair losses with weight 1.
-    return_parts: also return the device tensor [total, Ll1, ssim, l1_masked, smooth, alpha_loss, -, -]."""
+    return_parts: also return the device tensor [total, Ll1, ssim, l1_masked, smooth, alpha_loss, -, -].
+    trans_dist_dev: a 1-element device tensor that replaces `trans_dist` (the shift is drawn anew every iteration,
+    train.py:125-126: an iteration replayed as a HIP graph reads it from device memory)."""
     aw = None
     if gt_alpha_mask is not None:
         aw = 1.0 - gt_alpha_mask
     elif bg_mask is not None:
         aw = bg_mask
     total, parts = _BinocularLoss.apply(image, depth, alpha, shifted_image, gt_image, aw, focal_x, trans_dist,
-                                        lambda_dssim, lambda_smooth, int(slot), unit_grad, bool(return_parts))
+                                        lambda_dssim, lambda_smooth, int(slot), unit_grad, bool(return_parts), trans_dist_dev)
     return (total, parts) if return_parts else total
 
 
@@ -119,6 +122,8 @@ class _BinocularLossBatch(torch.autograd.Function):
             io.shifted_image = None if sh is None else sh.data_ptr()
             io.alpha_weight = None if aw is None else aw.data_ptr()
             io.focal_x, io.trans_dist = float(m["focal_x"] or 0.0), float(m["trans_dist"] or 0.0)
+            td = m.get("trans_dist_dev")
+            io.trans_dist_dev = None if td is None else td.data_ptr()
             io.lambda_dssim, io.lambda_smooth, io.grad_scale = float(m["lambda_dssim"]), float(m["lambda_smooth"]), 1.0
             io.dL_dimage, io.dL_ddepth, io.dL_dalpha = buf["g_image"].data_ptr(), buf["g_depth"].data_ptr(), buf["g_alpha"].data_ptr()
             io.dL_dshifted = buf["g_shifted"].data_ptr()
@@ -158,6 +163,7 @@ def binocular_loss_fused_batch(pairs, lambda_dssim: float = 0.2, lambda_smooth: 
         elif p.get("bg_mask") is not None:
             aw = p["bg_mask"]
         meta.append(dict(gt=p["gt_image"], alpha_weight=aw, focal_x=p.get("focal_x"), trans_dist=p.get("trans_dist"),
+                         trans_dist_dev=p.get("trans_dist_dev"),
                          lambda_dssim=p.get("lambda_dssim", lambda_dssim), lambda_smooth=lambda_smooth, slot=k))
         tensors += [p["image"], p["depth"], p["alpha"], p.get("shifted_image")]
     total, parts = _BinocularLossBatch.apply(meta, unit_grad, *tensors)

@@ -104,6 +104,7 @@ def _adam_launch(segs_py, step_count, betas, eps, opacity_decay, opacity_seg, de
         segs[k].param, segs[k].grad, segs[k].exp_avg, segs[k].exp_avg_sq = p or None, g or None, m or None, v or None
         segs[k].count, segs[k].lr = int(n), float(lr)
         segs[k].row_len, segs[k].first_row = (int(seg[6]), int(seg[7])) if len(seg) > 6 else (0, 0)
+        segs[k].lr_dev = (seg[8] or None) if len(seg) > 8 else None
     rc = _lib.lib().b3gs_adam_step(len(segs_py), segs, step_count.data_ptr(), betas[0], betas[1], eps,
                                    float(opacity_decay), int(opacity_seg), int(bool(decay_first)), int(bool(bump)),
                                    None if row_mask is None else row_mask.data_ptr(),
@@ -135,6 +136,9 @@ class FusedAdam:
         self.opacity_decay, self.opacity_index = float(opacity_decay), int(opacity_index)
         self.decay_first = bool(decay_first)
         self.skip_flag = None    # device int32: != 0 drops the update on the device (ViewShardedStep sets it)
+        # optional [len(params)] float32 tensor on the device: the learning rates the launch reads INSTEAD of `lrs` -- a step
+        # replayed as a HIP graph follows a schedule (train.py:83) through device memory (B3gsAdamSegment::lr_dev)
+        self.lr_device = None
 
     def step(self, row_mask: Optional[torch.Tensor] = None):
         """row_mask: the touched-rows bitmap of a sparse-row gradient slab (FusedRasterizer.finish_deferred)."""
@@ -145,11 +149,12 @@ class FusedAdam:
         """Adam for rows [first, first+count) of every tensor (row = one Gaussian); grad_ptrs[k] is the address of
         the gradient of row `first` of tensor k (rows contiguous).  The step counter advances when `last`."""
         segs, off = [], 0
-        for p, lr, gp in zip(self.params, self.lrs, grad_ptrs):
+        for k, (p, lr, gp) in enumerate(zip(self.params, self.lrs, grad_ptrs)):
             assert p.is_contiguous()
             w = p.numel() // max(p.shape[0], 1)
             segs.append((p.data_ptr() + 4 * w * first, gp, self.exp_avg.data_ptr() + 4 * (off + w * first),
-                         self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr, w, first))
+                         self.exp_avg_sq.data_ptr() + 4 * (off + w * first), w * count, lr, w, first,
+                         None if self.lr_device is None else self.lr_device.data_ptr() + 4 * k))
             off += p.numel()
         _adam_launch(segs, self.step_count, self.betas, self.eps, self.opacity_decay, self.opacity_index,
                      self.decay_first, last, self.params[0].device, row_mask, self.skip_flag)

@@ -314,6 +314,8 @@ typedef struct B3gsAdamSegment {
   float lr;
   int32_t row_len;    /* floats per Gaussian row of this tensor; only read when row_mask != NULL (0 = segment not masked) */
   int32_t first_row;  /* Gaussian index of the segment's first float (a segment starts at a row boundary when masked) */
+  const float* lr_dev; /* ABI 7, may be NULL: a device float that REPLACES `lr` (the position learning rate follows a
+                        * schedule, train.py:83: a step replayed as a HIP graph reads it from device memory) */
 } B3gsAdamSegment;
 /* `row_mask` (may be NULL): the touched_rows bitmap of B3gsRawGrads.  Element e of a segment with row_len > 0 belongs to
  * Gaussian first_row + e / row_len; when that Gaussian's bit is clear the gradient is taken as 0 WITHOUT reading it
@@ -354,9 +356,13 @@ typedef struct B3gsLossIO {
   float* dL_dalpha;            /* [1,H,W] */
   float* dL_dshifted;          /* [3,H,W]; required iff shifted_image */
   float* parts;                /* [8] */
+  /* (`workspace` below.)  ABI 7, last field of the struct: trans_dist_dev (may be NULL) -- a device float that REPLACES
+   * `trans_dist` when given: the shift of the binocular partner is drawn anew every iteration (train.py:125-126), and an
+   * iteration replayed as a HIP graph can only see it through device memory. */
   float* workspace;            /* b3gs_loss_workspace_floats(W, H) floats.  ABI 7: its first 512 floats (the partial-sum
                                 * slots) must be ZERO before the first call with this workspace; every call leaves them zero
                                 * (self-cleaning: no memset per call).  One workspace per pair in flight. */
+  const float* trans_dist_dev;
 } B3gsLossIO;
 size_t b3gs_loss_workspace_floats(int32_t W, int32_t H);
 int b3gs_binocular_loss(const B3gsLossIO* io, b3gs_stream_t stream);
