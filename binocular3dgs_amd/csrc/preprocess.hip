@@ -417,8 +417,13 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
       const unsigned long long rm = (ry1 - ry0 >= 64u ? ~0ull : ((1ull << (ry1 - ry0)) - 1ull)) << (ry0 & 63u);
       const unsigned long long cm = (rx1 - rx0 >= 64u ? ~0ull : ((1ull << (rx1 - rx0)) - 1ull)) << (rx0 & 63u);
       const bool exact = s_any[v][0] != ~0ull || s_any[v][1] != ~0ull;
-      if (!exact || ((s_any[v][0] & rm) != 0ull && (s_any[v][1] & cm) != 0ull))
-        hit = open_tiles(rect, open_map(g.nrowwords <= PRE_PRED_WORDS ? s_pred[v] : g.pred_rows, sc.W, sc.H)) != 0u;
+      if (!exact || ((s_any[v][0] & rm) != 0ull && (s_any[v][1] & cm) != 0ull)) {
+        // two copies of the walk, one per address space: through ONE generic pointer the loads are `flat_load` +
+        // `s_waitcnt vmcnt(0)`, and on gfx9 that counter also holds this wave's record stores of the view (measured: no
+        // difference at the headline's sizes -- few lanes get here -- but the wait had no reason to exist)
+        if (g.nrowwords <= PRE_PRED_WORDS) hit = open_tiles(rect, open_map(&s_pred[v][0], sc.W, sc.H)) != 0u;
+        else hit = open_tiles(rect, open_map(g.pred_rows, sc.W, sc.H)) != 0u;
+      }
     }
     const unsigned long long word = __ballot(hit);
     if ((threadIdx.x & 63u) == 0u) g.pflag[(size_t)i >> 6] = word;

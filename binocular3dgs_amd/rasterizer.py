@@ -506,10 +506,10 @@ def viewspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
 
 class _RawJob:
     """One render's backward, ready to be launched: its node, what the node saved, its pixel gradients."""
-    __slots__ = ("ctx", "saved", "gc", "gd", "ga", "stream", "needs_m2d", "m2d_leaf")
+    __slots__ = ("ctx", "saved", "gc", "gd", "ga", "stream", "needs_m2d", "m2d_leaf", "task")
 
-    def __init__(self, ctx, gc, gd, ga):
-        self.ctx, self.saved, self.gc, self.gd, self.ga = ctx, ctx.saved_tensors, gc, gd, ga
+    def __init__(self, ctx, gc, gd, ga, task):
+        self.ctx, self.saved, self.gc, self.gd, self.ga, self.task = ctx, ctx.saved_tensors, gc, gd, ga, task
         self.stream = torch.cuda.current_stream(gc.device)
         self.needs_m2d = bool(ctx.needs_input_grad[6])
         self.m2d_leaf = ctx.m2d_leaf
@@ -567,14 +567,16 @@ def _end_of_backward():
         of backward() and therefore before `optimizer.step()` of train.py:196-198 -- but behind the backward's launches, so
         the host waits for the forwards' read-backs while the device still has the whole backward queued (checking at the
         entry of the first node drained the queue between forward and backward of every iteration: ~0.2 ms of idle device)."""
-    flush, streams, tokens = _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"]
+    task, flush, streams, tokens = _task_cb["task"], _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"]
     _task_cb["task"], _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"] = None, [], [], []
     for ref in flush:
         node = ref()
         jobs = getattr(node, "pending", None) if node is not None else None
         if jobs:
             node.pending = []
-            _launch_backward(jobs, True)
+            jobs = [j for j in jobs if j.task == task]     # (see _RasterizeRaw.backward)
+            if jobs:
+                _launch_backward(jobs, True)
     for st in streams:
         cur = torch.cuda.current_stream(st.device)
         if cur != st:
@@ -810,12 +812,14 @@ class _RasterizeRaw(torch.autograd.Function):
         cfg = ctx.cfg
         if grad_color is None:
             grad_color = torch.zeros((3, cfg["H"], cfg["W"]), dtype=torch.float32, device=dev)
+        task = torch._C._current_graph_task_id()
         job = _RawJob(ctx, _dev_f32(grad_color, "dL_dout_color"),
                       None if grad_depth is None else _dev_f32(grad_depth, "dL_dout_depth"),
-                      None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha"))
-        task = torch._C._current_graph_task_id()
+                      None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha"), task)
         ctx.done_task = task
-        pending, ctx.pending = ctx.pending, []
+        # jobs parked here by later renders of THIS backward(); anything older was left by a backward() that raised before
+        # this node ran (retain_graph=True and a second attempt): its gradients belong to nobody
+        pending, ctx.pending = [j for j in ctx.pending if j.task == task], []
         needs = ctx.needs_input_grad
         if not _self_accumulate_ok(ctx, params):
             if pending:                      # (deferred by nodes for which self-accumulation was fine: launch them so)

@@ -472,3 +472,53 @@ def test_forward_on_a_side_stream_backward_called_from_the_default_stream():
         torch.cuda.synchronize()
         for g, r in zip(got, ref):
             assert rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 1e-4
+
+
+def test_a_backward_that_raised_midway_leaves_nothing_behind_for_the_next_attempt():
+    """retain_graph=True, a hook between the input view's image and the loss raises: the shifted render's node has already
+    parked its job at the input view's node, which never runs.  The second attempt on the same graph must deliver each
+    render's gradient ONCE (the parked job belongs to the failed graph task and is dropped)."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    W, H = 160, 120
+    model = _model(P=9000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=6, device="cuda")
+    for p in model.parameters():
+        p.grad = None
+    a, b = _render_pair(model, cam, scam, bg, hint=True, inplace=True)
+    _loss(a, b, gc, gd, ga).backward()
+    ref = [p.grad.clone() for p in model.parameters()]
+
+    from binocular3dgs_amd.render import PipelineParams, render
+    boom = {"on": True}
+
+    def hook(g):
+        if boom["on"]:
+            raise RuntimeError("interrupted")
+        return g
+
+    R._order_hint.clear()
+    R._last_raw_ctx.clear()
+    a = render(cam, model, PipelineParams(), bg)
+    img = a["render"] * 1.0                # (created BEFORE the shifted render: the engine runs that render's node first)
+    img.register_hook(hook)
+    b = render(scam, model, PipelineParams(), bg)
+    loss = (img * gc).sum() + (a["rendered_depth"] * gd).sum() + (a["rendered_alpha"] * ga).sum() + \
+        (b["render"] * gc.flip(-1)).sum()
+    for p in model.parameters():
+        p.grad = None
+    d0 = R._stats["deferred"]
+    with pytest.raises(RuntimeError, match="interrupted"):
+        loss.backward(retain_graph=True)
+    assert R._stats["deferred"] == d0 + 1, "the shifted render's job was parked before the hook fired"
+    for p in model.parameters():
+        p.grad = None                      # (whatever an interrupted backward left is discarded, as always)
+    boom["on"] = False
+    loss.backward()
+    for n, p, r in zip("xyz f_dc f_rest scaling rotation opacity".split(), model.parameters(), ref):
+        assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 1e-4, n
+    for pool in R._raw_scratch.values():
+        for s in pool:
+            assert float(s.abs().max()) == 0.0, "scratch rows must be left clean"
