@@ -11,7 +11,9 @@ Three surfaces, same Gaussians, same camera / shift sequence, random ground-trut
   "fused"     the build's own step: FusedRasterizer pair batch (shared depth sort) + fused loss block + one-launch Adam
               with the reference's decay order; the shifted camera in closed form on the device (Camera.shifted)
   "render"    render() per view (the zero-change rasterizer surface) with the same fused loss block and one-launch Adam;
-              the shifted camera built the reference's way (device inverse, device->host copy, Camera constructor)
+              the shifted camera built the reference's way (device inverse, device->host copy, Camera constructor);
+              densification statistics through this build's GaussianModel (the reference's sums without its boolean-mask
+              indexing, i.e. without two host syncs per iteration)
   "unchanged" what an unmodified train.py runs around the rasterizer: render() per view, the loss block as PyTorch ops
               (loss.binocular_loss = utils/loss_utils.py + inverse_warp_images), torch.optim.Adam over six groups,
               opacity decay and densification statistics as the reference's PyTorch statements
@@ -195,8 +197,12 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
             with torch.no_grad():
                 model._opacity.data = inverse_sigmoid(model.get_opacity * OPACITY_DECAY)   # gaussian_model.py:307-309
                 vis = pkg["visibility_filter"]
-                model.update_max_radii(pkg["radii"], vis)
-                model.add_densification_stats(pkg["viewspace_points"].grad, vis)
+                # train.py:178-179 / scene/gaussian_model.py:409-411 as the reference writes them: boolean-mask indexing, a
+                # host sync per statement (this build's GaussianModel forms the same sums without it: the "render" surface)
+                g = pkg["viewspace_points"].grad
+                model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], pkg["radii"][vis].float())
+                model.xyz_gradient_accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)
+                model.denom[vis] += 1
                 opt.step()
                 opt.zero_grad(set_to_none=True)
         extra = lambda: {}                                                                # noqa: E731

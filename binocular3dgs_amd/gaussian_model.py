@@ -71,15 +71,26 @@ class GaussianModel:
         self.denom = torch.zeros((P, 1), device=dev)
 
     def add_densification_stats(self, viewspace_point_grad, update_filter):
-        """scene/gaussian_model.py:409-411 (takes the gradient tensor itself: [P,3])."""
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_grad[update_filter, :2], dim=-1,
-                                                             keepdim=True)
-        self.denom[update_filter] += 1
+        """scene/gaussian_model.py:409-411 (takes the gradient tensor itself: [P,3]).  The reference indexes with the boolean
+        mask, which makes the host wait for the mask's population count on every call; the same sums are formed here without
+        leaving the device (rows outside the mask keep their bits)."""
+        if update_filter.dtype != torch.bool:
+            self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_grad[update_filter, :2], dim=-1,
+                                                                 keepdim=True)
+            self.denom[update_filter] += 1
+            return
+        m = update_filter.unsqueeze(-1)
+        n = torch.norm(viewspace_point_grad[:, :2], dim=-1, keepdim=True)
+        torch.where(m, self.xyz_gradient_accum + n, self.xyz_gradient_accum, out=self.xyz_gradient_accum)
+        self.denom += m
 
     def update_max_radii(self, radii, visibility_filter):
-        """train.py:178"""
-        self.max_radii2D[visibility_filter] = torch.max(self.max_radii2D[visibility_filter],
-                                                        radii[visibility_filter].float())
+        """train.py:178 (sync-free like add_densification_stats)"""
+        if visibility_filter.dtype != torch.bool:
+            self.max_radii2D[visibility_filter] = torch.max(self.max_radii2D[visibility_filter],
+                                                            radii[visibility_filter].float())
+            return
+        torch.where(visibility_filter, torch.maximum(self.max_radii2D, radii.float()), self.max_radii2D, out=self.max_radii2D)
 
     # ---- checkpoint tuple (scene/gaussian_model.py:61-93, train.py:41-43,200-202) ----------------------------
     def capture(self, optimizer=None):

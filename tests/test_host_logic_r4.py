@@ -80,3 +80,31 @@ def test_bench_defaults_for_one_and_for_n_ranks():
     assert (a.optimizer, a.pipeline_ranges) == ("b3gs", 4)
     a = bench.resolve_defaults(ns(optimizer="b3gs", pipeline_ranges=2), 4)
     assert a.pipeline_ranges == 2
+
+
+def test_densification_statistics_without_boolean_indexing_keep_the_reference_bits():
+    """gaussian_model.add_densification_stats / update_max_radii form the reference's sums (scene/gaussian_model.py:409-411,
+    train.py:178) without boolean-mask indexing (a host sync per call on a GPU): same bits as the indexed statements."""
+    import torch
+    from binocular3dgs_amd.gaussian_model import GaussianModel
+    torch.manual_seed(3)
+    P = 777
+    a, b = GaussianModel.__new__(GaussianModel), GaussianModel.__new__(GaussianModel)
+    for m in (a, b):
+        m._xyz = torch.zeros(P, 3)
+        m.init_densification_stats()
+    for _ in range(6):
+        g = torch.randn(P, 3)
+        vis = torch.rand(P) > 0.4
+        radii = (torch.rand(P) * 60).int() * vis
+        a.add_densification_stats(g, vis)
+        a.update_max_radii(radii, vis)
+        b.xyz_gradient_accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)
+        b.denom[vis] += 1
+        b.max_radii2D[vis] = torch.max(b.max_radii2D[vis], radii[vis].float())
+        idx = torch.nonzero(vis).reshape(-1)          # an index tensor takes the indexed statements
+        a.add_densification_stats(g, idx)
+        b.xyz_gradient_accum[idx] += torch.norm(g[idx, :2], dim=-1, keepdim=True)
+        b.denom[idx] += 1
+    assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
+    assert torch.equal(a.max_radii2D, b.max_radii2D)
