@@ -341,6 +341,9 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     if (fv.depth_order_from != -1 &&
         (fv.depth_order_from < 0 || fv.depth_order_from >= nviews || views[fv.depth_order_from].depth_order_from != -1))
       return fail(B3GS_ERR_ARG, "%s", "depth_order_from must name a view of the batch that sorts its own keys");
+    if (fv.depth_order_from != -1 && fv.hint_trusted && (fv.depth_order_from != k - 1 || !fv.overflow_flag))
+      return fail(B3GS_ERR_ARG, "%s", "a verified shared depth order (depth_order_from with hint_trusted) needs the donor to be "
+                                      "the previous view of the batch and an overflow word");
     if (fv.depth_order_hint && (fv.depth_order_from != -1 || !fv.hint_mismatch || fv.depth_order_hint == fv.geometry ||
                                 (fv.hint_trusted && !fv.overflow_flag)))
       return fail(B3GS_ERR_ARG, "%s", "depth_order_hint needs depth_order_from == -1, a hint_mismatch word, another buffer "
@@ -385,6 +388,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     if (d == k - 1) {   // adjacent in the batch: the projection kernel writes both rects with one 16-byte store
       pb.out[d].rect_role = 1;
       pb.out[k].rect_role = 2;
+      if (views[k].hint_trusted) pb.out[k].pair_fatal = views[k].overflow_flag;   // ... and compares the two depth keys
     }
   }
   for (int k = 0; k < nviews; k++) {

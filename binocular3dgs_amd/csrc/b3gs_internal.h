@@ -248,6 +248,8 @@ struct PreOut {
   const uint32_t* hint_key = nullptr;
   int32_t* hint_word = nullptr;
   int32_t* hint_fatal = nullptr;   // trusted hint (no sort launched): a differing key also raises bit 3 of this overflow word
+  int32_t* pair_fatal = nullptr;   // rect_role 2 (second of an adjacent pair that shares its partner's depth order): a key that
+                                   // differs from the partner's raises bit 3 of this overflow word (B3gsForwardView::hint_trusted)
 };
 struct PreBatch {
   int32_t n, raw_mode, tight;

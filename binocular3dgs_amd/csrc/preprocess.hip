@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   }
 
   uint2 held_rect = make_uint2(0u, 0u);
+  uint32_t held_key = 0u;
   PRE_TRACE(1, wall_clock64());
 #pragma unroll 1
   for (int v = 0; v < pb.n; v++) {
@@ -428,6 +429,9 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
     const unsigned long long word = __ballot(hit);
     if ((threadIdx.x & 63u) == 0u) g.pflag[(size_t)i >> 6] = word;
   }
+  // a pair that shares ONE depth order must have equal keys (same z row of the view matrix): checked when the caller asks
+  if (g.rect_role == 2 && g.pair_fatal && dkey != held_key) atomicOr(g.pair_fatal, 8);
+  held_key = dkey;
   if (g.rect_role == 1) held_rect = rect;
   else if (g.rect_role == 2) reinterpret_cast<uint4*>(g.rect - 1)[i] = make_uint4(held_rect.x, held_rect.y, rect.x, rect.y);
   else g.rect[(size_t)i * g.rect_stride] = rect;

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import atexit
+import contextlib
 import os
 import weakref
 from typing import NamedTuple, Optional
@@ -425,7 +426,111 @@ _raw_scratch = {}     # (device index, P) -> list of zeroed [P * 10] float buffe
 _zero_m2d = {}        # (device index, P) -> zeros [P, 3]: storage behind every render's `viewspace_points` leaf
 _order_hint = {}      # device index -> the last raw forward: dict(P, key_bits, geom, xyz_ptr, xyz_version)
 _last_raw_ctx = {}    # device index -> weakref of the last DIFFERENTIATED raw forward's node (+ what it rendered)
-_stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0}   # (tests / bench read these)
+_stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0, "lazy_batches": 0, "lazy_views": 0, "shared": 0}   # (tests / bench read these)
+
+
+# B3GS_DROPIN_LAZY=0: every render() launches its forward before it returns (see _LazyOut / _launch_forward)
+_LAZY_FWD = os.environ.get("B3GS_DROPIN_LAZY", "1") != "0"
+_LAZY_MAX = max(1, min(8, int(os.environ.get("B3GS_DROPIN_LAZY_MAX", "2"))))    # renders per batched forward (a pair)
+_pending_fwd = {}     # device index -> [_PendingFwd]: differentiated renders whose forward has not been launched yet
+
+
+class _PendingFwd:
+    """One render() whose forward is still to be launched: everything b3gs_forward_raw_batch needs, already allocated."""
+    __slots__ = ("ctx", "sc", "geom", "binning", "img", "out", "radii", "words", "cap", "key", "hint", "trusted", "zkey",
+                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P")
+
+
+def _meta_funcs():
+    """Tensor functions that read no element: they do not make a pending forward run."""
+    T = torch.Tensor
+    fs = {getattr(T, n) for n in ("size", "dim", "numel", "stride", "is_contiguous", "element_size", "is_floating_point",
+                                  "is_complex", "is_signed", "get_device", "storage_offset", "ndimension", "nelement",
+                                  "__len__", "__hash__") if hasattr(T, n)}
+    for name in ("shape", "dtype", "device", "requires_grad", "grad_fn", "is_cuda", "ndim", "is_leaf", "layout", "names",
+                 "is_sparse", "is_quantized", "is_meta", "grad", "output_nr", "_version", "is_nested", "_backward_hooks"):
+        g = getattr(getattr(T, name, None), "__get__", None)
+        if g is not None:
+            fs.add(g)
+    return fs
+
+
+class _LazyOut(torch.Tensor):
+    """What render() hands out while the forward of a differentiated render is still pending: the REAL output tensors
+    (storage allocated, autograd node attached) under a subclass whose only job is to notice the first use.  train.py:100-128
+    looks at nothing between its two render() calls -- it only files the outputs away -- so the input view and its shifted
+    partner can be launched as ONE two-view forward (one projection pass over the parameters, batched binning, one blend
+    launch) when the second call arrives.  Any torch function, method or operator applied to a pending output (everything but
+    shape / dtype / device-style metadata) launches what is pending first; so does the backward of the render's node, a
+    render of other parameters, another stream, another image size, and the `B3GS_DROPIN_LAZY_MAX`-th (2nd) pending render.
+    Until then the images hold NaN, so that a consumer that bypasses torch's function dispatch (a pybind extension reading
+    the raw pointer) cannot go unnoticed.  B3GS_DROPIN_LAZY=0 switches the whole mechanism off."""
+
+    _META = None
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if _pending_fwd:
+            if cls._META is None:
+                cls._META = _meta_funcs()
+            if func not in cls._META:
+                _flush_pending()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def _flush_pending(di=None):
+    """Launch the pending forwards (of one device, or of all)."""
+    for d in ([di] if di is not None else list(_pending_fwd)):
+        lst = _pending_fwd.pop(d, None)
+        if lst:
+            _launch_forward(lst)
+
+
+def _launch_forward(lst):
+    """ONE b3gs_forward_raw_batch for the pending renders `lst` (same parameters, stream, image size, key width)."""
+    L = _lib.lib()
+    p0 = lst[0]
+    n = len(lst)
+    fv = (_lib.B3gsForwardView * n)()
+    for k, p in enumerate(lst):
+        color, depth, alpha = p.out
+        fv[k].view = C.pointer(p.sc)
+        fv[k].geometry, fv[k].binning, fv[k].image = p.geom.data_ptr(), p.binning.data_ptr(), p.img.data_ptr()
+        fv[k].binning_capacity = p.cap
+        fv[k].out_color, fv[k].out_depth, fv[k].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
+        fv[k].radii, fv[k].device_num_rendered = p.radii.data_ptr(), p.words.data_ptr()
+        fv[k].depth_order_from, fv[k].seg1_fraction = -1, 0.0
+        fv[k].high_water, fv[k].overflow_flag = None, p.words[1:].data_ptr()
+        fv[k].depth_key_bits = p.key_bits
+        fv[k].fresh_image = 1
+        if (k > 0 and _ORDER_HINT and _lazy.trust_hints and p.zkey and p.zkey == lst[k - 1].zkey
+                and fv[k - 1].depth_order_from == -1):
+            # the host knows that this view's z row is its predecessor's (camera_depth_key): one depth sort for both; the
+            # projection compares the keys and a difference drops the step (bit 3) and ends the trust
+            fv[k].depth_order_from, fv[k].hint_trusted = k - 1, 1
+            _stats["shared"] += 1
+        if p.hint is not None and n == 1:
+            fv[k].depth_order_hint, fv[k].hint_mismatch = p.hint["geom"].data_ptr(), p.words[2:].data_ptr()
+            fv[k].hint_trusted = int(p.trusted)
+            _stats["hinted"] += 1
+            _stats["trusted"] += int(p.trusted)
+    cur = torch.cuda.current_stream(p0.dev)
+    other = cur.cuda_stream != p0.stream_id
+    with torch.cuda.device(p0.dev), (torch.cuda.stream(p0.stream) if other else contextlib.nullcontext()):
+        _lib.check(L.b3gs_forward_raw_batch(n, fv, C.byref(p0.ctx.rp), 3, p0.stream_id), "b3gs_forward_raw_batch")
+        for p in lst:
+            p.ctx.lazy_token = _lazy.track(p.key, p.cap, p.words[:2])
+            if p.vis is not None:
+                torch.gt(p.radii, 0, out=p.vis)
+    _stats["lazy_batches"] += 1
+    _stats["lazy_views"] += n
+    if _ORDER_HINT:
+        # (what a later render may adopt: the order of a view that SORTED -- a view that borrowed its neighbour's order inside
+        # this batch has no sorted arrays of its own)
+        p = [q for k, q in enumerate(lst) if fv[k].depth_order_from == -1][-1]
+        _order_hint[_dev_index(p.dev)] = dict(P=p.P, key_bits=p.key_bits, geom=p.geom, xyz=p.xyz_id, words=p.words, zkey=p.zkey,
+                                              stream=p.stream_id)
 
 
 def raw_model_ok(pc) -> bool:
@@ -722,17 +827,29 @@ class _RasterizeRaw(torch.autograd.Function):
         lazy = bool(cfg["differentiated"]) and _lazy.enabled and not cfg["debug"]
         if lazy:
             _lazy.poll()
+        stream_id = _stream(dev)
+        # the chain of this iteration's renders of these parameters (see backward)
+        batch_key = (di, P, K, int(cfg["sh_degree"]), float(cfg["scale_modifier"]), bool(cfg["debug"]),
+                     tuple(t.data_ptr() for t in (xyz, f_dc, f_rest, scaling, rotation, opacity)))
+        # may this render's forward WAIT for its partner (see _LazyOut)?  Only when render() hands out its outputs as
+        # _LazyOut, the render will be differentiated and the capacity of its shape is known (sync-free N)
+        fkey = (batch_key, stream_id, W, H, _lazy.key_bits, xyz._version)
+        wait = bool(_LAZY_FWD and cfg.get("lazy_outputs") and lazy and key in _lazy.capacity and P > 0)
+        pend = _pending_fwd.get(di)
+        if pend and not (wait and pend[0].fkey == fkey):
+            _flush_pending(di)        # something else is rendered first: what is pending goes now
+            pend = None
         geom = torch.empty((L.b3gs_geometry_bytes(P),), **u8)
         # recycled allocator memory: B3gsForwardView::fresh_image tells the library to read nothing from it (the batched
         # forward otherwise trusts a tile-order array it finds behind a signature in a PERSISTENT image buffer)
         img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
-        color, depth, alpha = torch.empty((3, H, W), **f32), torch.empty((1, H, W), **f32), torch.empty((1, H, W), **f32)
+        out = torch.empty((5, H, W), **f32)          # colour | depth | alpha
+        color, depth, alpha = out[0:3], out[3:4], out[4:5]
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         cap = _lazy.capacity.get(key) or max(1 << 20, 12 * P)
         # the previous raw forward of the same position tensor (same storage, same version counter): probably the same
         # Gaussians -- its depth order is offered to the library, which verifies key by key
         hint = _order_hint.get(di) if _ORDER_HINT else None
-        stream_id = _stream(dev)
         if hint is not None and not (hint["P"] == P and hint["key_bits"] == _lazy.key_bits and hint["stream"] == stream_id and
                                      hint["xyz"] == (xyz.data_ptr(), xyz._version) and hint["geom"].numel() == geom.numel()):
             hint = None
@@ -744,54 +861,74 @@ class _RasterizeRaw(torch.autograd.Function):
                 trusted = True
             else:
                 hint = None
-        while True:
-            binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
-            words = _zero_words(dev)                                       # [N, overflow word, key mismatch, spare], zero
-            fv = (_lib.B3gsForwardView * 1)()
-            fv[0].view = C.pointer(sc)
-            fv[0].geometry, fv[0].binning, fv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
-            fv[0].binning_capacity = cap
-            fv[0].out_color, fv[0].out_depth, fv[0].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
-            fv[0].radii, fv[0].device_num_rendered = radii.data_ptr(), words.data_ptr()
-            fv[0].depth_order_from, fv[0].seg1_fraction = -1, 0.0
-            fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
-            fv[0].depth_key_bits = _lazy.key_bits
-            fv[0].fresh_image = 1
-            if hint is not None and P > 0:
-                fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
-                fv[0].hint_trusted = int(trusted)
-                _stats["hinted"] += 1
-                _stats["trusted"] += int(trusted)
-            with torch.cuda.device(dev):
-                _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
-            if lazy and key in _lazy.capacity:
-                ctx.lazy_token = _lazy.track(key, cap, words[:2])
-                break
-            n, flag = (int(v) for v in words[:2].tolist())                # exact render: one read-back
-            _lazy.note(key, n)
-            if flag & 2:
-                _lazy.key_bits = 0
-                hint = None
-            if flag & 8:
-                _lazy.trust_hints, trusted = False, False
-            ctx.lazy_token = None
-            if n <= cap and not (flag & 10):
-                break
-            cap = max(cap, _lazy.capacity[key])                           # repeat with what it needs
-        if _ORDER_HINT:
-            _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version), words=words, zkey=zkey,
-                                   stream=stream_id)
+        ctx.lazy_token = None
+        if wait:
+            out.fill_(float("nan"))                                        # (see _LazyOut: nobody may read these unnoticed)
+            p = _PendingFwd()
+            p.ctx, p.sc, p.geom, p.img, p.out, p.radii, p.cap, p.key = ctx, sc, geom, img, (color, depth, alpha), radii, cap, key
+            p.binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+            p.words = _zero_words(dev)
+            p.hint, p.trusted, p.zkey, p.key_bits = hint, trusted, zkey, _lazy.key_bits
+            p.stream_id, p.stream, p.fkey, p.dev, p.P = stream_id, torch.cuda.current_stream(dev), fkey, dev, P
+            p.xyz_id, p.vis = (xyz.data_ptr(), xyz._version), None
+            binning = p.binning
+            ctx.rp = rp
+            cfg["pending"] = p
+            lst = _pending_fwd.setdefault(di, [])
+            lst.append(p)
+            if len(lst) >= _LAZY_MAX:
+                _flush_pending(di)
+        else:
+            while True:
+                binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+                words = _zero_words(dev)                                   # [N, overflow word, key mismatch, spare], zero
+                fv = (_lib.B3gsForwardView * 1)()
+                fv[0].view = C.pointer(sc)
+                fv[0].geometry, fv[0].binning, fv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
+                fv[0].binning_capacity = cap
+                fv[0].out_color, fv[0].out_depth, fv[0].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
+                fv[0].radii, fv[0].device_num_rendered = radii.data_ptr(), words.data_ptr()
+                fv[0].depth_order_from, fv[0].seg1_fraction = -1, 0.0
+                fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
+                fv[0].depth_key_bits = _lazy.key_bits
+                fv[0].fresh_image = 1
+                if hint is not None and P > 0:
+                    fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
+                    fv[0].hint_trusted = int(trusted)
+                    _stats["hinted"] += 1
+                    _stats["trusted"] += int(trusted)
+                with torch.cuda.device(dev):
+                    _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
+                if lazy and key in _lazy.capacity:
+                    ctx.lazy_token = _lazy.track(key, cap, words[:2])
+                    break
+                n, flag = (int(v) for v in words[:2].tolist())            # exact render: one read-back
+                _lazy.note(key, n)
+                if flag & 2:
+                    _lazy.key_bits = 0
+                    hint = None
+                if flag & 8:
+                    _lazy.trust_hints, trusted = False, False
+                ctx.lazy_token = None
+                if n <= cap and not (flag & 10):
+                    break
+                cap = max(cap, _lazy.capacity[key])                       # repeat with what it needs
+            if _ORDER_HINT:
+                _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
+                                       words=words, zkey=zkey, stream=stream_id)
         ctx.cfg, ctx.sc, ctx.rp = cfg, sc, rp
         ctx.save_for_backward(xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img)
         ctx.cap = cap
         ctx.m2d_leaf = means2D
+        if wait and ctx.lazy_token is None:
+            # still pending: the outputs leave as _LazyOut (made here, in the forward's no-grad mode: as_subclass() on a tensor
+            # that already carries a grad_fn would put an alias node between it and this one)
+            color, radii, depth, alpha = (t.as_subclass(_LazyOut) for t in (color, radii, depth, alpha))
         ctx.mark_non_differentiable(radii)
         # an output nobody differentiates (depth / alpha of the shifted render, train.py:128-129) arrives as None in the
         # backward, not as an image of zeros the blend backward would have to read
         ctx.set_materialize_grads(False)
-        # the chain of this iteration's renders of these parameters (see backward)
-        ctx.batch_key = (di, P, K, int(cfg["sh_degree"]), float(cfg["scale_modifier"]), bool(cfg["debug"]),
-                         tuple(t.data_ptr() for t in (xyz, f_dc, f_rest, scaling, rotation, opacity)))
+        ctx.batch_key = batch_key
         ctx.partner = None
         ctx.pending = []
         ctx.done_task = None
@@ -804,6 +941,8 @@ class _RasterizeRaw(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        if _pending_fwd:
+            _flush_pending()          # (a render whose outputs nobody touched before backward(): its forward runs now)
         if ctx.lazy_token is not None and not ctx.lazy_token[4]:
             _register_task(token=ctx.lazy_token)    # truncated lists / key span: raised at the end of THIS backward()
         saved = ctx.saved_tensors
@@ -840,9 +979,11 @@ class _RasterizeRaw(torch.autograd.Function):
         return (None,) * 8
 
 
-def rasterize_raw(pc, means2D, raster_settings, camera=None):
+def rasterize_raw(pc, means2D, raster_settings, camera=None, lazy_outputs=False):
     """render()'s fast path: `pc` = a model raw_model_ok() accepts.  -> (color, radii, depth, alpha).  `camera` (optional):
-    the object the matrices of `raster_settings` came from, for camera_depth_key()."""
+    the object the matrices of `raster_settings` came from, for camera_depth_key().  lazy_outputs: the caller hands the
+    outputs out as _LazyOut (render() does): -> (color, radii, depth, alpha, visibility) where the forward may still be
+    pending."""
     rs = raster_settings
     dev = pc._xyz.device
     t = [_dev_f32(x, n).reshape(-1) for x, n in ((rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"), (rs.projmatrix, "projmatrix"),
@@ -855,7 +996,15 @@ def rasterize_raw(pc, means2D, raster_settings, camera=None):
                debug=rs.debug, zkey=camera_depth_key(camera) if (camera is not None and _ORDER_HINT) else False,
                differentiated=torch.is_grad_enabled() and any(p.requires_grad for p in params + (means2D,)))
     del dev
-    return _RasterizeRaw.apply(*params, means2D, cfg)
+    if not lazy_outputs:
+        return _RasterizeRaw.apply(*params, means2D, cfg)
+    cfg["lazy_outputs"] = True
+    color, radii, depth, alpha = _RasterizeRaw.apply(*params, means2D, cfg)
+    p = cfg.pop("pending", None)
+    if p is None or p.ctx.lazy_token is not None:            # launched already (not eligible, or it completed a batch)
+        return color, radii, depth, alpha, radii > 0
+    p.vis = torch.empty((p.P,), dtype=torch.bool, device=p.dev)                      # radii > 0, formed behind the forward
+    return color, radii, depth, alpha, p.vis.as_subclass(_LazyOut)
 
 
 class GaussianRasterizer(nn.Module):

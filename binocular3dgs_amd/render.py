@@ -92,10 +92,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     if fused_node:
-        rendered_image, radii, depth, alpha = rasterize_raw(pc, screenspace_points, raster_settings, viewpoint_camera)
+        # (the forward of a render that will be differentiated may still be pending when this returns: rasterizer._LazyOut)
+        rendered_image, radii, depth, alpha, visible = rasterize_raw(pc, screenspace_points, raster_settings, viewpoint_camera,
+                                                                     lazy_outputs=True)
         return {"render": rendered_image,
                 "viewspace_points": screenspace_points,
-                "visibility_filter": radii > 0,
+                "visibility_filter": visible,
                 "radii": radii,
                 "rendered_depth": depth,
                 "rendered_alpha": alpha}

@@ -218,7 +218,10 @@ typedef struct B3gsForwardView {
   /* != 0: the caller KNOWS the keys are equal (it built both view matrices and their z rows are the same bits): the depth
    * sort is not even launched (an idle launch is ~5 us on this part, nine of them per view).  Still checked: a key that
    * differs sets *hint_mismatch and raises bit 3 of *overflow_flag (required non-NULL then) -- that view was rendered from
-   * a wrong depth order, the step is dropped like an overflowing one and the caller stops trusting its knowledge. */
+   * a wrong depth order, the step is dropped like an overflowing one and the caller stops trusting its knowledge.
+   * With depth_order_from == k - 1 (view k shares the order of the PREVIOUS view of the batch, no hint buffer involved): the
+   * projection compares this view's depth keys with that view's and raises bit 3 of *overflow_flag (required non-NULL) on
+   * a difference -- the same check for a pair rendered in one batch.  0: the pair is the caller's word (fused path). */
   int32_t hint_trusted;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,

@@ -67,10 +67,24 @@ def _golden_pairs():
     return out
 
 
+@pytest.fixture(autouse=True)
+def _forward_mode(request):
+    """Tests named test_lazy_* run with the default (a differentiated render's forward waits for its partner:
+    rasterizer._LazyOut); all others with B3GS_DROPIN_LAZY=0 semantics -- every render() launches its own forward before it
+    returns, which is what the depth-order hint / adoption mechanism they pin is about."""
+    import binocular3dgs_amd.rasterizer as R
+    R._flush_pending()
+    R._LAZY_FWD = request.node.name.startswith("test_lazy")
+    yield
+    R._flush_pending()
+    R._LAZY_FWD = True
+
+
 def _render_pair(model, cam, scam, bg, hint, inplace):
     import binocular3dgs_amd.rasterizer as R
     from binocular3dgs_amd.render import PipelineParams, render
     R._ORDER_HINT, R._INPLACE_GRADS = hint, inplace
+    R._flush_pending()
     R._order_hint.clear()
     R._last_raw_ctx.clear()
     try:
@@ -522,3 +536,218 @@ def test_a_backward_that_raised_midway_leaves_nothing_behind_for_the_next_attemp
     for pool in R._raw_scratch.values():
         for s in pool:
             assert float(s.abs().max()) == 0.0, "scratch rows must be left clean"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the default: the first render's forward waits for its partner (rasterizer._LazyOut)
+# ---------------------------------------------------------------------------------------------------------------------
+def _plain(t):
+    """the tensor behind a _LazyOut without going through torch's function dispatch (= without making it run)"""
+    with torch._C.DisableTorchFunctionSubclass():
+        return t.as_subclass(torch.Tensor)
+
+
+def test_lazy_pair_is_one_two_view_forward_with_the_results_of_two_single_ones():
+    """render(input view); render(shifted view) with nothing in between (train.py:100-128): ONE b3gs_forward_raw_batch of
+    two views when the second call arrives.  Until then the first render's images hold NaN; afterwards tile lists, images,
+    radii, visibility and all gradients equal the renders launched one by one."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.tensor([0.1, 0.0, 0.2], device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[1]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=5, device="cuda")
+    R._LAZY_FWD = False
+    for p in model.parameters():
+        p.grad = None
+    a0, b0 = _render_pair(model, cam, scam, bg, hint=False, inplace=True)
+    want_state = [_state(y, W, H) for y in (a0, b0)]
+    _loss(a0, b0, gc, gd, ga).backward()
+    ref = [p.grad.clone() for p in model.parameters()]
+    ref_m2d = (a0["viewspace_points"].grad.clone(), b0["viewspace_points"].grad.clone())
+    R._LAZY_FWD = True
+    for p in model.parameters():
+        p.grad = None
+    R._order_hint.clear()
+    R._last_raw_ctx.clear()
+    s0 = dict(R._stats)
+    a = render(cam, model, PipelineParams(), bg)
+    assert type(a["render"]) is R._LazyOut and len(R._pending_fwd[0]) == 1
+    assert a["render"].shape == (3, H, W) and a["render"].requires_grad and a["radii"].dtype == torch.int32   # metadata: no launch
+    assert len(R._pending_fwd[0]) == 1 and R._stats["lazy_batches"] == s0["lazy_batches"]
+    assert bool(torch.isnan(_plain(a["render"])).all()) and bool(torch.isnan(_plain(a["rendered_depth"])).all())
+    b = render(scam, model, PipelineParams(), bg)
+    assert not R._pending_fwd and R._stats["lazy_batches"] == s0["lazy_batches"] + 1
+    assert R._stats["lazy_views"] == s0["lazy_views"] + 2
+    assert R._stats["shared"] == s0["shared"] + 1          # Camera.shifted(): one depth sort for the pair, keys compared
+    assert type(b["render"]) is torch.Tensor                              # (the call that completed the batch)
+    for x, y, (ny, vy) in ((a, a0, want_state[0]), (b, b0, want_state[1])):
+        nx, vx = _state(x, W, H)
+        assert nx == ny and nx > 0
+        for k in ("point_list", "tile_ids", "ranges", "n_contrib", "tiles_touched", "depth_bits"):
+            assert torch.equal(vx[k], vy[k]), k
+        for k in ("render", "rendered_depth", "rendered_alpha", "radii", "visibility_filter"):
+            assert torch.equal(x[k], y[k]), k
+    _loss(a, b, gc, gd, ga).backward()
+    for n, p, r in zip("xyz f_dc f_rest scaling rotation opacity".split(), model.parameters(), ref):
+        assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 1e-4, n
+    for got, want in zip((a["viewspace_points"].grad, b["viewspace_points"].grad), ref_m2d):
+        assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("how", ["operator", "function", "method", "index", "repr", "numpy", "detach", "backward", "other_model",
+                                 "no_grad_render", "other_size", "other_stream"])
+def test_lazy_forward_runs_at_the_first_use_of_an_output(how):
+    """Whatever touches a pending output first makes the forward run before it: the values are those of an eager render."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 160, 120
+    model = _model(P=9000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    R._LAZY_FWD = False
+    want = render(cam, model, PipelineParams(), bg)
+    R._LAZY_FWD = True
+    R._order_hint.clear()
+    pkg = render(cam, model, PipelineParams(), bg)
+    img = pkg["render"]
+    assert R._pending_fwd and type(img) is R._LazyOut
+    s0 = R._stats["lazy_batches"]
+    if how == "operator":
+        got = (img * 1.0)
+    elif how == "function":
+        got = torch.stack([img])[0]
+    elif how == "method":
+        got = img.clone()
+    elif how == "index":
+        got = torch.cat([img[c:c + 1] for c in range(3)])
+    elif how == "repr":
+        repr(pkg["rendered_alpha"])
+        got = img
+    elif how == "numpy":
+        got = torch.from_numpy(img.detach().cpu().numpy()).cuda()
+    elif how == "detach":
+        got = img.detach()
+    elif how == "backward":
+        for p in model.parameters():
+            p.grad = None
+        torch.autograd.backward([img], [torch.ones(3, H, W, device="cuda")])
+        assert model._xyz.grad is not None and float(model._xyz.grad.abs().max()) > 0
+        got = img
+    elif how == "other_model":
+        render(cam, _model(P=5000, W=W, H=H, seed=3), PipelineParams(), bg)
+        got = img
+    elif how == "no_grad_render":
+        with torch.no_grad():
+            render(scam, model, PipelineParams(), bg)
+        got = img
+    elif how == "other_size":
+        small = synth.synth_view_set(96, 64, device="cuda")[0][0]
+        render(small, model, PipelineParams(), bg)
+        assert not R._pending_fwd            # (the first render of a shape is exact and synchronous: it never waits)
+        got = img
+    else:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            render(scam, model, PipelineParams(), bg)
+        torch.cuda.current_stream().wait_stream(side)
+        got = img
+    assert R._stats["lazy_batches"] >= s0 + 1
+    assert torch.equal(_plain(got) if type(got) is R._LazyOut else got, want["render"])
+    assert torch.equal(pkg["visibility_filter"], want["visibility_filter"]) and torch.equal(pkg["radii"], want["radii"])
+    R._flush_pending()
+
+
+def test_lazy_switch_off_and_direct_callers_are_eager():
+    """B3GS_DROPIN_LAZY=0 (module switch), rasterize_raw() called without lazy_outputs, and renders that will not be
+    differentiated never wait."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 160, 120
+    model = _model(P=9000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, _, _ = synth.synth_view_set(W, H, device="cuda")[0]
+    render(cam, model, PipelineParams(), bg)["render"].sum().item()      # (the shape's capacity is known from here on)
+    with torch.no_grad():
+        pkg = render(cam, model, PipelineParams(), bg)
+    assert type(pkg["render"]) is torch.Tensor and not R._pending_fwd
+    R._LAZY_FWD = False
+    pkg = render(cam, model, PipelineParams(), bg)
+    assert type(pkg["render"]) is torch.Tensor and not R._pending_fwd
+    R._LAZY_FWD = True
+    pkg = render(cam, model, PipelineParams(), bg)
+    assert type(pkg["render"]) is R._LazyOut and R._pending_fwd
+    R._flush_pending()
+    assert not bool(torch.isnan(pkg["render"]).any())
+
+
+def test_lazy_pair_with_a_camera_that_lies_about_its_z_row_is_refused():
+    """Two pending renders whose cameras claim the same z row share one depth sort (depth_order_from + hint_trusted): the
+    projection compares the keys, a difference raises bit 3 -- backward() refuses the step, the claim is not believed again
+    and the next pair sorts per view (images of a per-view render)."""
+    import copy
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import _lib, synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    gc, _, _ = synth.synth_pixel_grads(W, H, seed=5, device="cuda")
+    (c0, _, _), (c1, _, _) = synth.synth_view_set(W, H, device="cuda")[:2]
+    R._LAZY_FWD = False
+    want = render(c1, model, PipelineParams(), bg)["render"].detach().clone()
+    R._LAZY_FWD = True
+    liar = copy.copy(c1)
+    liar._b3gs_zkey = R.camera_depth_key(c0)
+    R._lazy.trust_hints = True
+    try:
+        for p in model.parameters():
+            p.grad = None
+        sh = R._stats["shared"]
+        a = render(c0, model, PipelineParams(), bg)
+        b = render(liar, model, PipelineParams(), bg)
+        assert R._stats["shared"] == sh + 1
+        with pytest.raises(_lib.B3gsError, match="depth order of another view"):
+            ((a["render"] + b["render"]) * gc).sum().backward()
+        assert R._lazy.trust_hints is False
+        a = render(c0, model, PipelineParams(), bg)
+        b = render(liar, model, PipelineParams(), bg)
+        assert R._stats["shared"] == sh + 1 and torch.equal(b["render"], want)
+    finally:
+        R._lazy.trust_hints = True
+
+
+def test_lazy_pair_then_a_single_render_adopts_the_order_of_the_view_that_sorted():
+    """After a two-view forward whose second view borrowed the first one's depth order, the order offered to the NEXT render
+    is the first view's (the borrower has no sorted arrays of its own): a third render of the same camera row, launched
+    alone, must produce the lists of a render that sorted for itself."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 208, 144
+    model = _model(W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cam, scam, _ = synth.synth_view_set(W, H, device="cuda")[1]
+    R._LAZY_FWD, R._ORDER_HINT = False, False
+    want = render(cam, model, PipelineParams(), bg)
+    R._LAZY_FWD, R._ORDER_HINT = True, True
+    R._lazy.trust_hints = True
+    sh = R._stats["shared"]
+    a = render(cam, model, PipelineParams(), bg)
+    b = render(scam, model, PipelineParams(), bg)
+    assert R._stats["shared"] == sh + 1 and not R._pending_fwd
+    t0 = R._stats["trusted"]
+    c = render(cam, model, PipelineParams(), bg)          # waits alone ...
+    c["render"].sum()                                     # ... launched alone, with the pair's order as a trusted hint
+    assert R._stats["trusted"] == t0 + 1
+    nc, vc = _state(c, W, H)
+    nw, vw = _state(want, W, H)
+    assert nc == nw
+    for k in ("point_list", "tile_ids", "ranges", "n_contrib"):
+        assert torch.equal(vc[k], vw[k]), k
+    assert torch.equal(c["render"], want["render"]) and b["render"].shape == a["render"].shape

@@ -108,3 +108,42 @@ def test_densification_statistics_without_boolean_indexing_keep_the_reference_bi
         b.denom[idx] += 1
     assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
     assert torch.equal(a.max_radii2D, b.max_radii2D)
+
+
+def test_lazy_output_runs_what_is_pending_at_the_first_use_and_not_for_metadata(monkeypatch):
+    """rasterizer._LazyOut (what render() hands out while a differentiated render's forward waits for its partner): any torch
+    function, method or operator on it launches what is pending first; shape / dtype / device-style metadata does not; the
+    results of operations are plain tensors; the autograd node stays attached."""
+    import torch
+    import binocular3dgs_amd.rasterizer as R
+    launched = []
+    monkeypatch.setattr(R, "_launch_forward", lambda lst: launched.append(list(lst)))
+    base = torch.ones(3, 4, 5, requires_grad=True) * 2.0
+    x = base.detach().requires_grad_(True).as_subclass(R._LazyOut)
+
+    def arm():
+        R._pending_fwd.clear()
+        R._pending_fwd[0] = ["view"]
+        launched.clear()
+
+    try:
+        arm()
+        assert x.shape == (3, 4, 5) and x.dtype == torch.float32 and x.device.type == "cpu" and x.requires_grad
+        assert x.size(1) == 4 and x.dim() == 3 and len(x) == 3 and x.numel() == 60 and not x.is_cuda and x.ndim == 3
+        assert launched == [] and R._pending_fwd
+        for use in (lambda: x * 2.0, lambda: x[0], lambda: x.sum(), lambda: torch.stack([x]), lambda: x.detach(),
+                    lambda: repr(x), lambda: x.clone(), lambda: x.cpu(), lambda: torch.nn.functional.relu(x),
+                    lambda: x.unsqueeze(0), lambda: x.data_ptr(), lambda: x + x, lambda: x.tolist(),
+                    lambda: x.sum().backward()):
+            arm()
+            r = use()
+            assert launched == [["view"]] and not R._pending_fwd, use
+            if torch.is_tensor(r):
+                assert r is x or type(r) is torch.Tensor      # (x.cpu() of a CPU tensor is x itself)
+        arm()
+        R._flush_pending(1)                      # another device's list: nothing happens
+        assert launched == [] and R._pending_fwd
+        R._flush_pending()
+        assert launched == [["view"]]
+    finally:
+        R._pending_fwd.clear()
