@@ -356,6 +356,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
     b3gs_bin_view(fv.binning, sc.P, fv.binning_capacity, &b);
     pb.sc[k] = sc;
     pb.out[k] = b3gs_pre_out(sc, g, im, fv.radii);
+    pb.out[k].visible = fv.visible;
     jobs[k] = BinJob{sc.W, sc.H, g, b, im, fv.binning_capacity, fv.device_num_rendered, fv.depth_order_from, nullptr,
                      nullptr, 1, 0, fv.high_water, fv.overflow_flag};
     if (fv.depth_order_hint && sc.P > 0) {   // ABI 7: an earlier forward's depth order, adopted while every key is equal

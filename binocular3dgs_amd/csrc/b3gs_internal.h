@@ -235,6 +235,7 @@ struct PreOut {
                         //    (keep the rect in a register); 2: second of that pair: store both as one 16-byte word
   uint32_t* clamped;
   int32_t* radii;
+  uint8_t* visible = nullptr;   // optional: radii > 0 as bytes (B3gsForwardView::visible)
   uint2* ranges;
   uint2* ranges2;
   unsigned long long* open_rows;

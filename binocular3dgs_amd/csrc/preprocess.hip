@@ -397,6 +397,7 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
     }
   }
   g.radii[i] = radius_out;
+  if (g.visible) g.visible[i] = radius_out > 0 ? 1 : 0;
   g.tiles_touched[i] = touched;
   g.depth_key[i] = dkey;
   // the depth order of an earlier forward is adopted only while every key equals the key that forward sorted

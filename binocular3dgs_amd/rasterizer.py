@@ -134,6 +134,8 @@ class _LazyN:
         self.pending = []      # [token] = [key, capacity used, pinned int32[1], event, checked]
         self.pinned = None
         self.slot = 0
+        self.pinned4 = None
+        self.slot4 = 0
         self.enabled = os.environ.get("B3GS_DROPIN_SYNC", "0") != "1"
         self.key_bits = 27     # fused render() node: depth sort on 27-bit keys until a render reports a key outside the span
         self.trust_hints = True    # ... and host-side knowledge of equal z rows is trusted until the device contradicts it
@@ -203,6 +205,25 @@ class _LazyN:
         tok = [key, cap, host, ev, False]
         self.pending.append(tok)
         return tok
+
+    def track_rows(self, keys, caps, rows):
+        """The same for the views of ONE batched forward: `rows` = their [n, 4] word rows, consecutive in device memory ->
+        one device-to-host copy and one event for all of them (a small copy occupies the stream for 10-20 us)."""
+        n = rows.shape[0]
+        if self.pinned4 is None:
+            self.pinned4 = torch.zeros((self.RING, 4), dtype=torch.int32).pin_memory()
+        if len(self.pending) >= self.RING - n:
+            self.poll(force=True)
+        if self.slot4 + n > self.RING:
+            self.slot4 = 0
+        host = self.pinned4[self.slot4:self.slot4 + n]
+        self.slot4 += n
+        host.copy_(rows, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(rows.device))
+        toks = [[keys[k], caps[k], host[k, :2], ev, False] for k in range(n)]
+        self.pending.extend(toks)
+        return toks
 
     def flush_at_exit(self):
         try:
@@ -438,7 +459,7 @@ _pending_fwd = {}     # device index -> [_PendingFwd]: differentiated renders wh
 class _PendingFwd:
     """One render() whose forward is still to be launched: everything b3gs_forward_raw_batch needs, already allocated."""
     __slots__ = ("ctx", "sc", "geom", "binning", "img", "out", "radii", "words", "cap", "key", "hint", "trusted", "zkey",
-                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P")
+                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P", "ring", "row")
 
 
 def _meta_funcs():
@@ -504,6 +525,8 @@ def _launch_forward(lst):
         fv[k].high_water, fv[k].overflow_flag = None, p.words[1:].data_ptr()
         fv[k].depth_key_bits = p.key_bits
         fv[k].fresh_image = 1
+        if p.vis is not None:
+            fv[k].visible = p.vis.data_ptr()          # (torch.bool is one byte, 0 / 1)
         if (k > 0 and _ORDER_HINT and _lazy.trust_hints and p.zkey and p.zkey == lst[k - 1].zkey
                 and fv[k - 1].depth_order_from == -1):
             # the host knows that this view's z row is its predecessor's (camera_depth_key): one depth sort for both; the
@@ -519,10 +542,12 @@ def _launch_forward(lst):
     other = cur.cuda_stream != p0.stream_id
     with torch.cuda.device(p0.dev), (torch.cuda.stream(p0.stream) if other else contextlib.nullcontext()):
         _lib.check(L.b3gs_forward_raw_batch(n, fv, C.byref(p0.ctx.rp), 3, p0.stream_id), "b3gs_forward_raw_batch")
-        for p in lst:
-            p.ctx.lazy_token = _lazy.track(p.key, p.cap, p.words[:2])
-            if p.vis is not None:
-                torch.gt(p.radii, 0, out=p.vis)
+        if n > 1 and all(q.ring is p0.ring and q.row == p0.row + k for k, q in enumerate(lst)):
+            toks = _lazy.track_rows([q.key for q in lst], [q.cap for q in lst], p0.ring[p0.row:p0.row + n])
+        else:
+            toks = [_lazy.track(q.key, q.cap, q.words[:2]) for q in lst]
+        for p, tok in zip(lst, toks):
+            p.ctx.lazy_token = tok
     _stats["lazy_batches"] += 1
     _stats["lazy_views"] += n
     if _ORDER_HINT:
@@ -554,17 +579,17 @@ def _dev_index(dev) -> int:
     return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
-def _zero_words(dev):
+def _zero_words(dev, with_row=False):
     """Four zeroed int32 words on `dev` without a fill kernel per render ([N, overflow word, depth-key mismatch, spare]):
     slots of a ring that is zeroed once per lap (a slot handed out is read by the host long before the ring comes round:
-    4096 renders later)."""
+    4096 renders later).  with_row: also (ring, row index) -- consecutive calls get consecutive rows of one tensor."""
     idx = _dev_index(dev)
     ent = _word_ring.get(idx)
     if ent is None or ent[1] >= ent[0].shape[0]:
         ent = _word_ring[idx] = [torch.zeros((4096, 4), dtype=torch.int32, device=dev), 0]
     w = ent[0][ent[1]]
     ent[1] += 1
-    return w
+    return (w, ent[0], ent[1] - 1) if with_row else w
 
 
 def camera_depth_key(cam):
@@ -846,6 +871,8 @@ class _RasterizeRaw(torch.autograd.Function):
         out = torch.empty((5, H, W), **f32)          # colour | depth | alpha
         color, depth, alpha = out[0:3], out[3:4], out[4:5]
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        # render()'s `visibility_filter` = radii > 0: written by the projection (B3gsForwardView::visible)
+        vis = cfg["vis"] = torch.empty((P,), dtype=torch.bool, device=dev) if cfg.get("lazy_outputs") else None
         cap = _lazy.capacity.get(key) or max(1 << 20, 12 * P)
         # the previous raw forward of the same position tensor (same storage, same version counter): probably the same
         # Gaussians -- its depth order is offered to the library, which verifies key by key
@@ -863,14 +890,15 @@ class _RasterizeRaw(torch.autograd.Function):
                 hint = None
         ctx.lazy_token = None
         if wait:
-            out.fill_(float("nan"))                                        # (see _LazyOut: nobody may read these unnoticed)
+            if len(pend or ()) + 1 < _LAZY_MAX:                            # (not for the render that completes the batch)
+                out.fill_(float("nan"))                                    # see _LazyOut: nobody may read these unnoticed
             p = _PendingFwd()
             p.ctx, p.sc, p.geom, p.img, p.out, p.radii, p.cap, p.key = ctx, sc, geom, img, (color, depth, alpha), radii, cap, key
             p.binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
-            p.words = _zero_words(dev)
+            p.words, p.ring, p.row = _zero_words(dev, with_row=True)
             p.hint, p.trusted, p.zkey, p.key_bits = hint, trusted, zkey, _lazy.key_bits
             p.stream_id, p.stream, p.fkey, p.dev, p.P = stream_id, torch.cuda.current_stream(dev), fkey, dev, P
-            p.xyz_id, p.vis = (xyz.data_ptr(), xyz._version), None
+            p.xyz_id, p.vis = (xyz.data_ptr(), xyz._version), vis
             binning = p.binning
             ctx.rp = rp
             cfg["pending"] = p
@@ -892,6 +920,7 @@ class _RasterizeRaw(torch.autograd.Function):
                 fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
                 fv[0].depth_key_bits = _lazy.key_bits
                 fv[0].fresh_image = 1
+                fv[0].visible = None if vis is None else vis.data_ptr()
                 if hint is not None and P > 0:
                     fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
                     fv[0].hint_trusted = int(trusted)
@@ -1000,11 +1029,10 @@ def rasterize_raw(pc, means2D, raster_settings, camera=None, lazy_outputs=False)
         return _RasterizeRaw.apply(*params, means2D, cfg)
     cfg["lazy_outputs"] = True
     color, radii, depth, alpha = _RasterizeRaw.apply(*params, means2D, cfg)
-    p = cfg.pop("pending", None)
+    p, vis = cfg.pop("pending", None), cfg.pop("vis")
     if p is None or p.ctx.lazy_token is not None:            # launched already (not eligible, or it completed a batch)
-        return color, radii, depth, alpha, radii > 0
-    p.vis = torch.empty((p.P,), dtype=torch.bool, device=p.dev)                      # radii > 0, formed behind the forward
-    return color, radii, depth, alpha, p.vis.as_subclass(_LazyOut)
+        return color, radii, depth, alpha, vis
+    return color, radii, depth, alpha, vis.as_subclass(_LazyOut)
 
 
 class GaussianRasterizer(nn.Module):

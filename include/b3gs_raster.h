@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 7
+#define B3GS_ABI_VERSION 8
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -223,6 +223,9 @@ typedef struct B3gsForwardView {
    * projection compares this view's depth keys with that view's and raises bit 3 of *overflow_flag (required non-NULL) on
    * a difference -- the same check for a pair rendered in one batch.  0: the pair is the caller's word (fused path). */
   int32_t hint_trusted;
+  /* ABI 8 (may be NULL): [P] bytes <- radii > 0, render()'s `visibility_filter` (gaussian_renderer/__init__.py:99), written
+   * by the projection next to the radius instead of by a compare kernel per render afterwards. */
+  uint8_t* visible;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);
