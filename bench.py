@@ -651,12 +651,32 @@ def main():
             extras["dropin_iters_per_s"] = round(5 / el, 2)
             extras["dropin_what"] = ("the same 6-view iteration through the zero-change surface: render() per view (one "
                                      "autograd node on the raw parameters each, rasterizer._RasterizeRaw) + torch.autograd."
-                                     "backward + one-launch Adam.  Behind that surface the shifted view of every pair adopts its "
-                                     "input view's depth order (device-checked, ABI 7) and the six nodes of the backward launch "
-                                     "ONE blend backward + ONE chain-rule pass (engine-checked self-accumulation); the forward of "
-                                     "each view stays a single-view pipeline: render() must return finished tensors")
+                                     "backward + one-launch Adam.  Behind that surface the forward of a render waits for its "
+                                     "partner (outputs that launch what is pending at their first use, rasterizer._LazyOut): an "
+                                     "input view and its shifted view run as ONE two-view forward with one depth sort (keys "
+                                     "compared on the device, ABI 8), three such launches per iteration; the six nodes of the "
+                                     "backward launch ONE blend backward + ONE chain-rule pass (engine-checked "
+                                     "self-accumulation).  dropin_eager_forward_iters_per_s: B3GS_DROPIN_LAZY=0, every render() "
+                                     "launches its own forward before it returns (the shifted view adopts the depth order)")
             from binocular3dgs_amd import rasterizer as _R
             extras["dropin_stats"] = dict(_R._stats)
+            _R._flush_pending()
+            _R._LAZY_FWD = False
+            try:
+                el = j.timed_best(5)
+                extras["dropin_eager_forward_iters_per_s"] = round(5 / el, 2)
+            finally:
+                _R._flush_pending()
+                _R._LAZY_FWD = True
+            # B3GS_DROPIN_LAZY_MAX=6: this loop renders its six views before anything consumes them, so all six can wait
+            # for ONE forward (train.py's own loop consumes a pair at a time: the default of 2 is its shape)
+            old_max, _R._LAZY_MAX = _R._LAZY_MAX, 6
+            try:
+                el = j.timed_best(5)
+                extras["dropin_lazy_max6_iters_per_s"] = round(5 / el, 2)
+            finally:
+                _R._flush_pending()
+                _R._LAZY_MAX = old_max
             del j
             torch.cuda.empty_cache()
             # the reference's own iteration shape (one random input view + one random shifted partner, cameras changing every

@@ -751,3 +751,45 @@ def test_lazy_pair_then_a_single_render_adopts_the_order_of_the_view_that_sorted
     for k in ("point_list", "tile_ids", "ranges", "n_contrib"):
         assert torch.equal(vc[k], vw[k]), k
     assert torch.equal(c["render"], want["render"]) and b["render"].shape == a["render"].shape
+
+
+def test_lazy_max_above_two_batches_every_pending_render_of_the_iteration():
+    """B3GS_DROPIN_LAZY_MAX = 6: the six renders of an iteration wait for ONE six-view forward (three pairs, three depth
+    sorts), launched by the backward; gradients equal renders launched one by one."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    W, H = 160, 120
+    model = _model(P=12000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    cams = [c for cam, scam, _ in synth.synth_view_set(W, H, device="cuda")[:3] for c in (cam, scam)]
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=4, device="cuda")
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        R._order_hint.clear()
+        R._last_raw_ctx.clear()
+        pk = [render(c, model, PipelineParams(), bg) for c in cams]
+        outs = [x for i, k in enumerate(pk) for x in ((k["render"], k["rendered_depth"], k["rendered_alpha"]) if i % 2 == 0
+                                                      else (k["render"],))]
+        grads = [g for i in range(6) for g in ((gc, gd, ga) if i % 2 == 0 else (gc,))]
+        torch.autograd.backward(outs, grads)
+        return pk, [p.grad.clone() for p in model.parameters()]
+
+    R._LAZY_FWD = False
+    pk0, ref = run()
+    R._LAZY_FWD, old = True, R._LAZY_MAX
+    R._LAZY_MAX = 6
+    try:
+        s0 = dict(R._stats)
+        pk, got = run()
+        assert R._stats["lazy_batches"] == s0["lazy_batches"] + 1 and R._stats["lazy_views"] == s0["lazy_views"] + 6
+        assert R._stats["shared"] == s0["shared"] + 3
+    finally:
+        R._LAZY_MAX = old
+    for a, b in zip(pk, pk0):
+        assert torch.equal(a["render"], b["render"]) and torch.equal(a["radii"], b["radii"])
+        assert torch.equal(a["visibility_filter"], b["visibility_filter"])
+    for n, g, r in zip("xyz f_dc f_rest scaling rotation opacity".split(), got, ref):
+        assert rel_l2(g.cpu().numpy(), r.cpu().numpy()) < 1e-4, n
