@@ -647,8 +647,8 @@ def main():
             dargs.optimizer = "b3gs"
             j = Job(dargs, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", path="dropin", graph=False)
             j.prepare(2)
-            el = j.timed_best(10)
-            extras["dropin_iters_per_s"] = round(10 / el, 2)
+            el = j.timed_best(20)
+            extras["dropin_iters_per_s"] = round(20 / el, 2)
             extras["dropin_what"] = ("the same 6-view iteration through the zero-change surface: render() per view (one "
                                      "autograd node on the raw parameters each, rasterizer._RasterizeRaw) + torch.autograd."
                                      "backward + one-launch Adam.  Behind that surface the forward of a render waits for its "
@@ -663,8 +663,8 @@ def main():
             _R._flush_pending()
             _R._LAZY_FWD = False
             try:
-                el = j.timed_best(10)
-                extras["dropin_eager_forward_iters_per_s"] = round(10 / el, 2)
+                el = j.timed_best(20)
+                extras["dropin_eager_forward_iters_per_s"] = round(20 / el, 2)
             finally:
                 _R._flush_pending()
                 _R._LAZY_FWD = True
@@ -672,8 +672,8 @@ def main():
             # for ONE forward (train.py's own loop consumes a pair at a time: the default of 2 is its shape)
             old_max, _R._LAZY_MAX = _R._LAZY_MAX, 6
             try:
-                el = j.timed_best(10)
-                extras["dropin_lazy_max6_iters_per_s"] = round(10 / el, 2)
+                el = j.timed_best(20)
+                extras["dropin_lazy_max6_iters_per_s"] = round(20 / el, 2)
             finally:
                 _R._flush_pending()
                 _R._LAZY_MAX = old_max
