@@ -823,7 +823,10 @@ class _RasterizeRaw(torch.autograd.Function):
 
     What an unchanged train.py:100,128 gets on top of that (the input view and its shifted partner are two render()
     calls of one iteration):
-      * forward -- the second render adopts the depth order of the first: its view matrix has the same z row (the shift
+      * forward -- by default the first render WAITS for the second (its outputs are _LazyOut: they launch what is pending
+        at their first use) and both run as one two-view b3gs_forward_raw_batch with one depth sort when the host knows the
+        z rows are equal (keys compared on the device, ABI 8).  When every render launches by itself (something consumed
+        the first result in between, B3GS_DROPIN_LAZY=0) the second render adopts the depth order of the first: its view matrix has the same z row (the shift
         is along the camera x axis, scene/__init__.py:96-115), so every depth key is equal; the library CHECKS that on the
         device (B3gsForwardView::depth_order_hint) and sorts itself when a key differs, so the answer never depends on it;
       * backward -- inside a plain accumulating `loss.backward()` the nodes of renders of the same parameters hand their
