@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
   constexpr int HAL = 2, TW = LT + 2 * HAL;
   __shared__ float sD[TW][TW + 1];   // disparity * mask with a halo of 2
   __shared__ float sG[TW][TW + 1];   // sum over channels of gt, same halo (edge weights: one value per pixel)
-  __shared__ float red[4];
+  __shared__ float red4[4][4];
   const int W = a.W, H = a.H;
   const size_t hw = (size_t)H * W;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * LT + tx;
@@ -310,27 +310,46 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
       sG[rr][cc] = gsum;
     }
     __syncthreads();
-    if (in) {
-      const Disp me = disparity_at(a, r, c);
-      float dLdd = 0.f;
-      if (me.m != 0.f) {   // both taps inside
-        const float x0 = floorf(me.d), x1 = x0 + 1.0f;
-        const int c0 = c + (int)x0, c1 = c0 + 1;
-        const float w0 = x1 - me.d, w1 = me.d - x0;
+    // the warp term: every lane of the wave runs the channel loop (the merge below talks to the neighbouring lanes)
+    Disp me;
+    me.d = 0.f; me.m = 0.f;
+    if (in) me = disparity_at(a, r, c);
+    const bool warp_ok = in && me.m != 0.f;   // both taps inside
+    const float wx0 = warp_ok ? floorf(me.d) : 0.f;
+    const int c0 = warp_ok ? c + (int)wx0 : -0x40000000, c1 = c0 + 1;
+    const float w0 = (wx0 + 1.0f) - me.d, w1 = me.d - wx0;
+    float dLdd = 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-          const float s0 = a.shifted[ch * hw + (size_t)r * W + c0], s1 = a.shifted[ch * hw + (size_t)r * W + c1];
-          const float warped = w0 * s0 + w1 * s1;
-          const float diff = warped * me.m - a.gt[ch * hw + p] * me.m;
-          s_l1m += fabsf(diff);
-          const float gW = sgn(diff) * me.m * a.c_l1m;   // dL/dwarped
-          if (gW != 0.f) {
-            atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c0], w0 * gW);
-            atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c1], w1 * gW);
-            dLdd += gW * (s1 - s0);
-          }
+    for (int ch = 0; ch < 3; ch++) {
+      float v0 = 0.f, v1 = 0.f;
+      bool has = false;
+      if (warp_ok) {
+        const float s0 = a.shifted[ch * hw + (size_t)r * W + c0], s1 = a.shifted[ch * hw + (size_t)r * W + c1];
+        const float warped = w0 * s0 + w1 * s1;
+        const float diff = warped * me.m - a.gt[ch * hw + p] * me.m;
+        s_l1m += fabsf(diff);
+        const float gW = sgn(diff) * me.m * a.c_l1m;   // dL/dwarped
+        if (gW != 0.f) {
+          has = true;
+          v0 = w0 * gW;
+          v1 = w1 * gW;
+          dLdd += gW * (s1 - s0);
         }
       }
+      // Neighbouring pixels of a row mostly share floor(disparity): my right tap is then my right neighbour's left tap.
+      // Its contribution rides on my atomic and it skips its own (the scatter's atomics were 16 of the kernel's 36 us).
+      const int n_c0 = __shfl_down(c0, 1, 64), l_c0 = __shfl_up(c0, 1, 64);
+      const float n_v0 = __shfl_down(v0, 1, 64);
+      const int n_has = __shfl_down((int)has, 1, 64), l_has = __shfl_up((int)has, 1, 64);
+      const bool take = has && n_has && tx < LT - 1 && n_c0 == c1;          // (tx + 1 is the next lane of the same row)
+      const bool given = has && l_has && tx > 0 && c0 == l_c0 + 1;
+      if (take) v1 += n_v0;
+#ifndef B3GS_LOSS_ABLATE_ATOMIC
+      if (has && !given) atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c0], v0);
+      if (has) atomicAdd(&a.dL_dshifted[ch * hw + (size_t)r * W + c1], v1);
+#endif
+    }
+    if (in) {
       // edge-aware smoothness of D' = d*m: |ex * dx(D')| + |ey * dy(D')| on the interior
       // g at location (rr,cc) along axis: value and d/dD' factor
       auto gx_at = [&](int rr, int cc, float& val) -> float {   // returns sign(v)*ex*c_smooth, val = |v|
@@ -366,10 +385,22 @@ __global__ void __launch_bounds__(256) binocular_kernel(LossBatch lb) {
       a.dL_ddepth[p] = dLdd * (-me.d / (a.depth[p] + 1e-5f));
     }
   }
-  const float t0 = block_sum_256(s_alpha, red);
-  const float t1 = block_sum_256(s_l1m, red);
-  const float t2 = block_sum_256(s_sx, red);
-  const float t3 = block_sum_256(s_sy, red);
+  // the four sums of the workgroup behind ONE pair of barriers
+  float v4[4] = {s_alpha, s_l1m, s_sx, s_sy};
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v4[q] += __shfl_xor(v4[q], d, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) red4[q][tid >> 6] = v4[q];
+  }
+  __syncthreads();
+  const float t0 = red4[0][0] + red4[0][1] + red4[0][2] + red4[0][3];
+  const float t1 = red4[1][0] + red4[1][1] + red4[1][2] + red4[1][3];
+  const float t2 = red4[2][0] + red4[2][1] + red4[2][2] + red4[2][3];
+  const float t3 = red4[3][0] + red4[3][1] + red4[3][2] + red4[3][3];
   if (tid == 0) {
     if (t0 != 0.f) add_sum(a.sums, 5, t0);
     if (t1 != 0.f) add_sum(a.sums, 2, t1);
