@@ -590,6 +590,9 @@ def test_lazy_pair_is_one_two_view_forward_with_the_results_of_two_single_ones()
             assert torch.equal(vx[k], vy[k]), k
         for k in ("render", "rendered_depth", "rendered_alpha", "radii", "visibility_filter"):
             assert torch.equal(x[k], y[k]), k
+        # (ABI 8: the projection writes the visibility bytes itself)
+        assert x["visibility_filter"].dtype == torch.bool and torch.equal(x["visibility_filter"], x["radii"] > 0)
+        assert torch.equal(y["visibility_filter"], y["radii"] > 0) and 0 < int(y["visibility_filter"].sum()) < y["radii"].numel()
     _loss(a, b, gc, gd, ga).backward()
     for n, p, r in zip("xyz f_dc f_rest scaling rotation opacity".split(), model.parameters(), ref):
         assert rel_l2(p.grad.cpu().numpy(), r.cpu().numpy()) < 1e-4, n
