@@ -542,10 +542,17 @@ def _launch_forward(lst):
     other = cur.cuda_stream != p0.stream_id
     with torch.cuda.device(p0.dev), (torch.cuda.stream(p0.stream) if other else contextlib.nullcontext()):
         _lib.check(L.b3gs_forward_raw_batch(n, fv, C.byref(p0.ctx.rp), 3, p0.stream_id), "b3gs_forward_raw_batch")
-        if n > 1 and all(q.ring is p0.ring and q.row == p0.row + k for k, q in enumerate(lst)):
-            toks = _lazy.track_rows([q.key for q in lst], [q.cap for q in lst], p0.ring[p0.row:p0.row + n])
-        else:
-            toks = [_lazy.track(q.key, q.cap, q.words[:2]) for q in lst]
+        try:
+            if n > 1 and all(q.ring is p0.ring and q.row == p0.row + k for k, q in enumerate(lst)):
+                toks = _lazy.track_rows([q.key for q in lst], [q.cap for q in lst], p0.ring[p0.row:p0.row + n])
+            else:
+                toks = [_lazy.track(q.key, q.cap, q.words[:2]) for q in lst]
+        except BaseException:
+            # (track*() polls older renders when its ring is full and may raise THEIR overflow: these views are launched
+            # all the same -- mark them so, with nothing left to confirm)
+            for p in lst:
+                p.ctx.lazy_token = [p.key, p.cap, None, None, True]
+            raise
         for p, tok in zip(lst, toks):
             p.ctx.lazy_token = tok
     _stats["lazy_batches"] += 1
