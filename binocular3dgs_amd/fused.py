@@ -240,6 +240,9 @@ class FusedRasterizer:
                     for j in range(k):
                         if donor is not None and chunk[j]["cam"] is donor and arr[j].depth_order_from == -1:
                             arr[k].depth_order_from = j
+                            # (ABI 8: for an adjacent pair the projection compares the two depth keys of every Gaussian -- a
+                            # camera that names a `same_depth_as` whose z row it does not have raises bit 3: check_overflow)
+                            arr[k].hint_trusted = 1 if j == k - 1 else 0
                 rc = L.b3gs_forward_raw_batch(len(chunk), arr, C.byref(rp), 3, st.cuda_stream)
                 _lib.check(rc, "b3gs_forward_raw_batch")
             if streams is not None:
@@ -432,6 +435,10 @@ class FusedRasterizer:
         if hw <= self.capacity and not flag and not timed_out:
             return 0
         self.overflow_flag.zero_()
+        if flag & 8:
+            raise _lib.B3gsError("B3GS_ERR_ARG: a view was rendered from the depth order of the camera it names as "
+                                 "`same_depth_as`, but its depth keys differ (the z rows of the two view matrices are not the "
+                                 "same bits); the steps since the last check were dropped on the device")
         if flag & 2:                    # a depth key outside the 27-bit span: sort all 32 bits from now on
             self.depth_key_bits = 0
         if (flag & 4) or timed_out:

@@ -1016,3 +1016,30 @@ def test_forward_reuses_the_backward_tile_order_without_changing_the_images():
     third = fwd(views, False)           # back to 6 views with a 4-view order in the buffer
     for a, b in zip(first, third):
         assert torch.equal(a, b)
+
+
+def test_a_pair_that_claims_a_shared_depth_order_it_does_not_have_is_reported():
+    """render_batch() sorts ONE depth order for a camera and the camera that names it as `same_depth_as` (Camera.shifted()).
+    For an adjacent pair the projection compares the two depth keys of every Gaussian (ABI 8): a camera that claims a parent
+    whose z row it does not have raises bit 3 of the overflow word -- check_overflow() says so instead of letting the
+    device drop every following step in silence; honest pairs leave the word zero."""
+    import copy
+    from binocular3dgs_amd import _lib
+    from binocular3dgs_amd.fused import FusedRasterizer
+    W, H = 200, 144
+    model, pairs, bg = _setup(W=W, H=H)
+    (c0, s0, _), (c1, _, _) = pairs[:2]
+    fr = FusedRasterizer(model, W, H, num_slots=2)
+    with torch.no_grad():
+        fr.render_batch([(c0, 0), (s0, 1)], bg, _span_checked=True)
+    assert fr.check_overflow() == 0
+    liar = copy.copy(c1)
+    liar.same_depth_as = c0
+    with torch.no_grad():
+        fr.render_batch([(c0, 0), (liar, 1)], bg, _span_checked=True)
+    with pytest.raises(_lib.B3gsError, match="same_depth_as"):
+        fr.check_overflow()
+    assert int(fr.overflow_flag.item()) == 0          # cleared: the next honest pair is fine
+    with torch.no_grad():
+        fr.render_batch([(c0, 0), (s0, 1)], bg, _span_checked=True)
+    assert fr.check_overflow() == 0
