@@ -169,11 +169,14 @@ class _LazyN:
                               f"-- repeat the step")
 
     def poll(self, force=False):
-        keep, over = [], None
+        keep, over, waiting = [], None, False
         for tok in self.pending:
             if tok[4]:
                 continue
-            if not (force or tok[3].query()):
+            # (not forced: an early look only -- the copies of one stream complete in order, so behind the first one that is
+            # still in flight nothing is asked: an event query costs microseconds and every forward comes through here)
+            if waiting or not (force or tok[3].query()):
+                waiting = not force
                 keep.append(tok)
                 continue
             r = self._resolve(tok)

@@ -89,8 +89,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         prefiltered=False,
         debug=pipe.debug,
     )
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
     if fused_node:
         # (the forward of a render that will be differentiated may still be pending when this returns: rasterizer._LazyOut)
         rendered_image, radii, depth, alpha, visible = rasterize_raw(pc, screenspace_points, raster_settings, viewpoint_camera,
@@ -102,6 +100,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
                 "rendered_depth": depth,
                 "rendered_alpha": alpha}
 
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
