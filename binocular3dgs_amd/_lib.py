@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("B3GS_LIB") or os.path.join(_HERE, "libb3gs_raster.so")   # B3GS_LIB: A/B builds of the kernels
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -107,7 +107,11 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            "b3gs_backward_raw_accumulate", "b3gs_blend_forward_batch", "b3gs_blend_backward_batch",
            "b3gs_adam_step", "b3gs_forward_raw_batch", "b3gs_loss_workspace_floats", "b3gs_binocular_loss",
            "b3gs_densify_classify", "b3gs_densify_scatter", "b3gs_knn_workspace_bytes", "b3gs_knn_mean_dist2",
-           "b3gs_backward_raw_accumulate_range", "b3gs_binocular_loss_batch")
+           "b3gs_backward_raw_accumulate_range", "b3gs_binocular_loss_batch",
+           # ABI 9: the training loop's statements one by one
+           "b3gs_lossfn_workspace_floats", "b3gs_l1_loss_forward", "b3gs_l1_loss_backward", "b3gs_inverse_warp_forward",
+           "b3gs_inverse_warp_backward", "b3gs_smooth_loss_forward", "b3gs_smooth_loss_backward", "b3gs_ssim_forward",
+           "b3gs_ssim_backward", "b3gs_opacity_decay", "b3gs_add_densification_stats", "b3gs_adam_step_at")
 
 _lib = None
 
@@ -189,6 +193,24 @@ def lib():
     L.b3gs_adam_step.argtypes = [C.c_int32, C.POINTER(B3gsAdamSegment), C.c_void_p, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_adam_step.restype = C.c_int
+    V, I32, I64, F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    L.b3gs_lossfn_workspace_floats.argtypes = [I64, I32, I32]
+    L.b3gs_lossfn_workspace_floats.restype = C.c_size_t
+    L.b3gs_l1_loss_forward.argtypes = [V, V, V, I64, I32, I64, V, V, V]
+    L.b3gs_l1_loss_backward.argtypes = [V, V, V, I64, I32, I64, V, V, V, V, V]
+    L.b3gs_inverse_warp_forward.argtypes = [V, V, I32, I32, I32, I32, V, V, V]
+    L.b3gs_inverse_warp_backward.argtypes = [V, V, V, I32, I32, I32, I32, V, V, V]
+    L.b3gs_smooth_loss_forward.argtypes = [V, V, I32, I32, I32, I32, V, V, V]
+    L.b3gs_smooth_loss_backward.argtypes = [V, V, I32, I32, I32, I32, V, V, V, V]
+    L.b3gs_ssim_forward.argtypes = [V, V, I32, I32, I32, I32, I32, V, I32, V, V, V]
+    L.b3gs_ssim_backward.argtypes = [V, V, V, I32, I32, I32, I32, I32, V, V, V, V]
+    L.b3gs_opacity_decay.argtypes = [V, I64, F, V]
+    L.b3gs_add_densification_stats.argtypes = [I64, V, I64, V, V, V, V]
+    L.b3gs_adam_step_at.argtypes = [I32, C.POINTER(B3gsAdamSegment), I32, F, F, F, V]
+    for fn in (L.b3gs_l1_loss_forward, L.b3gs_l1_loss_backward, L.b3gs_inverse_warp_forward, L.b3gs_inverse_warp_backward,
+               L.b3gs_smooth_loss_forward, L.b3gs_smooth_loss_backward, L.b3gs_ssim_forward, L.b3gs_ssim_backward,
+               L.b3gs_opacity_decay, L.b3gs_add_densification_stats, L.b3gs_adam_step_at):
+        fn.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.b3gs_mark_visible.restype = C.c_int
     L.b3gs_debug_views.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -53,24 +53,50 @@ def focal2fov(focal: float, pixels: int) -> float:
     return 2 * math.atan(pixels / (2 * focal))
 
 
-_pinned = {}     # device -> [pinned float32 ring [64, 35], next slot]
+_pinned = {}     # device -> _PinnedRing
+
+
+class _PinnedRing:
+    """Rows of pinned host memory for asynchronous uploads of a few dozen floats.  A row is handed out again `rows` uploads
+    later -- by then its copy has normally run; an event recorded behind every copy makes that CERTAIN (a loop
+    that never synchronises, e.g. shifted cameras precomputed for a whole dataset behind a busy queue, can run more than 64
+    uploads ahead of the stream): a row whose copy is still in flight is waited for, not overwritten."""
+
+    def __init__(self, rows: int, cols: int):
+        self.buf = torch.empty((rows, cols), dtype=torch.float32).pin_memory()
+        self.events = [None] * rows
+        self.next = 0
+
+    def take(self):
+        """-> (row index, host row): safe to write"""
+        k = self.next % self.buf.shape[0]
+        self.next += 1
+        ev = self.events[k]
+        if ev is not None and not ev.query():
+            ev.synchronize()
+        return k, self.buf[k]
+
+    def uploaded(self, k: int, device):
+        """call right behind the non_blocking copy of row k"""
+        ev = self.events[k]
+        if ev is None:
+            ev = self.events[k] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
 
 
 def _staging(device):
-    """(host tensor, its numpy view): 35 floats the next shifted camera is assembled in.  On a HIP device: a slot of a
+    """(host tensor, its numpy view, done): 35 floats the next shifted camera is assembled in.  On a HIP device: a row of a
     pinned ring, so that the upload is an asynchronous copy (a pageable source makes the runtime block the host until the
-    stream has drained: ~170 us per iteration of the two-view schedule); a slot is reused 64 cameras later, long after its
-    copy ran."""
+    stream has drained: ~170 us per iteration of the two-view schedule); `done()` is called behind the copy."""
     device = torch.device(device)
     if device.type != "cuda":
         row = torch.empty(35, dtype=torch.float32)
-        return row, row.numpy()
-    ent = _pinned.get(device)
-    if ent is None:
-        ent = _pinned[device] = [torch.empty((64, 35), dtype=torch.float32).pin_memory(), 0]
-    row = ent[0][ent[1] % 64]
-    ent[1] += 1
-    return row, row.numpy()
+        return row, row.numpy(), lambda: None
+    ring = _pinned.get(device)
+    if ring is None:
+        ring = _pinned[device] = _PinnedRing(64, 35)
+    k, row = ring.take()
+    return row, row.numpy(), lambda: ring.uploaded(k, device)
 
 
 class Camera:
@@ -150,9 +176,10 @@ class Camera:
         #   wvt'[3,0] = wvt[3,0] - t,   full'[3,:] = wvt'[3,:] @ proj,   centre' = centre + t * wvt[:3,0]  (the camera x axis)
         # (round 3 cloned the view matrix, patched it and re-ran bmm + inverse on the device: ~25 tiny kernels, 54 us of
         # stream time per iteration of the reference's two-view schedule -- bench_ref_schedule.py)
-        row, buf = _staging(self.device)
+        row, buf, done = _staging(self.device)
         _shifted_block(self._host_matrices(), trans_dist, buf)
         dev_buf = row.to(self.device, non_blocking=True) if self.device.type == "cuda" else row
+        done()
         cam.world_view_transform = dev_buf[:16].view(4, 4)
         cam.full_proj_transform = dev_buf[16:32].view(4, 4)
         cam.camera_center = dev_buf[32:35]
@@ -187,7 +214,8 @@ class CameraPairSlots:
         dev = template.device
         self.device = dev
         self.block = torch.zeros(72, dtype=torch.float32, device=dev)
-        self._ring = [torch.empty((64, 72), dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.empty((64, 72)), 0]
+        self._ring = _PinnedRing(64, 72) if dev.type == "cuda" else None
+        self._host_row = None if dev.type == "cuda" else torch.empty(72, dtype=torch.float32)
         self.cam, self.shifted = Camera.__new__(Camera), Camera.__new__(Camera)
         for k, c in enumerate((self.cam, self.shifted)):
             c.__dict__.update({a: v for a, v in template.__dict__.items() if a not in ("_host", "_b3gs_zkey", "same_depth_as")})
@@ -200,8 +228,7 @@ class CameraPairSlots:
         self.set(template, trans_dist)
 
     def set(self, camera: Camera, trans_dist: float):
-        row = self._ring[0][self._ring[1] % 64]
-        self._ring[1] += 1
+        k, row = self._ring.take() if self._ring is not None else (0, self._host_row)
         buf = row.numpy()
         h = camera._host_matrices()
         buf[:16] = h["wvt"].reshape(-1)
@@ -211,6 +238,8 @@ class CameraPairSlots:
         buf[70] = np.float32(trans_dist)
         buf[71] = 0.0
         self.block.copy_(row, non_blocking=True)
+        if self._ring is not None:
+            self._ring.uploaded(k, self.device)
         # (what rasterizer.camera_depth_key derives the z row from follows the pose: its cache is dropped)
         self.cam.R, self.cam.T, self.cam.trans, self.cam.scale = camera.R, camera.T, camera.trans, camera.scale
         self.cam.__dict__.pop("_b3gs_zkey", None)

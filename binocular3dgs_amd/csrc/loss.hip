@@ -11,13 +11,11 @@
 // at 800x600 on MI355X, four times the whole rasterizer); here: 4 launches per pair, gradients produced
 // in the same pass as the value (the loss is the root of the graph: its upstream gradient is a scalar).
 // Every image is H*W*{1,3} floats: L2-resident; the kernels are launch/latency bound, not HBM bound.
-#include "b3gs_internal.h"
-#include <cmath>
+#include "loss_common.h"
 
 namespace {
+using namespace b3gs_loss;
 
-constexpr int LT = 16;          // output tile
-constexpr int LR = 5;           // SSIM window radius
 // partial sums: thousands of workgroups adding to ONE address serialise in L2 (measured: 153 us for the SSIM
 // statistics kernel, almost all of it the two atomics per workgroup); each of the 8 sums is spread over 64
 // slots picked by workgroup index and folded by the finalize kernel
@@ -26,7 +24,6 @@ __device__ __forceinline__ void add_sum(float* sums, int q, float v) {
   const unsigned b = blockIdx.y * gridDim.x + blockIdx.x + blockIdx.z * 7u;
   atomicAdd(&sums[q * SLOTS + (b & (SLOTS - 1))], v);
 }
-struct Win { float w[11]; };
 
 // one (input view, shifted view) pair; every kernel takes up to B3GS_MAX_FUSED_VIEWS pairs per launch (blockIdx.z)
 struct PairArgs {
@@ -55,61 +52,6 @@ struct LossBatch {
   int n;
   PairArgs p[B3GS_MAX_FUSED_VIEWS];
 };
-
-__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
-
-__device__ __forceinline__ float block_sum_256(float v, float* tmp) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x;
-  __syncthreads();
-  if ((tid & 63) == 0) tmp[tid >> 6] = v;
-  __syncthreads();
-  return tmp[0] + tmp[1] + tmp[2] + tmp[3];
-}
-
-// ---- SSIM: separable 11-tap window through LDS, 32x32 outputs per workgroup, 4 outputs per thread in both passes
-// (a sliding window of 14 LDS values feeds 4 outputs: 3.4x fewer LDS reads than one output per thread)
-constexpr int ST = 32;            // outputs per workgroup side
-constexpr int SW = ST + 2 * LR;   // 42 inputs per side
-
-// horizontal pass for NQ quantities: item = (row, group of 4 columns); in[q][row][col] -> out[q][row][col]
-template <int NQ>
-__device__ __forceinline__ void hpass4(const float (*in)[SW][SW + 1], float (*out)[SW][ST + 1], const Win& win, int tid) {
-  for (int it = tid; it < SW * (ST / 4); it += 256) {
-    const int r = it / (ST / 4), c0 = (it % (ST / 4)) * 4;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-      float v[14];
-#pragma unroll
-      for (int j = 0; j < 14; j++) v[j] = in[q][r][c0 + j];
-#pragma unroll
-      for (int o = 0; o < 4; o++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) acc = fmaf(win.w[k], v[o + k], acc);
-        out[q][r][c0 + o] = acc;
-      }
-    }
-  }
-}
-// vertical pass: thread = (column tx, group of 4 rows): res[q][o] for rows 4*tg + o
-template <int NQ>
-__device__ __forceinline__ void vpass4(const float (*hq)[SW][ST + 1], const Win& win, int tx, int tg, float (&res)[NQ][4]) {
-#pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    float v[14];
-#pragma unroll
-    for (int j = 0; j < 14; j++) v[j] = hq[q][4 * tg + j][tx];
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; k++) acc = fmaf(win.w[k], v[o + k], acc);
-      res[q][o] = acc;
-    }
-  }
-}
 
 // sums[0] += sum |x-y|, sums[1] += sum ssim_map; maps: dS/dmu1, dS/dE[x^2], dS/dE[xy] per channel
 // LDS: the x / y tile with its halo (14.4 KB) + the horizontal results of TWO quantities at a time (11 KB) = 25.5 KB, i.e.
@@ -449,11 +391,7 @@ extern "C" int b3gs_binocular_loss_batch(int32_t npairs, const B3gsLossIO* ios, 
   if (npairs <= 0 || npairs > B3GS_MAX_FUSED_VIEWS || !ios)
     return b3gs_fail(B3GS_ERR_ARG, "b3gs_binocular_loss", "pair count must be 1..8 and ios non-NULL");
   hipStream_t s = (hipStream_t)stream;
-  // window exactly as utils/loss_utils.py:23-26: double exp -> float tensor -> normalised in float
-  Win win;
-  float g[11], tot = 0.f;
-  for (int k = 0; k < 11; k++) { g[k] = (float)std::exp(-(double)((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); tot += g[k]; }
-  for (int k = 0; k < 11; k++) win.w[k] = g[k] / tot;
+  const Win win = make_window();
   LossBatch lb;
   lb.n = npairs;
   int gx = 0, gy = 0;

@@ -1,0 +1,561 @@
+// The loss functions of the binocular training step ONE BY ONE, behind the reference's own call signatures (ABI 9;
+// VERDICT r4 item 1): an unchanged train.py:123-148 calls
+//   l1_loss(network_output, gt, mask=None)                              utils/loss_utils.py:18-21
+//   ssim(img1, img2, window_size=11, size_average=True)                 utils/loss_utils.py:36-66
+//   SmoothLoss().forward(disparity, image)                              utils/loss_utils.py:68-91
+//   inverse_warp_images(image, disparity, row_indices, column_indices)  utils/graphics_utils.py:80-125
+// as separate statements with PyTorch glue between them, so the one-call block of loss.hip cannot stand in for them.
+// Each function is one launch forward and one launch backward (value and EVERY input gradient); the python side
+// (binocular3dgs_amd/loss_utils.py, graphics_utils.py) wraps them as autograd.Functions.
+//
+// Scalar results: every workgroup leaves one partial sum, the workgroup that arrives last folds them IN INDEX ORDER
+// (deterministic, no float atomics, no second launch) and resets the arrival counter.  Hand-off per the CDNA4 rules for
+// data that crosses XCDs inside one launch: plain store -> agent-scope release fence -> s_waitcnt vmcnt(0) -> relaxed
+// agent-scope ticket; the last workgroup: agent-scope acquire fence -> barrier -> plain loads.
+#include "loss_common.h"
+
+namespace {
+using namespace b3gs_loss;
+
+// workspace header: word 0 = second-level arrival counter, words 32 + 32 k (k < 64) = first-level counters a cache line
+// apart; all zero between launches.  Thousands of workgroups arriving at ONE address cost 10-18 ns each once they pile up
+// (measured on the Adam launch, optim.hip: 85 us of 105) -- a workgroup counts itself in one of 64 counters and only the
+// last of every counter touches the shared one.
+constexpr unsigned WS_SLOTS = 64u, WS_SLOT_STRIDE = 32u;
+constexpr int WS_HEADER = 32 + WS_SLOTS * WS_SLOT_STRIDE;
+
+// Every thread of a 256-thread workgroup passes its value(s): NV partial sums per workgroup go to
+// ws[WS_HEADER + q * nblocks + block].  Returns true in EVERY thread of the workgroup that arrived last (all partials of
+// the launch are then visible to it).  Hand-off (CDNA4: the XCDs' L2s are not coherent with each other): the partial is a
+// write-through (sc1) store, drained with s_waitcnt vmcnt(0) before the relaxed agent-scope ticket -- no release fence,
+// whose L2 write-back costs microseconds per workgroup --; the last workgroup issues ONE agent-scope acquire, then plain loads.
+template <int NV>
+__device__ __forceinline__ bool arrive_last(const float (&v)[NV], float* __restrict__ ws, unsigned nblocks, unsigned block) {
+  __shared__ float red[NV][4];
+  __shared__ unsigned s_last;
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x;
+  float w[NV];
+#pragma unroll
+  for (int q = 0; q < NV; q++) {
+    w[q] = v[q];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w[q] += __shfl_xor(w[q], d, 64);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; q++) red[q][tid >> 6] = w[q];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float* part = ws + WS_HEADER;
+#pragma unroll
+    for (int q = 0; q < NV; q++)
+      __hip_atomic_store(&part[(size_t)q * nblocks + block], (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned* hdr = reinterpret_cast<unsigned*>(ws);
+    const unsigned slot = block & (WS_SLOTS - 1u);
+    const unsigned mine = (nblocks - slot + WS_SLOTS - 1u) / WS_SLOTS;      // workgroups that share this counter
+    unsigned* cnt = hdr + 32 + slot * WS_SLOT_STRIDE;
+    unsigned last = 0u;
+    if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // self-cleaning
+      const unsigned nslots = nblocks < WS_SLOTS ? nblocks : WS_SLOTS;
+      if (__hip_atomic_fetch_add(hdr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslots - 1u) {
+        __hip_atomic_store(hdr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        last = 1u;
+      }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0u;
+}
+
+// Sum of part[lo .. hi) by the whole workgroup: fixed assignment of elements to threads, fixed tree -- the same bits
+// whatever order the workgroups arrived in.  Result in every thread.
+__device__ __forceinline__ float fold_range(const float* __restrict__ part, unsigned lo, unsigned hi) {
+  __shared__ float red[4];
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x;
+  float a = 0.f;
+  for (unsigned i = lo + tid; i < hi; i += 256) a += part[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = a;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// l1_loss: mean |x*m - y*m|.  Items = (batch b, pixel p) with C values each: mask index b*hw + p (C = 1, hw = n for
+// "no mask" / "mask of x's shape").
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) l1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ mask, int64_t items, int64_t hw, int C,
+                                                     float inv_n, float* __restrict__ out, float* __restrict__ ws) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const float m = mask ? mask[i] : 1.f;
+    for (int c = 0; c < C; c++) {
+      const int64_t e = (b * C + c) * hw + p;
+      acc += mask ? fabsf(x[e] * m - y[e] * m) : fabsf(x[e] - y[e]);
+    }
+  }
+  float v[1] = {acc};
+  if (arrive_last<1>(v, ws, gridDim.x, blockIdx.x)) {
+    const float tot = fold_range(ws + WS_HEADER, 0, gridDim.x);
+    if (threadIdx.x == 0) out[0] = tot * inv_n;
+  }
+}
+
+__global__ void __launch_bounds__(256) l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ mask, int64_t items, int64_t hw, int C,
+                                                     float inv_n, const float* __restrict__ g_out, float* __restrict__ gx,
+                                                     float* __restrict__ gy, float* __restrict__ gm) {
+  const float g = g_out[0] * inv_n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const float m = mask ? mask[i] : 1.f;
+    float dm = 0.f;
+    for (int c = 0; c < C; c++) {
+      const int64_t e = (b * C + c) * hw + p;
+      const float xv = x[e], yv = y[e];
+      const float s = sgn(mask ? (xv * m - yv * m) : (xv - yv)) * g;
+      if (gx) gx[e] = s * m;
+      if (gy) gy[e] = -s * m;
+      dm += s * xv - s * yv;        // d|x m - y m| / dm = sign * (x - y), term by term like autograd's two products
+    }
+    if (gm) gm[i] = dm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// inverse_warp_images: out[b,ch,r,c] = (x1 - d) img[b,ch,r,c+x0] + (d - x0) img[b,ch,r,c+x1], x0 = floor(d), x1 = x0 + 1,
+// zero where either tap leaves the row.
+// ------------------------------------------------------------------------------------------------------------------
+struct Tap { int c0; float w0, w1; bool ok; };
+__device__ __forceinline__ Tap warp_tap(float d, int c, int W) {
+  Tap t;
+  t.ok = false; t.c0 = 0; t.w0 = 0.f; t.w1 = 0.f;
+  if (!(fabsf(d) < 1.0e6f)) return t;          // (inf / NaN disparity: the reference's cast to int64 is undefined there)
+  const float x0 = floorf(d), x1 = x0 + 1.0f;
+  const int c0 = c + (int)x0, c1 = c0 + 1;
+  if (c0 < 0 || c0 >= W || c1 < 0 || c1 >= W) return t;
+  t.ok = true; t.c0 = c0; t.w0 = x1 - d; t.w1 = d - x0;
+  return t;
+}
+
+__global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__ img, const float* __restrict__ disp, int B, int C,
+                                                       int H, int W, float* __restrict__ out, float* __restrict__ zero_me) {
+  const int64_t hw = (int64_t)H * W, items = (int64_t)B * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const int c = (int)(p % W);
+    const int64_t row = p - c;
+    const Tap t = warp_tap(disp[i], c, W);
+    for (int ch = 0; ch < C; ch++) {
+      const int64_t base = (b * C + ch) * hw;
+      float v = 0.f;
+      if (t.ok) v = t.w0 * img[base + row + t.c0] + t.w1 * img[base + row + t.c0 + 1];
+      out[base + p] = v;
+      if (zero_me) zero_me[base + p] = 0.f;     // the gradient buffer the backward scatters into
+    }
+  }
+}
+
+// g_img (may be NULL) must be zero on entry: bilinear scatter with atomics; g_disp (may be NULL) is overwritten
+__global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__ img, const float* __restrict__ disp,
+                                                       const float* __restrict__ g_out, int B, int C, int H, int W,
+                                                       float* __restrict__ g_img, float* __restrict__ g_disp) {
+  const int64_t hw = (int64_t)H * W, items = (int64_t)B * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const int c = (int)(p % W);
+    const int64_t row = p - c;
+    const Tap t = warp_tap(disp[i], c, W);
+    float gd = 0.f;
+    if (t.ok) {
+      for (int ch = 0; ch < C; ch++) {
+        const int64_t base = (b * C + ch) * hw;
+        const float g = g_out[base + p];
+        if (g_img && g != 0.f) {
+          atomicAdd(&g_img[base + row + t.c0], t.w0 * g);
+          atomicAdd(&g_img[base + row + t.c0 + 1], t.w1 * g);
+        }
+        if (g_disp) gd += g * (img[base + row + t.c0 + 1] - img[base + row + t.c0]);
+      }
+    }
+    if (g_disp) g_disp[i] = gd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SmoothLoss.forward(disparity [B,1,H,W], image [B,C,H,W]):
+//   mean_{interior} |exp(-0.33 |sum_c dx(image_c)|) dx(disparity)| + the same along y;   dx(t) = 0.5 (t[c+1] - t[c-1])
+// (the reference's fixed 3x3 convolutions without padding: the result lives on rows 1..H-2, columns 1..W-2).
+// ------------------------------------------------------------------------------------------------------------------
+struct Edge { float ex, v; float a; };   // weight, weighted derivative, the image derivative the weight was formed from
+template <bool ALONG_X>
+__device__ __forceinline__ Edge edge_at(const float* __restrict__ img, const float* __restrict__ disp, int C, int H, int W,
+                                        int64_t b, int r, int c) {
+  Edge e;
+  e.ex = 0.f; e.v = 0.f; e.a = 0.f;
+  if (r < 1 || r > H - 2 || c < 1 || c > W - 2) return e;
+  const int64_t hw = (int64_t)H * W;
+  const int64_t step = ALONG_X ? 1 : W;
+  const int64_t q = (int64_t)r * W + c;
+  float a = 0.f;
+  for (int ch = 0; ch < C; ch++) {
+    const float* im = img + (b * C + ch) * hw;
+    a += 0.5f * im[q + step] - 0.5f * im[q - step];
+  }
+  const float* dp = disp + b * hw;
+  e.a = a;
+  e.ex = expf(fabsf(a) * -0.33f);
+  e.v = e.ex * (0.5f * dp[q + step] - 0.5f * dp[q - step]);
+  return e;
+}
+
+__global__ void __launch_bounds__(256) smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ img, int B,
+                                                         int C, int H, int W, float inv_cnt, float* __restrict__ out,
+                                                         float* __restrict__ ws) {
+  const int64_t hw = (int64_t)H * W, items = (int64_t)B * hw;
+  float sx = 0.f, sy = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+    sx += fabsf(edge_at<true>(img, disp, C, H, W, b, r, c).v);
+    sy += fabsf(edge_at<false>(img, disp, C, H, W, b, r, c).v);
+  }
+  float v[2] = {sx, sy};
+  if (arrive_last<2>(v, ws, gridDim.x, blockIdx.x)) {
+    const float tx_ = fold_range(ws + WS_HEADER, 0, gridDim.x);
+    const float ty_ = fold_range(ws + WS_HEADER, gridDim.x, 2 * gridDim.x);
+    if (threadIdx.x == 0) out[0] = tx_ * inv_cnt + ty_ * inv_cnt;
+  }
+}
+
+__global__ void __launch_bounds__(256) smooth_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ img, int B,
+                                                         int C, int H, int W, float inv_cnt, const float* __restrict__ g_out,
+                                                         float* __restrict__ g_disp, float* __restrict__ g_img) {
+  const int64_t hw = (int64_t)H * W, items = (int64_t)B * hw;
+  const float g = g_out[0] * inv_cnt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < items; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, p = i - b * hw;
+    const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+    // value [r][c] is the +0.5 tap of location (r, c-1) and the -0.5 tap of (r, c+1); rows likewise
+    const Edge xl = edge_at<true>(img, disp, C, H, W, b, r, c - 1), xr = edge_at<true>(img, disp, C, H, W, b, r, c + 1);
+    const Edge yu = edge_at<false>(img, disp, C, H, W, b, r - 1, c), yd = edge_at<false>(img, disp, C, H, W, b, r + 1, c);
+    if (g_disp) {
+      // d|ex dD| / d(dD) = sign(v) ex
+      g_disp[i] = g * (0.5f * (sgn(xl.v) * xl.ex) - 0.5f * (sgn(xr.v) * xr.ex) + 0.5f * (sgn(yu.v) * yu.ex) -
+                       0.5f * (sgn(yd.v) * yd.ex));
+    }
+    if (g_img) {
+      // d|v| / da = |v| * (-0.33 sign(a))  (v = exp(-0.33 |a|) dD): the same for every channel of the image
+      const float h = 0.5f * (-0.33f * sgn(xl.a) * fabsf(xl.v)) - 0.5f * (-0.33f * sgn(xr.a) * fabsf(xr.v)) +
+                      0.5f * (-0.33f * sgn(yu.a) * fabsf(yu.v)) - 0.5f * (-0.33f * sgn(yd.a) * fabsf(yd.v));
+      for (int ch = 0; ch < C; ch++) g_img[(b * C + ch) * hw + p] = g * h;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ssim(img1, img2): the passes of loss.hip (separable 11-tap window through LDS, 32x32 outputs per workgroup) for
+// `planes` = B*C independent images.  maps (may be NULL: value only): [5][planes][H][W] =
+//   dS/dmu1, dS/dE[x^2], dS/dE[xy], dS/dmu2, dS/dE[y^2]   (the last two only when want_y)
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 6) ssim_fn_stats_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                                                               int planes, int H, int W, float* __restrict__ maps, int want_y,
+                                                               int groups, float inv_cnt, float* __restrict__ out,
+                                                               float* __restrict__ ws, Win win) {
+  __shared__ float sin[2][SW][SW + 1];
+  __shared__ float hq[2][SW][ST + 1];
+  const int plane = blockIdx.z;
+  const size_t hw = (size_t)H * W;
+  const float* __restrict__ x = img1 + plane * hw;
+  const float* __restrict__ y = img2 + plane * hw;
+  const int tid = threadIdx.y * LT + threadIdx.x;
+  const int r0 = blockIdx.y * ST - LR, c0 = blockIdx.x * ST - LR;
+  for (int i = tid; i < SW * SW; i += 256) {
+    const int r = i / SW, c = i - r * SW, gr = r0 + r, gc = c0 + c;
+    const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
+    sin[0][r][c] = in ? x[(size_t)gr * W + gc] : 0.f;
+    sin[1][r][c] = in ? y[(size_t)gr * W + gc] : 0.f;
+  }
+  __syncthreads();
+  const int tx = tid & 31, tg = tid >> 5;
+  float res[5][4];
+#pragma unroll
+  for (int grp = 0; grp < 3; grp++) {   // (mu1, mu2) | (E[x^2], E[y^2]) | (E[xy]) -- same taps, same order as loss.hip
+    for (int it = tid; it < SW * (ST / 4); it += 256) {
+      const int r = it / (ST / 4), cc = (it % (ST / 4)) * 4;
+      float xv[14], yv[14];
+#pragma unroll
+      for (int j = 0; j < 14; j++) { xv[j] = sin[0][r][cc + j]; yv[j] = sin[1][r][cc + j]; }
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const float wk = win.w[k], xx = xv[o + k], yy = yv[o + k];
+          if (grp == 0) { a0 = fmaf(wk, xx, a0); a1 = fmaf(wk, yy, a1); }
+          else if (grp == 1) { a0 = fmaf(wk, xx * xx, a0); a1 = fmaf(wk, yy * yy, a1); }
+          else { a0 = fmaf(wk, xx * yy, a0); }
+        }
+        hq[0][r][cc + o] = a0;
+        if (grp < 2) hq[1][r][cc + o] = a1;
+      }
+    }
+    __syncthreads();
+    if (grp < 2) {
+      float two[2][4];
+      vpass4<2>(hq, win, tx, tg, two);
+#pragma unroll
+      for (int o = 0; o < 4; o++) { res[2 * grp][o] = two[0][o]; res[2 * grp + 1][o] = two[1][o]; }
+    } else {
+      float one[1][4];
+      vpass4<1>(hq, win, tx, tg, one);
+#pragma unroll
+      for (int o = 0; o < 4; o++) res[4][o] = one[0][o];
+    }
+    __syncthreads();
+  }
+  float ss = 0.f;
+  const int gc = blockIdx.x * ST + tx;
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int gr = blockIdx.y * ST + 4 * tg + o;
+    if (gr < H && gc < W) {
+      const float mu1 = res[0][o], mu2 = res[1][o], e11 = res[2][o], e22 = res[3][o], e12 = res[4][o];
+      const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+      const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+      const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+      const float inv = 1.0f / (B1 * B2);
+      const float S = A1 * A2 * inv;
+      ss += S;
+      if (maps) {
+        const size_t p = (size_t)gr * W + gc, ph = (size_t)planes * hw;
+        maps[0 * ph + plane * hw + p] = 2.f * mu2 * (A2 - A1) * inv - S * (2.f * mu1 / B1 - 2.f * mu1 / B2);
+        maps[1 * ph + plane * hw + p] = -S / B2;
+        maps[2 * ph + plane * hw + p] = 2.f * A1 * inv;
+        if (want_y) {
+          maps[3 * ph + plane * hw + p] = 2.f * mu1 * (A2 - A1) * inv - S * (2.f * mu2 / B1 - 2.f * mu2 / B2);
+          maps[4 * ph + plane * hw + p] = -S / B2;
+        }
+      }
+    }
+  }
+  // `groups` results: 1 (size_average) or one per batch element -- the workgroups of a plane, and the planes of a batch
+  // element, are consecutive in the partial-sum array
+  float v[1] = {ss};
+  const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned me = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (arrive_last<1>(v, ws, nb, me)) {
+    const unsigned per = nb / (unsigned)groups;
+    for (int gI = 0; gI < groups; gI++) {
+      const float tot = fold_range(ws + WS_HEADER, gI * per, (gI + 1) * per);
+      if (tid == 0) out[gI] = tot * inv_cnt;
+    }
+  }
+}
+
+// d(mean SSIM)/d(img): coef * (w * dS/dmu + 2 self (w * dS/dE[self^2]) + other (w * dS/dE[xy])), three maps through one
+// LDS tile (as loss.hip::ssim_grad_kernel).  which = 0: gradient of img1 (maps 0, 1, 2); 1: of img2 (maps 3, 4, 2).
+// g_out: [1] (size_average) or one value per batch element (planes_per_group planes each).
+__global__ void __launch_bounds__(256) ssim_fn_grad_kernel(const float* __restrict__ self_img, const float* __restrict__ other_img,
+                                                           const float* __restrict__ maps, int planes, int H, int W, int which,
+                                                           int planes_per_group, float inv_cnt, const float* __restrict__ g_out,
+                                                           float* __restrict__ grad, Win win) {
+  __shared__ float sm[1][SW][SW + 1];
+  __shared__ float hq[1][SW][ST + 1];
+  const int plane = blockIdx.z;
+  const size_t hw = (size_t)H * W, ph = (size_t)planes * hw;
+  const int tid = threadIdx.y * LT + threadIdx.x;
+  const int r0 = blockIdx.y * ST - LR, c0 = blockIdx.x * ST - LR;
+  const int tx = tid & 31, tg = tid >> 5;
+  const int sel[3] = {which ? 3 : 0, which ? 4 : 1, 2};
+  float res[3][4];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const float* __restrict__ mp = maps + sel[m] * ph + plane * hw;
+    for (int i = tid; i < SW * SW; i += 256) {
+      const int r = i / SW, c = i - r * SW, gr = r0 + r, gc = c0 + c;
+      const bool in = gr >= 0 && gr < H && gc >= 0 && gc < W;
+      sm[0][r][c] = in ? mp[(size_t)gr * W + gc] : 0.f;
+    }
+    __syncthreads();
+    hpass4<1>(sm, hq, win, tid);
+    __syncthreads();
+    float one[1][4];
+    vpass4<1>(hq, win, tx, tg, one);
+#pragma unroll
+    for (int o = 0; o < 4; o++) res[m][o] = one[0][o];
+    __syncthreads();
+  }
+  const float coef = g_out[plane / planes_per_group] * inv_cnt;
+  const int gc = blockIdx.x * ST + tx;
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int gr = blockIdx.y * ST + 4 * tg + o;
+    if (gr < H && gc < W) {
+      const size_t p = plane * hw + (size_t)gr * W + gc;
+      grad[p] = coef * (res[0][o] + 2.f * self_img[p] * res[1][o] + other_img[p] * res[2][o]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The per-iteration model statements of train.py:171-179 (scene/gaussian_model.py:307-309, :409-411)
+// ------------------------------------------------------------------------------------------------------------------
+// o <- logit(sigmoid(o) * factor), the operations of `inverse_sigmoid(get_opacity * factor)` one by one
+__global__ void __launch_bounds__(256) opacity_decay_kernel(float* __restrict__ o, int64_t n, float factor) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = (1.0f / (1.0f + expf(-o[i]))) * factor;
+    o[i] = logf(s / (1.0f - s));
+  }
+}
+
+// xyz_gradient_accum[f] += ||grad[f, :2]||, denom[f] += 1 for the rows the filter selects (filter: one byte per row)
+__global__ void __launch_bounds__(256) densify_stats_kernel(const float* __restrict__ grad, int64_t stride,
+                                                            const uint8_t* __restrict__ filter, int64_t P,
+                                                            float* __restrict__ accum, float* __restrict__ denom) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    if (!filter[i]) continue;
+    const float gx = grad[i * stride], gy = grad[i * stride + 1];
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+  }
+}
+
+inline unsigned grid_for(int64_t items, unsigned cap = 1024u) {
+  const int64_t b = (items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > (int64_t)cap ? cap : b));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// C ABI (include/b3gs_raster.h, "ABI 9")
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" size_t b3gs_lossfn_workspace_floats(int64_t planes, int32_t H, int32_t W) {
+  const int64_t tiles = (int64_t)((W > 0 ? W : 0) + ST - 1) / ST * (((H > 0 ? H : 0) + ST - 1) / ST);
+  const int64_t nb = (planes > 0 ? planes : 0) * tiles;
+  return (size_t)WS_HEADER + (size_t)(nb > 2048 ? nb : 2048);
+}
+
+extern "C" int b3gs_l1_loss_forward(const float* x, const float* y, const float* mask, int64_t batch, int32_t channels,
+                                    int64_t hw, float* out, float* workspace, b3gs_stream_t stream) {
+  if (!x || !y || !out || !workspace || batch <= 0 || channels <= 0 || hw <= 0)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_l1_loss_forward", "NULL pointer or empty shape");
+  const int64_t items = batch * hw;
+  const float inv_n = 1.0f / (float)((double)items * channels);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(grid_for(items, 512u)), dim3(256), 0, (hipStream_t)stream, x, y, mask, items, hw, channels, inv_n,
+                     out, workspace);
+  return b3gs_launch_status("b3gs_l1_loss_forward");
+}
+
+extern "C" int b3gs_l1_loss_backward(const float* x, const float* y, const float* mask, int64_t batch, int32_t channels,
+                                     int64_t hw, const float* grad_out, float* grad_x, float* grad_y, float* grad_mask,
+                                     b3gs_stream_t stream) {
+  if (!x || !y || !grad_out || batch <= 0 || channels <= 0 || hw <= 0 || (grad_mask && !mask))
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_l1_loss_backward", "NULL pointer, empty shape, or a mask gradient without a mask");
+  const int64_t items = batch * hw;
+  const float inv_n = 1.0f / (float)((double)items * channels);
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(items, 8192u)), dim3(256), 0, (hipStream_t)stream, x, y, mask, items, hw,
+                     channels, inv_n, grad_out, grad_x, grad_y, grad_mask);
+  return b3gs_launch_status("b3gs_l1_loss_backward");
+}
+
+extern "C" int b3gs_inverse_warp_forward(const float* image, const float* disparity, int32_t B, int32_t C, int32_t H, int32_t W,
+                                         float* out, float* zero_fill, b3gs_stream_t stream) {
+  if (!image || !disparity || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_inverse_warp_forward", "NULL pointer or empty shape");
+  hipLaunchKernelGGL(warp_fwd_kernel, dim3(grid_for((int64_t)B * H * W, 8192u)), dim3(256), 0, (hipStream_t)stream, image, disparity,
+                     B, C, H, W, out, zero_fill);
+  return b3gs_launch_status("b3gs_inverse_warp_forward");
+}
+
+extern "C" int b3gs_inverse_warp_backward(const float* image, const float* disparity, const float* grad_out, int32_t B, int32_t C,
+                                          int32_t H, int32_t W, float* grad_image, float* grad_disparity, b3gs_stream_t stream) {
+  if (!image || !disparity || !grad_out || B <= 0 || C <= 0 || H <= 0 || W <= 0)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_inverse_warp_backward", "NULL pointer or empty shape");
+  hipLaunchKernelGGL(warp_bwd_kernel, dim3(grid_for((int64_t)B * H * W, 8192u)), dim3(256), 0, (hipStream_t)stream, image, disparity,
+                     grad_out, B, C, H, W, grad_image, grad_disparity);
+  return b3gs_launch_status("b3gs_inverse_warp_backward");
+}
+
+extern "C" int b3gs_smooth_loss_forward(const float* disparity, const float* image, int32_t B, int32_t C, int32_t H, int32_t W,
+                                        float* out, float* workspace, b3gs_stream_t stream) {
+  if (!disparity || !image || !out || !workspace || B <= 0 || C <= 0 || H < 3 || W < 3)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_smooth_loss_forward", "NULL pointer or an image smaller than the 3x3 stencil");
+  const float inv_cnt = 1.0f / (float)((double)B * (H - 2) * (W - 2));
+  hipLaunchKernelGGL(smooth_fwd_kernel, dim3(grid_for((int64_t)B * H * W, 1024u)), dim3(256), 0, (hipStream_t)stream, disparity, image, B, C,
+                     H, W, inv_cnt, out, workspace);
+  return b3gs_launch_status("b3gs_smooth_loss_forward");
+}
+
+extern "C" int b3gs_smooth_loss_backward(const float* disparity, const float* image, int32_t B, int32_t C, int32_t H, int32_t W,
+                                         const float* grad_out, float* grad_disparity, float* grad_image, b3gs_stream_t stream) {
+  if (!disparity || !image || !grad_out || B <= 0 || C <= 0 || H < 3 || W < 3)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_smooth_loss_backward", "NULL pointer or an image smaller than the 3x3 stencil");
+  const float inv_cnt = 1.0f / (float)((double)B * (H - 2) * (W - 2));
+  hipLaunchKernelGGL(smooth_bwd_kernel, dim3(grid_for((int64_t)B * H * W, 8192u)), dim3(256), 0, (hipStream_t)stream, disparity, image,
+                     B, C, H, W, inv_cnt, grad_out, grad_disparity, grad_image);
+  return b3gs_launch_status("b3gs_smooth_loss_backward");
+}
+
+extern "C" int b3gs_ssim_forward(const float* img1, const float* img2, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                                 int32_t size_average, float* maps, int32_t maps_for_img2, float* out, float* workspace,
+                                 b3gs_stream_t stream) {
+  if (!img1 || !img2 || !out || !workspace || batch <= 0 || channels <= 0 || H <= 0 || W <= 0)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_ssim_forward", "NULL pointer or empty shape");
+  const int planes = batch * channels;
+  if (planes > 65535) return b3gs_fail(B3GS_ERR_ARG, "b3gs_ssim_forward", "more than 65535 image planes in one call");
+  const int groups = size_average ? 1 : batch;
+  const float inv_cnt = 1.0f / (float)((double)(planes / groups) * H * W);
+  const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  hipLaunchKernelGGL(ssim_fn_stats_kernel, grid, dim3(LT, LT), 0, (hipStream_t)stream, img1, img2, planes, H, W, maps,
+                     maps_for_img2 ? 1 : 0, groups, inv_cnt, out, workspace, make_window());
+  return b3gs_launch_status("b3gs_ssim_forward");
+}
+
+extern "C" int b3gs_ssim_backward(const float* img1, const float* img2, const float* maps, int32_t batch, int32_t channels,
+                                  int32_t H, int32_t W, int32_t size_average, const float* grad_out, float* grad_img1,
+                                  float* grad_img2, b3gs_stream_t stream) {
+  if (!img1 || !img2 || !maps || !grad_out || batch <= 0 || channels <= 0 || H <= 0 || W <= 0)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_ssim_backward", "NULL pointer or empty shape");
+  const int planes = batch * channels;
+  if (planes > 65535) return b3gs_fail(B3GS_ERR_ARG, "b3gs_ssim_backward", "more than 65535 image planes in one call");
+  const int groups = size_average ? 1 : batch;
+  const float inv_cnt = 1.0f / (float)((double)(planes / groups) * H * W);
+  const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+  const Win win = make_window();
+  if (grad_img1)
+    hipLaunchKernelGGL(ssim_fn_grad_kernel, grid, dim3(LT, LT), 0, (hipStream_t)stream, img1, img2, maps, planes, H, W, 0,
+                       planes / groups, inv_cnt, grad_out, grad_img1, win);
+  if (grad_img2)
+    hipLaunchKernelGGL(ssim_fn_grad_kernel, grid, dim3(LT, LT), 0, (hipStream_t)stream, img2, img1, maps, planes, H, W, 1,
+                       planes / groups, inv_cnt, grad_out, grad_img2, win);
+  return b3gs_launch_status("b3gs_ssim_backward");
+}
+
+extern "C" int b3gs_opacity_decay(float* opacity, int64_t count, float factor, b3gs_stream_t stream) {
+  if (count < 0 || (count > 0 && !opacity)) return b3gs_fail(B3GS_ERR_ARG, "b3gs_opacity_decay", "NULL pointer or negative count");
+  if (count == 0) return B3GS_OK;
+  hipLaunchKernelGGL(opacity_decay_kernel, dim3(grid_for(count, 8192u)), dim3(256), 0, (hipStream_t)stream, opacity, count, factor);
+  return b3gs_launch_status("b3gs_opacity_decay");
+}
+
+extern "C" int b3gs_add_densification_stats(int64_t P, const float* viewspace_grad, int64_t row_stride, const uint8_t* update_filter,
+                                            float* xyz_gradient_accum, float* denom, b3gs_stream_t stream) {
+  if (P < 0 || (P > 0 && (!viewspace_grad || !update_filter || !xyz_gradient_accum || !denom)) || row_stride < 2)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_add_densification_stats", "NULL pointer, negative count or a row stride below 2");
+  if (P == 0) return B3GS_OK;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3(grid_for(P, 8192u)), dim3(256), 0, (hipStream_t)stream, viewspace_grad, row_stride,
+                     update_filter, P, xyz_gradient_accum, denom);
+  return b3gs_launch_status("b3gs_add_densification_stats");
+}

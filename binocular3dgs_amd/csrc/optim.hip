@@ -45,10 +45,11 @@ template <int VEC>
 __global__ void __launch_bounds__(256)
     adam_kernel(AdamSegs segs, int32_t* __restrict__ step_ptr, int bump, float beta1, float beta2, float eps,
                 float opacity_decay, int opacity_seg, int decay_first, const unsigned long long* __restrict__ row_mask,
-                const int32_t* __restrict__ skip_if_nonzero) {
+                const int32_t* __restrict__ skip_if_nonzero, int host_step) {
   // a step rendered from truncated tile lists (B3gsForwardView::overflow_flag) is dropped here, on the device
   if (skip_if_nonzero && *skip_if_nonzero != 0) return;
-  const float t = (float)(*step_ptr + 1);
+  // host_step > 0 (b3gs_adam_step_at): the caller counts the steps itself, like torch.optim.Adam's state["step"]
+  const float t = host_step > 0 ? (float)host_step : (float)(*step_ptr + 1);
   const float bc1 = 1.0f - powf(beta1, t);
   const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
   const uint32_t total = segs.start[segs.n] / VEC;
@@ -181,9 +182,47 @@ extern "C" int b3gs_adam_step(int32_t nseg, const B3gsAdamSegment* segs, int32_t
   const unsigned long long* mask = reinterpret_cast<const unsigned long long*>(row_mask);
   if (vec4)
     hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
-                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero);
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero, 0);
   else
     hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, a, device_step, bump_step_after ? 1 : 0, beta1, beta2,
-                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero);
+                       eps, opacity_decay, opacity_segment, opacity_decay_first, mask, skip_if_nonzero, 0);
   return b3gs_launch_status("b3gs_adam_step");
+}
+
+// The same update with the step number given by the HOST (1-based: the value torch.optim.Adam's state["step"] holds AFTER
+// its increment): the optimiser behind `gaussians.optimizer.step()` of an unchanged train.py:196-198 keeps torch's
+// per-parameter state layout (step / exp_avg / exp_avg_sq), so the count lives where torch keeps it.
+extern "C" int b3gs_adam_step_at(int32_t nseg, const B3gsAdamSegment* segs, int32_t step, float beta1, float beta2,
+                                 float eps, b3gs_stream_t stream) {
+  if (nseg < 0 || nseg > 8 || (nseg > 0 && !segs) || step < 1)
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_adam_step_at", "0..8 segments and a step number >= 1 are required");
+  AdamSegs a;
+  a.n = nseg;
+  uint64_t tot = 0;
+  bool vec4 = true;
+  for (int k = 0; k < nseg; k++) {
+    if (segs[k].count < 0 ||
+        (segs[k].count > 0 && (!segs[k].param || !segs[k].grad || !segs[k].exp_avg || !segs[k].exp_avg_sq)))
+      return b3gs_fail(B3GS_ERR_ARG, "b3gs_adam_step_at", "negative count or NULL pointer in a non-empty segment");
+    a.s[k] = segs[k];
+    a.start[k] = (uint32_t)tot;
+    tot += (uint64_t)segs[k].count;
+    const uintptr_t bits = (uintptr_t)segs[k].param | (uintptr_t)segs[k].grad | (uintptr_t)segs[k].exp_avg |
+                           (uintptr_t)segs[k].exp_avg_sq;
+    if (segs[k].count > 0 && ((bits & 15u) || (segs[k].count & 3))) vec4 = false;
+  }
+  if (tot > 0xFFFFFFFFull) return b3gs_fail(B3GS_ERR_ARG, "b3gs_adam_step_at", "more than 2^32 parameter floats in one call");
+  a.start[nseg] = (uint32_t)tot;
+  for (int k = nseg + 1; k < 9; k++) a.start[k] = (uint32_t)tot;
+  if (tot == 0) return B3GS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const uint64_t items = vec4 ? tot / 4 : tot;
+  const unsigned blocks = (unsigned)((items + 255) / 256 < 256u * 32u ? (items + 255) / 256 : 256u * 32u);
+  if (vec4)
+    hipLaunchKernelGGL(adam_kernel<4>, dim3(blocks), dim3(256), 0, s, a, (int32_t*)nullptr, 0, beta1, beta2, eps, 0.0f, -1, 0,
+                       (const unsigned long long*)nullptr, (const int32_t*)nullptr, step);
+  else
+    hipLaunchKernelGGL(adam_kernel<1>, dim3(blocks), dim3(256), 0, s, a, (int32_t*)nullptr, 0, beta1, beta2, eps, 0.0f, -1, 0,
+                       (const unsigned long long*)nullptr, (const int32_t*)nullptr, step);
+  return b3gs_launch_status("b3gs_adam_step_at");
 }

@@ -209,7 +209,8 @@ class FusedRasterizer:
             # streams of their own -- the ~25 launches of a forward are a serial chain of mostly latency-bound kernels, two
             # independent chains interleave in each other's ramp-up / drain gaps.  Pairs stay together (shared depth sort).
             if self.schedule == "groups" and len(specs) > 2:
-                per = max(2, 2 * (-(-len(specs) // (2 * getattr(self, "groups", 2)))))
+                # (never more views per launch than the library takes: more than 16 views in two groups are cut further)
+                per = min(MAX_BATCH - MAX_BATCH % 2, max(2, 2 * (-(-len(specs) // (2 * getattr(self, "groups", 2))))))
                 bounds = list(range(0, len(specs), per))
             else:
                 per, bounds = MAX_BATCH, list(range(0, len(specs), MAX_BATCH))

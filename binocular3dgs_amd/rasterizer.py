@@ -19,6 +19,7 @@ import ctypes as C
 import atexit
 import contextlib
 import os
+import threading
 import weakref
 from typing import NamedTuple, Optional
 
@@ -26,6 +27,7 @@ import torch
 from torch import nn
 
 from . import _lib
+from ._cuda import device_guard, raw_stream
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -58,8 +60,7 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
-def _stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+_stream = raw_stream
 
 
 def _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
@@ -204,7 +205,8 @@ class _LazyN:
         self.slot = (self.slot + 1) % self.RING
         host.copy_(n_dev, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(n_dev.device))
+        with device_guard(n_dev.device):
+            ev.record()                                   # (the current stream: where the copy was just enqueued)
         tok = [key, cap, host, ev, False]
         self.pending.append(tok)
         return tok
@@ -223,7 +225,8 @@ class _LazyN:
         self.slot4 += n
         host.copy_(rows, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(rows.device))
+        with device_guard(rows.device):
+            ev.record()
         toks = [[keys[k], caps[k], host[k, :2], ev, False] for k in range(n)]
         self.pending.extend(toks)
         return toks
@@ -282,7 +285,7 @@ class _CModule:
                 binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
                 img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
                 n_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-                with torch.cuda.device(dev):
+                with device_guard(dev):
                     rc = L.b3gs_forward_capacity(C.byref(sc), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
                                                  color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii),
                                                  n_dev.data_ptr(), _stream(dev))
@@ -301,7 +304,7 @@ class _CModule:
 
         cbs = [mk("geom"), mk("binning"), mk("img")]
         n = C.c_int32(0)
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             rc = L.b3gs_forward(C.byref(sc), cbs[0], None, cbs[1], None, cbs[2], None, color.data_ptr(),
                                 depth.data_ptr(), alpha.data_ptr(), _ptr(radii), C.byref(n), _stream(dev))
         _lib.check(rc, "b3gs_forward")
@@ -351,7 +354,7 @@ class _CModule:
         dL_dscales = torch.empty((P, 3) if has_sr else (0, 3), **f)
         dL_drot = torch.empty((P, 4) if has_sr else (0, 4), **f)
         radii_i = radii.to(torch.int32).contiguous()
-        with torch.cuda.device(dev):
+        with device_guard(dev):
             rc = L.b3gs_backward(C.byref(sc), int(R), _ptr(radii_i), _ptr(geomBuffer), _ptr(binningBuffer),
                                  _ptr(imageBuffer), _ptr(dC), _ptr(dD), _ptr(dA), _ptr(dL_dmeans2D),
                                  _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
@@ -445,24 +448,114 @@ class _RasterizeGaussians(torch.autograd.Function):
 # the backward of several renders); B3GS_DROPIN_ORDER_HINT=0: every render sorts its own depth keys
 _INPLACE_GRADS = os.environ.get("B3GS_DROPIN_INPLACE_GRADS", "1") != "0"
 _ORDER_HINT = os.environ.get("B3GS_DROPIN_ORDER_HINT", "1") != "0"
-_raw_scratch = {}     # (device index, P) -> list of zeroed [P * 10] float buffers, one per view of a batched backward; left
-                      #                      clean by every backward (b3gs_backward_raw_accumulate)
-_zero_m2d = {}        # (device index, P) -> zeros [P, 3]: storage behind every render's `viewspace_points` leaf
-_order_hint = {}      # device index -> the last raw forward: dict(P, key_bits, geom, xyz_ptr, xyz_version)
-_last_raw_ctx = {}    # device index -> weakref of the last DIFFERENTIATED raw forward's node (+ what it rendered)
-_stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0, "lazy_batches": 0, "lazy_views": 0, "shared": 0}   # (tests / bench read these)
-
-
 # B3GS_DROPIN_LAZY=0: every render() launches its forward before it returns (see _LazyOut / _launch_forward)
 _LAZY_FWD = os.environ.get("B3GS_DROPIN_LAZY", "1") != "0"
 _LAZY_MAX = max(1, min(8, int(os.environ.get("B3GS_DROPIN_LAZY_MAX", "2"))))    # renders per batched forward (a pair)
-_pending_fwd = {}     # device index -> [_PendingFwd]: differentiated renders whose forward has not been launched yet
+# B3GS_DROPIN_LAZY_IDLE=1: a render waits for its partner even when the device has nothing queued (default: it only waits
+# while the stream is busy -- an idle device gains more from starting this view's forward now than from the shared launch)
+_LAZY_WHEN_IDLE = os.environ.get("B3GS_DROPIN_LAZY_IDLE", "0") == "1"
+
+
+class _DropinState:
+    """Everything the raw-parameter surface remembers between calls, in ONE object behind ONE re-entrant lock (round 4 kept
+    seven module-level dicts that the caller's thread and autograd's device thread both wrote).  The entry points that
+    touch it -- the forward and the backward of _RasterizeRaw, the flush of pending forwards (any thread that first
+    touches a pending output), the final callback of a backward() -- hold the lock for their whole body, so renders issued
+    from several Python threads (their own models, their own streams) interleave as whole calls.  Per-backward state is
+    keyed by the engine's graph-task id: concurrent or nested backward() calls keep separate entries."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.raw_scratch = {}     # (device index, P) -> list of zeroed [P * 10] float buffers, one per view of a batched
+        #                           backward; left clean by every backward (b3gs_backward_raw_accumulate)
+        self.zero_m2d = {}        # (device index, P) -> zeros [P, 3]: storage behind every render's `viewspace_points` leaf
+        self.order_hint = {}      # device index -> the last raw forward: dict(P, key_bits, geom, xyz, words, zkey, stream)
+        self.last_raw_ctx = {}    # device index -> weakref of the last DIFFERENTIATED raw forward's node (+ what it rendered)
+        self.pending_fwd = {}     # device index -> [_PendingFwd]: differentiated renders whose forward is not launched yet
+        self.tasks = {}           # graph-task id -> _TaskState of a backward() in flight
+        self.word_ring = {}       # device index -> [zeroed int32 ring, next slot]
+        self.busy = {}            # (device index, stream) -> event behind the last forward / backward this module launched there
+        self.stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0, "lazy_batches": 0,
+                      "lazy_views": 0, "shared": 0, "eager_idle": 0}   # (tests / bench read these)
+
+
+_S = _DropinState()
+# (the names tests and tools have always used: the SAME dict objects)
+_raw_scratch, _zero_m2d, _order_hint, _last_raw_ctx = _S.raw_scratch, _S.zero_m2d, _S.order_hint, _S.last_raw_ctx
+_pending_fwd, _stats = _S.pending_fwd, _S.stats
+
+
+def _locked(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        with _S.lock:
+            return fn(*a, **k)
+    return wrapper
+
+
+# ---- private torch entry points, probed once -------------------------------------------------------------------------
+# The batched backward and the end-of-backward capacity check lean on three engine hooks that are not public API:
+#   torch._C._will_engine_execute_node(node)        "will this backward() run that node?"
+#   torch._C._current_graph_task_id()               identity of the backward() in flight
+#   Variable._execution_engine.queue_callback(fn)   "call fn as the last act of this backward()"
+# and the pending forward on torch._C.DisableTorchFunctionSubclass.  A torch build without one of them gets the plain
+# behaviour instead of an AttributeError in the middle of loss.backward(): every node launches its own backward and RETURNS
+# its gradients to autograd, the capacity check sits at the entry of the node, every render launches before it returns.
+def _probe_engine() -> bool:
+    try:
+        eng = torch.autograd.Variable._execution_engine
+        return (callable(torch._C._will_engine_execute_node) and callable(torch._C._current_graph_task_id)
+                and callable(eng.queue_callback))
+    except AttributeError:
+        return False
+
+
+def _probe_lazy() -> bool:
+    return hasattr(torch._C, "DisableTorchFunctionSubclass") and hasattr(torch.Tensor, "as_subclass")
+
+
+_ENGINE_HOOKS = _probe_engine()
+_LAZY_OK = _probe_lazy()
+
+
+def _refresh_probes():
+    """(tests: after monkeypatching the private entry points away)"""
+    global _ENGINE_HOOKS, _LAZY_OK
+    _ENGINE_HOOKS, _LAZY_OK = _probe_engine(), _probe_lazy()
+    return _ENGINE_HOOKS, _LAZY_OK
+
+
+def _mark_busy(di, stream_id):
+    """An event behind the work this module just queued on the CURRENT stream (id `stream_id`; see the wait decision in
+    _RasterizeRaw.forward)."""
+    key = (di, stream_id)
+    ev = _S.busy.get(key)
+    if ev is None:
+        if len(_S.busy) > 16:
+            _S.busy.clear()
+        ev = _S.busy[key] = torch.cuda.Event()
+    ev.record()
+
+
+def _stream_obj(p):
+    """The torch Stream of a pending forward / a parked backward job (built only when a launch crosses streams)."""
+    return torch.cuda.ExternalStream(p.stream_id, device=p.dev)
+
+
+def _current_task() -> int:
+    return torch._C._current_graph_task_id() if _ENGINE_HOOKS else -1
+
+
+def _will_execute(node) -> bool:
+    return bool(_ENGINE_HOOKS and torch._C._will_engine_execute_node(node))
 
 
 class _PendingFwd:
     """One render() whose forward is still to be launched: everything b3gs_forward_raw_batch needs, already allocated."""
     __slots__ = ("ctx", "sc", "geom", "binning", "img", "out", "radii", "words", "cap", "key", "hint", "trusted", "zkey",
-                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P", "ring", "row")
+                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P", "ring", "row", "handed")
 
 
 def _meta_funcs():
@@ -502,7 +595,14 @@ class _LazyOut(torch.Tensor):
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
+    def __reduce_ex__(self, proto):
+        # (pickling / torch.save of an output that is still pending: launch, then pickle as the plain tensor it is)
+        _flush_pending()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
 
+
+@_locked
 def _flush_pending(di=None):
     """Launch the pending forwards (of one device, or of all)."""
     for d in ([di] if di is not None else list(_pending_fwd)):
@@ -541,9 +641,9 @@ def _launch_forward(lst):
             fv[k].hint_trusted = int(p.trusted)
             _stats["hinted"] += 1
             _stats["trusted"] += int(p.trusted)
-    cur = torch.cuda.current_stream(p0.dev)
-    other = cur.cuda_stream != p0.stream_id
-    with torch.cuda.device(p0.dev), (torch.cuda.stream(p0.stream) if other else contextlib.nullcontext()):
+    other = raw_stream(p0.dev) != p0.stream_id
+    cur = torch.cuda.current_stream(p0.dev) if other else None
+    with device_guard(p0.dev), (torch.cuda.stream(_stream_obj(p0)) if other else contextlib.nullcontext()):
         _lib.check(L.b3gs_forward_raw_batch(n, fv, C.byref(p0.ctx.rp), 3, p0.stream_id), "b3gs_forward_raw_batch")
         try:
             if n > 1 and all(q.ring is p0.ring and q.row == p0.row + k for k, q in enumerate(lst)):
@@ -558,6 +658,22 @@ def _launch_forward(lst):
             raise
         for p, tok in zip(lst, toks):
             p.ctx.lazy_token = tok
+        _mark_busy(_dev_index(p0.dev), p0.stream_id)
+    if other:
+        # (whoever triggered the launch is about to read the outputs on ITS stream -- a consumer on a side stream
+        # that ordered itself behind render()'s stream before the first use saw an empty queue there)
+        cur.wait_stream(_stream_obj(p0))
+    # the outputs handed out as _LazyOut are plain tensors from here on: nothing is pending behind them any more, and a
+    # later torch.save() / deepcopy / subclass check sees torch.Tensor, not a private class of this module
+    for p in lst:
+        for ref in (p.handed or ()):
+            t = ref()
+            if t is not None:
+                try:
+                    t.__class__ = torch.Tensor
+                except TypeError:
+                    pass
+        p.handed = None
     _stats["lazy_batches"] += 1
     _stats["lazy_views"] += n
     if _ORDER_HINT:
@@ -582,7 +698,7 @@ def raw_model_ok(pc) -> bool:
         return False
 
 
-_word_ring = {}       # device index -> [zeroed int32 ring, next slot]
+_word_ring = _S.word_ring
 
 
 def _dev_index(dev) -> int:
@@ -597,6 +713,8 @@ def _zero_words(dev, with_row=False):
     ent = _word_ring.get(idx)
     if ent is None or ent[1] >= ent[0].shape[0]:
         ent = _word_ring[idx] = [torch.zeros((4096, 4), dtype=torch.int32, device=dev), 0]
+        # (slots are handed to launches on ANY stream: the fill must have run before the first of them -- once per 4096 renders)
+        torch.cuda.current_stream(dev).synchronize()
     w = ent[0][ent[1]]
     ent[1] += 1
     return (w, ent[0], ent[1] - 1) if with_row else w
@@ -646,11 +764,12 @@ def viewspace_leaf(xyz: torch.Tensor) -> torch.Tensor:
 
 class _RawJob:
     """One render's backward, ready to be launched: its node, what the node saved, its pixel gradients."""
-    __slots__ = ("ctx", "saved", "gc", "gd", "ga", "stream", "needs_m2d", "m2d_leaf", "task")
+    __slots__ = ("ctx", "saved", "gc", "gd", "ga", "dev", "stream_id", "needs_m2d", "m2d_leaf", "task")
 
     def __init__(self, ctx, gc, gd, ga, task):
         self.ctx, self.saved, self.gc, self.gd, self.ga, self.task = ctx, ctx.saved_tensors, gc, gd, ga, task
-        self.stream = torch.cuda.current_stream(gc.device)
+        self.dev = gc.device
+        self.stream_id = raw_stream(gc.device)
         self.needs_m2d = bool(ctx.needs_input_grad[6])
         self.m2d_leaf = ctx.m2d_leaf
 
@@ -661,7 +780,7 @@ def _leaf_accumulates(node, t) -> bool:
     if node is None or type(node).__name__ != "AccumulateGrad" or getattr(node, "variable", None) is not t:
         return False
     try:
-        if not torch._C._will_engine_execute_node(node):
+        if not _will_execute(node):
             return False
     except RuntimeError:      # "a leaf node was passed ... but we are currently running autograd.grad()"
         return False
@@ -678,27 +797,45 @@ def _self_accumulate_ok(ctx, params) -> bool:
     one batch)?  Only inside a plain accumulating backward(): every parameter a leaf whose AccumulateGrad the engine is
     going to execute in this graph task, no hooks, no create_graph.  torch.autograd.grad(), backward(inputs=[...]) without
     all six, hooked parameters, double backward: the gradients are RETURNED to autograd like the reference's."""
-    if not _INPLACE_GRADS or torch.is_grad_enabled() or not all(ctx.needs_input_grad[:6]):
+    if not (_INPLACE_GRADS and _ENGINE_HOOKS) or torch.is_grad_enabled() or not all(ctx.needs_input_grad[:6]):
         return False
     nf = ctx.next_functions
     # (the answer for the six parameters is the same for every node of this graph task that renders them: asked once)
-    task = torch._C._current_graph_task_id()
-    if _acc_cache.get("task") != task:
-        _acc_cache.clear()
-        _acc_cache["task"] = task
-    ok = _acc_cache.get(ctx.batch_key)
+    acc = _task_state().acc
+    ok = acc.get(ctx.batch_key)
     if ok is None:
-        ok = _acc_cache[ctx.batch_key] = all(_leaf_accumulates(nf[i][0], t) for i, t in enumerate(params))
+        ok = acc[ctx.batch_key] = all(_leaf_accumulates(nf[i][0], t) for i, t in enumerate(params))
     if not ok:
         return False
     return (not ctx.needs_input_grad[6]) or _leaf_accumulates(nf[6][0], ctx.m2d_leaf)
 
 
-_task_cb = {"task": None, "streams": [], "flush": [], "tokens": []}
-_acc_cache = {}
+class _TaskState:
+    """What one backward() (one graph task of the engine) has parked with this module."""
+    __slots__ = ("streams", "flush", "tokens", "acc", "created")
+
+    def __init__(self):
+        self.streams, self.flush, self.tokens = [], [], []
+        self.acc = {}          # batch_key -> may the nodes of these parameters accumulate into .grad themselves?
+        self.created = []      # tensors whose .grad THIS backward created (set back to None when the step is refused)
 
 
-def _end_of_backward():
+def _task_state() -> _TaskState:
+    """The entry of the backward() in flight (created on first use, together with its final callback)."""
+    task = _current_task()
+    st = _S.tasks.get(task)
+    if st is None:
+        if len(_S.tasks) >= 16:      # entries of backward() calls that raised inside a node (their final callback never ran)
+            for old in sorted(_S.tasks)[:len(_S.tasks) - 15]:
+                del _S.tasks[old]
+        st = _S.tasks[task] = _TaskState()
+        if _ENGINE_HOOKS:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _end_of_backward(task))
+    return st
+
+
+@_locked
+def _end_of_backward(task):
     """Final callback of the graph task (runs on the caller's ambient streams, after the engine has synchronised them with
     the streams of the leaves IT accumulated), i.e. the last thing `loss.backward()` does before it returns:
       * launch what is still deferred -- a node that was expected to run in this backward and did not;
@@ -706,45 +843,46 @@ def _end_of_backward():
       * check the N of every sync-free forward differentiated in this backward (_LazyN): truncated tile lists raise HERE, out
         of backward() and therefore before `optimizer.step()` of train.py:196-198 -- but behind the backward's launches, so
         the host waits for the forwards' read-backs while the device still has the whole backward queued (checking at the
-        entry of the first node drained the queue between forward and backward of every iteration: ~0.2 ms of idle device)."""
-    task, flush, streams, tokens = _task_cb["task"], _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"]
-    _task_cb["task"], _task_cb["flush"], _task_cb["streams"], _task_cb["tokens"] = None, [], [], []
-    for ref in flush:
+        entry of the first node drained the queue between forward and backward of every iteration: ~0.2 ms of idle device).
+        A refused step leaves no half-made gradients behind: every `.grad` this backward CREATED is set back to None
+        (gradients it added into an existing `.grad` cannot be taken out again -- the message says to zero them)."""
+    st = _S.tasks.pop(task, None)
+    if st is None:
+        return
+    for ref in st.flush:
         node = ref()
         jobs = getattr(node, "pending", None) if node is not None else None
         if jobs:
             node.pending = []
             jobs = [j for j in jobs if j.task == task]     # (see _RasterizeRaw.backward)
             if jobs:
-                _launch_backward(jobs, True)
-    for st in streams:
-        cur = torch.cuda.current_stream(st.device)
-        if cur != st:
-            cur.wait_stream(st)
+                _launch_backward(jobs, True, st)
+    for dev, sid in st.streams:
+        if raw_stream(dev) != sid:
+            torch.cuda.current_stream(dev).wait_stream(torch.cuda.ExternalStream(sid, device=dev))
     err = None
-    for tok in tokens:
+    for tok in st.tokens:
         try:
             _lazy.confirm(tok)
         except _lib.B3gsError as exc:      # (every token is resolved -- capacities grow -- before the first error leaves)
             err = err or exc
     if err is not None:
-        raise err
+        for t in st.created:
+            t.grad = None
+        raise _lib.B3gsError(f"{err} (gradients this backward() created were discarded; call zero_grad() before repeating "
+                             f"the step if .grad held earlier contributions)")
 
 
-def _register_task(stream=None, flush_ref=None, token=None):
-    task = torch._C._current_graph_task_id()
-    if _task_cb["task"] != task:
-        _task_cb["task"], _task_cb["streams"], _task_cb["flush"], _task_cb["tokens"] = task, [], [], []
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-    if stream is not None and stream not in _task_cb["streams"]:
-        _task_cb["streams"].append(stream)
+def _register_task(flush_ref=None, token=None):
+    st = _task_state()
     if flush_ref is not None:
-        _task_cb["flush"].append(flush_ref)
+        st.flush.append(flush_ref)
     if token is not None:
-        _task_cb["tokens"].append(token)
+        st.tokens.append(token)
+    return st
 
 
-def _launch_backward(jobs, self_acc):
+def _launch_backward(jobs, self_acc, task_state=None):
     """Blend backward + per-Gaussian chain rule of `jobs` (renders of the SAME parameter tensors), at most 8 views per
     launch.  self_acc: the gradients are added to (or become) `.grad` of the parameters and of every render's
     `viewspace_points` leaf, nothing is returned; otherwise (one job) fresh tensors are returned for autograd."""
@@ -753,25 +891,28 @@ def _launch_backward(jobs, self_acc):
     params = jobs[-1].saved[:6]
     dev, P = params[0].device, params[0].shape[0]
     f32 = dict(dtype=torch.float32, device=dev)
-    skey = (_dev_index(dev), P)
+    cur_id = raw_stream(dev)
+    skey = (_dev_index(dev), P, cur_id)       # (per stream: two streams' backwards may be in flight together)
     pool = _raw_scratch.get(skey)
     if pool is None:
         if len(_raw_scratch) > 4:
             _raw_scratch.clear()
         pool = _raw_scratch[skey] = []
-    cur = torch.cuda.current_stream(dev)
     for j in jobs:
-        if j.stream != cur:
-            cur.wait_stream(j.stream)       # pixel gradients produced on another stream (deferred from another node)
+        if j.stream_id != cur_id:           # pixel gradients produced on another stream (deferred from another node)
+            torch.cuda.current_stream(dev).wait_stream(_stream_obj(j))
     if self_acc:
         missing = [t.grad is None for t in params]
         overwrite = all(missing)
         grads = []
+        tstate = task_state if task_state is not None else _register_task()
+        if (dev, cur_id) not in tstate.streams:
+            tstate.streams.append((dev, cur_id))
         for t, m in zip(params, missing):
             if m:
                 t.grad = torch.empty_like(t) if overwrite else torch.zeros_like(t)
+                tstate.created.append(t)
             grads.append(t.grad)
-        _register_task(stream=cur)
     else:
         assert len(jobs) == 1
         overwrite = True
@@ -782,7 +923,7 @@ def _launch_backward(jobs, self_acc):
     gr.scaling, gr.rotation, gr.opacity = grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr()
     gr.touched_rows = None
     m2d_out = []
-    with torch.cuda.device(dev):
+    with device_guard(dev):
         s = _stream(dev)
         for c0 in range(0, len(jobs), 8):
             chunk = jobs[c0:c0 + 8]
@@ -812,12 +953,20 @@ def _launch_backward(jobs, self_acc):
                                                       None, s), "b3gs_backward_raw_accumulate")
             _stats["launches"] += 1
             _stats["batched_views"] += n
+    _mark_busy(_dev_index(dev), cur_id)
+    # the chain rule uses view 0's depth-sort key arrays as scratch -- a later forward must not adopt "sorted
+    # keys" from a geometry buffer whose backward has run (include/b3gs_raster.h, depth_order_hint)
+    di = _dev_index(dev)
+    hint = _order_hint.get(di)
+    if hint is not None and any(hint["geom"] is j.saved[7] for j in jobs):
+        _order_hint.pop(di, None)
     if self_acc:
         for j, g in zip(jobs, m2d_out):
             if g is not None:
                 leaf = j.m2d_leaf
                 if leaf.grad is None:
                     leaf.grad = g
+                    tstate.created.append(leaf)
                 else:
                     leaf.grad += g
         return None
@@ -845,6 +994,7 @@ class _RasterizeRaw(torch.autograd.Function):
         torch.autograd.grad(), backward(inputs=...), hooks, create_graph the gradients are returned per node."""
 
     @staticmethod
+    @_locked
     def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, means2D, cfg):
         L = _lib.lib()
         dev, P = xyz.device, xyz.shape[0]
@@ -872,8 +1022,18 @@ class _RasterizeRaw(torch.autograd.Function):
         # may this render's forward WAIT for its partner (see _LazyOut)?  Only when render() hands out its outputs as
         # _LazyOut, the render will be differentiated and the capacity of its shape is known (sync-free N)
         fkey = (batch_key, stream_id, W, H, _lazy.key_bits, xyz._version)
-        wait = bool(_LAZY_FWD and cfg.get("lazy_outputs") and lazy and key in _lazy.capacity and P > 0)
+        wait = bool(_LAZY_FWD and _LAZY_OK and cfg.get("lazy_outputs") and lazy and key in _lazy.capacity and P > 0)
         pend = _pending_fwd.get(di)
+        if wait and not pend and not _LAZY_WHEN_IDLE:
+            # Waiting for the partner pays while the device still works on what this module queued before (the previous
+            # pair of a loop that renders several pairs per iteration).  When that work is DONE -- train.py's own loop reads
+            # the loss / indexes with a mask between two iterations -- the device would sit idle while the host prepares
+            # the partner's render (and builds its camera, train.py:124-127): start this view now; its partner adopts the
+            # depth order (a two-view launch saves ~0.1 ms of device time, an idle device loses more than that)
+            ev = _S.busy.get((di, stream_id))
+            if ev is None or ev.query():
+                wait = False
+                _stats["eager_idle"] += 1
         if pend and not (wait and pend[0].fkey == fkey):
             _flush_pending(di)        # something else is rendered first: what is pending goes now
             pend = None
@@ -910,8 +1070,9 @@ class _RasterizeRaw(torch.autograd.Function):
             p.binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
             p.words, p.ring, p.row = _zero_words(dev, with_row=True)
             p.hint, p.trusted, p.zkey, p.key_bits = hint, trusted, zkey, _lazy.key_bits
-            p.stream_id, p.stream, p.fkey, p.dev, p.P = stream_id, torch.cuda.current_stream(dev), fkey, dev, P
+            p.stream_id, p.stream, p.fkey, p.dev, p.P = stream_id, None, fkey, dev, P
             p.xyz_id, p.vis = (xyz.data_ptr(), xyz._version), vis
+            p.handed = None
             binning = p.binning
             ctx.rp = rp
             cfg["pending"] = p
@@ -939,7 +1100,7 @@ class _RasterizeRaw(torch.autograd.Function):
                     fv[0].hint_trusted = int(trusted)
                     _stats["hinted"] += 1
                     _stats["trusted"] += int(trusted)
-                with torch.cuda.device(dev):
+                with device_guard(dev):
                     _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
                 if lazy and key in _lazy.capacity:
                     ctx.lazy_token = _lazy.track(key, cap, words[:2])
@@ -955,6 +1116,8 @@ class _RasterizeRaw(torch.autograd.Function):
                 if n <= cap and not (flag & 10):
                     break
                 cap = max(cap, _lazy.capacity[key])                       # repeat with what it needs
+            if lazy:
+                _mark_busy(di, stream_id)
             if _ORDER_HINT:
                 _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
                                        words=words, zkey=zkey, stream=stream_id)
@@ -966,6 +1129,7 @@ class _RasterizeRaw(torch.autograd.Function):
             # still pending: the outputs leave as _LazyOut (made here, in the forward's no-grad mode: as_subclass() on a tensor
             # that already carries a grad_fn would put an alias node between it and this one)
             color, radii, depth, alpha = (t.as_subclass(_LazyOut) for t in (color, radii, depth, alpha))
+            cfg["pending"].handed = [weakref.ref(t) for t in (color, radii, depth, alpha)]
         ctx.mark_non_differentiable(radii)
         # an output nobody differentiates (depth / alpha of the shifted render, train.py:128-129) arrives as None in the
         # backward, not as an image of zeros the blend backward would have to read
@@ -982,18 +1146,22 @@ class _RasterizeRaw(torch.autograd.Function):
         return color, radii, depth, alpha
 
     @staticmethod
+    @_locked
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
         if _pending_fwd:
             _flush_pending()          # (a render whose outputs nobody touched before backward(): its forward runs now)
         if ctx.lazy_token is not None and not ctx.lazy_token[4]:
-            _register_task(token=ctx.lazy_token)    # truncated lists / key span: raised at the end of THIS backward()
+            if _ENGINE_HOOKS:
+                _register_task(token=ctx.lazy_token)    # truncated lists / key span: raised at the end of THIS backward()
+            else:
+                _lazy.confirm(ctx.lazy_token)           # (no final callback available: at the entry of the node)
         saved = ctx.saved_tensors
         params = saved[:6]
         dev = params[0].device
         cfg = ctx.cfg
         if grad_color is None:
             grad_color = torch.zeros((3, cfg["H"], cfg["W"]), dtype=torch.float32, device=dev)
-        task = torch._C._current_graph_task_id()
+        task = _current_task()
         job = _RawJob(ctx, _dev_f32(grad_color, "dL_dout_color"),
                       None if grad_depth is None else _dev_f32(grad_depth, "dL_dout_depth"),
                       None if grad_alpha is None else _dev_f32(grad_alpha, "dL_dout_alpha"), task)
@@ -1010,7 +1178,7 @@ class _RasterizeRaw(torch.autograd.Function):
         jobs = pending + [job]
         partner = ctx.partner() if ctx.partner is not None else None
         if (partner is not None and partner.done_task != task and partner.batch_key == ctx.batch_key
-                and not cfg["debug"] and torch._C._will_engine_execute_node(partner)):
+                and not cfg["debug"] and _will_execute(partner)):
             # an earlier render of the same parameters runs its backward later in THIS graph task: it launches ours with its
             # own (one blend backward, one chain-rule pass for all of them)
             partner.pending = partner.pending + jobs
@@ -1045,7 +1213,9 @@ def rasterize_raw(pc, means2D, raster_settings, camera=None, lazy_outputs=False)
     p, vis = cfg.pop("pending", None), cfg.pop("vis")
     if p is None or p.ctx.lazy_token is not None:            # launched already (not eligible, or it completed a batch)
         return color, radii, depth, alpha, vis
-    return color, radii, depth, alpha, vis.as_subclass(_LazyOut)
+    vis = vis.as_subclass(_LazyOut)
+    p.handed.append(weakref.ref(vis))
+    return color, radii, depth, alpha, vis
 
 
 class GaussianRasterizer(nn.Module):

@@ -716,7 +716,7 @@ class ViewShardedStep:
                     continue
                 vis = pkg["visibility_filter"]
                 m.update_max_radii(pkg["radii"], vis)
-                m.add_densification_stats(g, vis)
+                m._accumulate_stats(g, vis)
 
     def _loss_pixel_grads(self, pkgs, loss_fn, batch_loss_fn):
         """Loss of every pair whose INPUT view lives here, on detached leaves of the rendered images; returns the

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 8
+#define B3GS_ABI_VERSION 9
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -400,6 +400,66 @@ int b3gs_densify_scatter(const B3gsDensifyIO* io, const int32_t* flags, const in
                          const int32_t* off_clone, const int32_t* off_split, int32_t n_keep, int32_t n_clone,
                          int32_t n_split, const float* noise, float* const* out_param, float* const* out_exp_avg,
                          float* const* out_exp_avg_sq, b3gs_stream_t stream);
+
+/* ---- ABI 9: the statements of the training loop ONE BY ONE, behind the reference's own call signatures ------------
+ * An unchanged train.py:123-198 calls l1_loss / ssim / SmoothLoss.forward / inverse_warp_images as separate statements
+ * with PyTorch glue between them, then gaussians.opacity_decay(), add_densification_stats() and optimizer.step(): each
+ * of them is one launch here (value forward; EVERY input gradient backward), wrapped on the python side as
+ * autograd.Functions / methods with exactly the reference's signatures (binocular3dgs_amd/loss_utils.py,
+ * graphics_utils.py, gaussian_model.py, optim.py).  All tensors fp32, contiguous, on the device.
+ *
+ * Scalar results are deterministic (per-workgroup partial sums folded in index order by the workgroup that arrives
+ * last: no float atomics, no second launch).  `workspace`: b3gs_lossfn_workspace_floats(planes, H, W) floats whose
+ * header (the first 2080 words: two levels of arrival counters) is ZERO before the first call; every call leaves it zero.
+ * One workspace per stream. */
+size_t b3gs_lossfn_workspace_floats(int64_t planes, int32_t H, int32_t W);
+
+/* utils/loss_utils.py:18-21  l1_loss(network_output, gt, mask=None) = mean |x*mask - y*mask|.
+ * x, y: [batch, channels, hw]; mask: NULL, or [batch, hw] (broadcast over the channels; a mask of x's own shape is
+ * passed as channels = 1, hw = numel / batch).  out: [1].  backward: grad_out = the upstream gradient, a device scalar;
+ * grad_x / grad_y / grad_mask may each be NULL (not wanted). */
+int b3gs_l1_loss_forward(const float* x, const float* y, const float* mask, int64_t batch, int32_t channels, int64_t hw,
+                         float* out, float* workspace, b3gs_stream_t stream);
+int b3gs_l1_loss_backward(const float* x, const float* y, const float* mask, int64_t batch, int32_t channels, int64_t hw,
+                          const float* grad_out, float* grad_x, float* grad_y, float* grad_mask, b3gs_stream_t stream);
+
+/* utils/graphics_utils.py:80-125  inverse_warp_images(image [B,C,H,W], disparity [B,1,H,W], row_indices, column_indices)
+ * -> [B,C,H,W]: linear interpolation between columns c + floor(d) and the next one, zero where either leaves the row.
+ * zero_fill (may be NULL): a [B,C,H,W] buffer the forward fills with zeros on its way -- the grad_image of the backward,
+ * which ADDS into it (bilinear scatter); grad_image / grad_disparity may each be NULL. */
+int b3gs_inverse_warp_forward(const float* image, const float* disparity, int32_t B, int32_t C, int32_t H, int32_t W,
+                              float* out, float* zero_fill, b3gs_stream_t stream);
+int b3gs_inverse_warp_backward(const float* image, const float* disparity, const float* grad_out, int32_t B, int32_t C,
+                               int32_t H, int32_t W, float* grad_image, float* grad_disparity, b3gs_stream_t stream);
+
+/* utils/loss_utils.py:68-91  SmoothLoss.forward(disparity [B,1,H,W], image [B,C,H,W]): edge-aware first-order
+ * smoothness on the interior (the reference's fixed 3x3 convolutions have no padding).  out: [1]. */
+int b3gs_smooth_loss_forward(const float* disparity, const float* image, int32_t B, int32_t C, int32_t H, int32_t W,
+                             float* out, float* workspace, b3gs_stream_t stream);
+int b3gs_smooth_loss_backward(const float* disparity, const float* image, int32_t B, int32_t C, int32_t H, int32_t W,
+                              const float* grad_out, float* grad_disparity, float* grad_image, b3gs_stream_t stream);
+
+/* utils/loss_utils.py:36-66  ssim(img1, img2, window_size=11, size_average=True): 11x11 Gaussian window (sigma 1.5),
+ * zero padding, every [H,W] plane by itself.  out: [1], or [batch] when size_average == 0.  maps (NULL: value only):
+ * 5 * batch * channels * H * W floats the backward reads (the last two fifths only written when maps_for_img2 != 0,
+ * i.e. when img2 wants a gradient too).  backward: grad_out [1] or [batch]; grad_img1 / grad_img2 may be NULL. */
+int b3gs_ssim_forward(const float* img1, const float* img2, int32_t batch, int32_t channels, int32_t H, int32_t W,
+                      int32_t size_average, float* maps, int32_t maps_for_img2, float* out, float* workspace,
+                      b3gs_stream_t stream);
+int b3gs_ssim_backward(const float* img1, const float* img2, const float* maps, int32_t batch, int32_t channels, int32_t H,
+                       int32_t W, int32_t size_average, const float* grad_out, float* grad_img1, float* grad_img2,
+                       b3gs_stream_t stream);
+
+/* scene/gaussian_model.py:307-309  opacity_decay(factor): o <- inverse_sigmoid(sigmoid(o) * factor), in place. */
+int b3gs_opacity_decay(float* opacity, int64_t count, float factor, b3gs_stream_t stream);
+/* scene/gaussian_model.py:409-411  add_densification_stats: for the rows update_filter (one byte per row) selects,
+ * xyz_gradient_accum += ||viewspace_grad[row, :2]|| and denom += 1.  row_stride: floats per row of viewspace_grad (3). */
+int b3gs_add_densification_stats(int64_t P, const float* viewspace_grad, int64_t row_stride, const uint8_t* update_filter,
+                                 float* xyz_gradient_accum, float* denom, b3gs_stream_t stream);
+/* train.py:196-198 optimizer.step() for an optimiser that keeps torch.optim.Adam's state layout: b3gs_adam_step with the
+ * step number given by the host (1-based, the value of state["step"] after its increment); no decay, no row mask. */
+int b3gs_adam_step_at(int32_t nseg, const B3gsAdamSegment* segs, int32_t step, float beta1, float beta2, float eps,
+                      b3gs_stream_t stream);
 
 /* ---- scale initialisation -------------------------------------------------------------
  * mean_dist2[i] = mean squared distance from point i to its 3 nearest OTHER points: the distCUDA2 of the

@@ -154,7 +154,7 @@ class Trainer:
                 model._opacity.data = inverse_sigmoid(model.get_opacity * self.opacity_decay)
             vis = pkg["visibility_filter"]
             model.update_max_radii(pkg["radii"], vis)
-            model.add_densification_stats(pkg["viewspace_points"].grad, vis)
+            model.add_densification_stats(pkg["viewspace_points"], vis)
             if it > self.densify_from_iter and it % self.densification_interval == 0:
                 P = model.get_xyz.shape[0]
                 noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it))

@@ -186,7 +186,7 @@ def test_densification_statistics_match_reference_formula():
                                     [gc, gd, ga, gc])
             vis = pkg["visibility_filter"]
             ref.update_max_radii(pkg["radii"], vis)
-            ref.add_densification_stats(pkg["viewspace_points"].grad, vis)
+            ref.add_densification_stats(pkg["viewspace_points"], vis)
     # a handful of Gaussians may flip visibility (in-kernel vs torch activations): compare where both agree
     same = got[2].reshape(-1) == ref.denom.reshape(-1)
     assert float(same.float().mean()) > 0.999

@@ -97,13 +97,15 @@ def test_densification_statistics_without_boolean_indexing_keep_the_reference_bi
         g = torch.randn(P, 3)
         vis = torch.rand(P) > 0.4
         radii = (torch.rand(P) * 60).int() * vis
-        a.add_densification_stats(g, vis)
+        leaf = torch.zeros(P, 3, requires_grad=True)       # render()'s `viewspace_points`: the gradient is read from .grad
+        leaf.grad = g
+        a.add_densification_stats(leaf, vis)
         a.update_max_radii(radii, vis)
         b.xyz_gradient_accum[vis] += torch.norm(g[vis, :2], dim=-1, keepdim=True)
         b.denom[vis] += 1
         b.max_radii2D[vis] = torch.max(b.max_radii2D[vis], radii[vis].float())
         idx = torch.nonzero(vis).reshape(-1)          # an index tensor takes the indexed statements
-        a.add_densification_stats(g, idx)
+        a.add_densification_stats(leaf, idx)
         b.xyz_gradient_accum[idx] += torch.norm(g[idx, :2], dim=-1, keepdim=True)
         b.denom[idx] += 1
     assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum) and torch.equal(a.denom, b.denom)
