@@ -325,7 +325,8 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
     return out
 
 
-def table(dev, fov: float, seed: int, sizes=((500_000, 800, 600), (500_000, 504, 378), (100_000, 800, 600), (100_000, 504, 378)),
+def table(dev, fov: float, seed: int, sizes=((500_000, 800, 600), (500_000, 504, 378), (100_000, 800, 600), (100_000, 504, 378),
+                                              (500_000, 400, 300)),      # (the last: DTU at --resolution 4, script/run_dtu.py:11)
           surfaces=("fused", "fused_graph", "render", "unchanged", "unchanged_item", "torch_ops"), steps: int = 40) -> dict:
     res = {"what": "train.py's own iteration shape: ONE random input view + ONE randomly shifted partner per iteration "
                    "(cameras change every step), binocular loss block, opacity decay before the optimiser step, "
@@ -339,6 +340,8 @@ def table(dev, fov: float, seed: int, sizes=((500_000, 800, 600), (500_000, 504,
     for P, W, H in sizes:
         row = {}
         for s in surfaces:
+            if s == "unchanged_item" and (P, W, H) != sizes[0]:
+                continue                      # (the progress bar's loss.item(): measured at the first size only)
             row[s] = run(dev, P, W, H, fov, s, steps=steps, seed=seed)
             torch.cuda.empty_cache()
         res[f"P{P // 1000}k_{W}x{H}"] = row

@@ -68,10 +68,15 @@ __device__ __forceinline__ void load_scale_rot(const SceneX& sx_, int i, float s
     const float* ls = sx_.raw.scaling + 3 * (size_t)i;
     s[0] = expf(ls[0]); s[1] = expf(ls[1]); s[2] = expf(ls[2]);
     const float4 r = reinterpret_cast<const float4*>(sx_.raw.rotation)[i];
-    const float n = sqrtf(((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w);
-    const float inv = 1.0f / fmaxf(n, 1e-12f);
-    q[0] = r.x * inv; q[1] = r.y * inv; q[2] = r.z * inv; q[3] = r.w * inv;
-    *inv_norm = inv;
+    // Bit for bit what torch-ROCm's F.normalize(_rotation) hands the reference's rasterizer (scene/gaussian_model.py:99-101):
+    // ATen reduces the four squares of a row as a tree, (x0^2 + x1^2) + (x2^2 + x3^2) (four lanes, shuffle-down by 1 then 2),
+    // takes the correctly rounded square root, clamps at eps and DIVIDES every element -- multiplying by one reciprocal, or
+    // summing left to right, lands one ulp beside it for ~1 quaternion in 4, which moved 0-3 integer radii per view at 1M
+    // Gaussians (tests/test_gpu_round5.py::test_in_kernel_activations_are_torch_bits pins all three accessors)
+    const float n = sqrtf((r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w));
+    const float den = fmaxf(n, 1e-12f);
+    q[0] = r.x / den; q[1] = r.y / den; q[2] = r.z / den; q[3] = r.w / den;
+    *inv_norm = 1.0f / den;
   } else {
     const float* ps = sx_.sc.scales + 3 * (size_t)i;
     s[0] = ps[0]; s[1] = ps[1]; s[2] = ps[2];
@@ -1139,4 +1144,32 @@ void b3gs_launch_mark_visible(int32_t P, const float* means3D, const float* view
                               hipStream_t s) {
   if (P <= 0) return;
   hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, viewmatrix, present);
+}
+
+
+// ---- parity hook: the activations exactly as the kernels above evaluate them ------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) debug_activations_kernel(SceneX sx_, float* __restrict__ scales, float* __restrict__ rot,
+                                                                float* __restrict__ opacity) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= sx_.sc.P) return;
+  float s[3], q[4], inv;
+  load_scale_rot<true>(sx_, i, s, q, &inv);
+  for (int k = 0; k < 3; k++) scales[3 * (size_t)i + k] = s[k];
+  for (int k = 0; k < 4; k++) rot[4 * (size_t)i + k] = q[k];
+  opacity[i] = load_opacity<true>(sx_, i);
+}
+}  // namespace
+
+extern "C" int b3gs_debug_activations(int32_t P, const B3gsRawParams* raw, float* scales, float* rotations, float* opacity,
+                                      b3gs_stream_t stream) {
+  if (P < 0 || !raw || (P > 0 && (!raw->scaling || !raw->rotation || !raw->opacity || !scales || !rotations || !opacity)))
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_debug_activations", "NULL pointer or negative count");
+  if (P == 0) return B3GS_OK;
+  SceneX sx_{};
+  sx_.sc.P = P;
+  sx_.raw = *raw;
+  sx_.raw_mode = 1;
+  hipLaunchKernelGGL(debug_activations_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, sx_, scales, rotations, opacity);
+  return b3gs_launch_status("b3gs_debug_activations");
 }

@@ -527,7 +527,19 @@ __device__ __forceinline__ void bwd_eval(BwdPixel& px, const float4& A, const fl
     const bool live = (base + (uint32_t)(J) < px.last) && !(power > 0.0f) && !(alpha < B3GS_ALPHA_MIN); \
     if (TRACE) n_iter++;                                                                         \
     if (__builtin_amdgcn_ballot_w64(live) != 0) {                                                \
-      if (TRACE) { n_live++; n_lanes += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(live)); }      \
+      if (TRACE) {                                                                               \
+        const unsigned long long lm_ = __builtin_amdgcn_ballot_w64(live);                        \
+        n_live++; n_lanes += (unsigned)__builtin_popcountll(lm_);                                \
+        /* lane = 8 y + x: candidates whose live pixels sit in ONE half of the quadrant (rows 0-3 / 4-7, columns 0-3 / 4-7) */ \
+        const bool top_ = !(lm_ >> 32), bot_ = !(lm_ & 0xFFFFFFFFull);                           \
+        const bool lft_ = !(lm_ & 0xF0F0F0F0F0F0F0F0ull), rgt_ = !(lm_ & 0x0F0F0F0F0F0F0F0Full); \
+        const unsigned code_ = top_ ? 1u : bot_ ? 2u : lft_ ? 3u : rgt_ ? 4u : 0u;                \
+        n_half += code_ != 0u;                                                                   \
+        /* ... and ADJACENT live candidates in complementary halves: the only pairs one loop trip could serve together */ \
+        n_pair += (code_ != 0u && prev_half == (code_ ^ ((code_ <= 2u) ? 3u : 7u)));             \
+        prev_half = (n_pair_last_ == n_pair) ? code_ : 0u;                                       \
+        n_pair_last_ = n_pair;                                                                   \
+      }                                                                                          \
       float p[10];                                                                               \
       bwd_eval(px, A, B, Cc.x, Cc.y, dx_, dy_, u_, v_, nw_, G, alpha, live, p);                  \
       B3GS_ROW_WRITES(p);                                                                        \
@@ -571,7 +583,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
   __shared__ uint32_t s_max_last[4];
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  unsigned n_iter = 0, n_live = 0, n_lanes = 0;
+  unsigned n_iter = 0, n_live = 0, n_lanes = 0, n_half = 0, n_pair = 0, prev_half = 0, n_pair_last_ = 0;
   // longest-tile-first inside the XCD class (BlendBatch::order); placement never affects results
   const int bid = batch.order ? 8 * (int)batch.order[(blockIdx.x & 7u) * (unsigned)batch.cls_size + (blockIdx.x >> 3)] + (int)(blockIdx.x & 7u)
                               : (int)blockIdx.x;
@@ -718,7 +730,7 @@ __global__ void __launch_bounds__(256, B3GS_BWD_WAVES)
     unsigned long long* t = trace + 4 * ((size_t)blockIdx.x * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;            // shader cycles this wave lived
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);  // 100 MHz wall clock: start | end
-    t[2] = n_iter;
+    t[2] = (unsigned long long)n_iter | ((unsigned long long)(n_half & 0xFFFFu) << 32) | ((unsigned long long)(n_pair & 0xFFFFu) << 48);
     t[3] = (unsigned long long)n_live | ((unsigned long long)n_lanes << 32);   // live iterations | live lanes summed
   }
 }
@@ -752,7 +764,7 @@ __global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
   __shared__ WaveSharedBwd<REGS ? 1 : SC> sh;
   const unsigned long long t_start = TRACE ? __builtin_readcyclecounter() : 0ull;
   const unsigned long long r_start = TRACE ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  unsigned n_iter = 0, n_live = 0, n_lanes = 0;
+  unsigned n_iter = 0, n_live = 0, n_lanes = 0, n_half = 0, n_pair = 0, prev_half = 0, n_pair_last_ = 0;
 #ifdef B3GS_BWD_QUAD_LINEAR
   const unsigned w = blockIdx.x & 3u, blk = blockIdx.x >> 2;     // quadrant, tile-level block
 #else
@@ -935,7 +947,7 @@ __global__ void __launch_bounds__(64, REGS ? B3GS_BWD_QWAVES : B3GS_BWD_WAVES)
     unsigned long long* t = trace + 4 * ((size_t)blk * 4 + w);
     t[0] = __builtin_readcyclecounter() - t_start;
     t[1] = (r_start << 32) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFull);
-    t[2] = n_iter;
+    t[2] = (unsigned long long)n_iter | ((unsigned long long)(n_half & 0xFFFFu) << 32) | ((unsigned long long)(n_pair & 0xFFFFu) << 48);
     t[3] = (unsigned long long)n_live | ((unsigned long long)n_lanes << 32);
   }
 }

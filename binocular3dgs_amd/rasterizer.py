@@ -475,6 +475,7 @@ class _DropinState:
         self.tasks = {}           # graph-task id -> _TaskState of a backward() in flight
         self.word_ring = {}       # device index -> [zeroed int32 ring, next slot]
         self.busy = {}            # (device index, stream) -> event behind the last forward / backward this module launched there
+        self.adapt = {}           # (device index, stream) -> the eager-on-idle rule's memory (see _RasterizeRaw.forward)
         self.stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0, "lazy_batches": 0,
                       "lazy_views": 0, "shared": 0, "eager_idle": 0}   # (tests / bench read these)
 
@@ -1024,16 +1025,34 @@ class _RasterizeRaw(torch.autograd.Function):
         fkey = (batch_key, stream_id, W, H, _lazy.key_bits, xyz._version)
         wait = bool(_LAZY_FWD and _LAZY_OK and cfg.get("lazy_outputs") and lazy and key in _lazy.capacity and P > 0)
         pend = _pending_fwd.get(di)
-        if wait and not pend and not _LAZY_WHEN_IDLE:
+        if wait and not _LAZY_WHEN_IDLE:
             # Waiting for the partner pays while the device still works on what this module queued before (the previous
-            # pair of a loop that renders several pairs per iteration).  When that work is DONE -- train.py's own loop reads
-            # the loss / indexes with a mask between two iterations -- the device would sit idle while the host prepares
-            # the partner's render (and builds its camera, train.py:124-127): start this view now; its partner adopts the
-            # depth order (a two-view launch saves ~0.1 ms of device time, an idle device loses more than that)
-            ev = _S.busy.get((di, stream_id))
-            if ev is None or ev.query():
-                wait = False
-                _stats["eager_idle"] += 1
+            # pair of a loop that renders several pairs per iteration) and whenever the loop is bound by the HOST (a shared
+            # launch is ~20 kernel launches less).  When the device is idle AND the scene is large enough for it to matter
+            # -- train.py's own loop reads the loss / indexes with a mask between two iterations, so every iteration starts
+            # on an empty queue -- the device would sit idle while the host prepares the partner's render and builds its
+            # camera (train.py:124-127): start this view now; its partner adopts the depth order.  "Large enough" is
+            # observed, not guessed: when the partner of an eagerly started view arrives, was that view's forward still
+            # running?  Yes -> the overlap was real, stay eager; no (twice in a row) -> wait again, and probe once in a while.
+            am = _S.adapt.setdefault((di, stream_id), {"eager": True, "miss": 0, "probe": 0, "check": None, "key": None})
+            if not pend:
+                if am["check"] is not None and am["key"] == batch_key:      # this is the partner of an eager view: sample
+                    still_running = not am["check"].query()
+                    am["miss"] = 0 if still_running else am["miss"] + 1
+                    if still_running:
+                        am["eager"] = True
+                    elif am["miss"] >= 2:
+                        am["eager"], am["probe"] = False, 64
+                    am["check"] = None
+                else:
+                    ev = _S.busy.get((di, stream_id))
+                    if ev is None or ev.query():                            # nothing of ours is executing
+                        if am["eager"] or am["probe"] <= 0:
+                            wait = False
+                            am["key"], am["want_check"] = batch_key, True
+                            _stats["eager_idle"] += 1
+                        else:
+                            am["probe"] -= 1
         if pend and not (wait and pend[0].fkey == fkey):
             _flush_pending(di)        # something else is rendered first: what is pending goes now
             pend = None
@@ -1118,6 +1137,13 @@ class _RasterizeRaw(torch.autograd.Function):
                 cap = max(cap, _lazy.capacity[key])                       # repeat with what it needs
             if lazy:
                 _mark_busy(di, stream_id)
+                am = _S.adapt.get((di, stream_id))
+                if am is not None and am.pop("want_check", False):
+                    ck = am.get("ck_event")
+                    if ck is None:
+                        ck = am["ck_event"] = torch.cuda.Event()
+                    ck.record()
+                    am["check"] = ck
             if _ORDER_HINT:
                 _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
                                        words=words, zkey=zkey, stream=stream_id)

@@ -493,6 +493,12 @@ typedef struct B3gsDebugViews {
 int b3gs_debug_views(int32_t P, int32_t W, int32_t H, int64_t num_rendered, const char* geometry,
                      const char* binning, const char* image, B3gsDebugViews* out);
 
+/* Parity hook (ABI 9): the accessors of scene/gaussian_model.py:95-115 exactly as the raw-parameter kernels evaluate them
+ * -- exp(_scaling) [P,3], F.normalize(_rotation) [P,4], sigmoid(_opacity) [P] -- so that a test can hold them against the
+ * torch operators bit for bit (integer radii on the raw-parameter path depend on it). */
+int b3gs_debug_activations(int32_t P, const B3gsRawParams* raw, float* scales, float* rotations, float* opacity,
+                           b3gs_stream_t stream);
+
 /* Per-stage timing hook (thread-local): when non-NULL, b3gs_forward/backward record HIP events
  * around every stage on `stream` WITHOUT synchronising.  After the caller has synchronised the
  * stream, b3gs_timing_collect() adds the elapsed milliseconds of every parked stage to the sink

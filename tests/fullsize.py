@@ -291,3 +291,67 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fra
     m["stat_denom_mismatch"] = int((model.denom.cpu().numpy().ravel() != st_cnt).sum())
     m["stat_max_radii_mismatch"] = int((model.max_radii2D.cpu().numpy().ravel() != st_rad).sum())
     return m
+
+
+def render_node_metrics(P, W, H, fov=60.0, seed=0, views=6):
+    """The zero-change surface at full size against the oracle: render() per view exactly as an unchanged train.py calls it
+    (the raw-parameter node: in-kernel activations, tight binning, the forward of a pair as ONE two-view launch with one
+    depth sort, every node of the backward launched as one batch that accumulates into .grad), all views of one iteration,
+    one backward.  Per view: integer radii, visibility, images; over the iteration: parameter gradients (oracle gradients
+    chained through fp64 activations), every input view's `viewspace_points.grad`."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    dev = "cuda"
+    model = synth.synth_model(P, seed=seed, device=dev, width=W, height=H, fovx_deg=fov)
+    pairs = view_set(W, H, fov, views)
+    bg = torch.zeros(3, device=dev)
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=seed, device=dev)
+    gc2 = synth.synth_pixel_grads(W, H, seed=100 + seed, device=dev)[0]
+    pipe = PipelineParams()
+    with torch.no_grad():                                  # (the first render of a shape is the exact, synchronous one)
+        render(pairs[0][0], model, pipe, bg)
+    R._flush_pending()
+    old_idle, R._LAZY_WHEN_IDLE = R._LAZY_WHEN_IDLE, True  # the two-view launch, whatever the queue holds
+    s0 = dict(R._stats)
+    try:
+        for p in model.parameters():
+            p.grad = None
+        vlist, pkgs, o_t, g_t = [], [], [], []
+        for cam, scam, _t in pairs:
+            a = render(cam, model, pipe, bg)
+            pkgs.append(a)
+            vlist.append((cam, True, (gc, gd, ga)))
+            o_t += [a["render"], a["rendered_depth"], a["rendered_alpha"]]
+            g_t += [gc, gd, ga]
+            if scam is not None:
+                b = render(scam, model, pipe, bg)
+                pkgs.append(b)
+                vlist.append((scam, False, (gc2, None, None)))
+                o_t.append(b["render"])
+                g_t.append(gc2)
+        torch.autograd.backward(o_t, g_t)
+        torch.cuda.synchronize()
+    finally:
+        R._LAZY_WHEN_IDLE = old_idle
+    m = dict(P=P, W=W, H=H, views=len(vlist), stats={k: R._stats[k] - s0[k] for k in R._stats})
+    per_view = [None] * len(vlist)
+
+    def cb(k, st, ref):
+        o = pkgs[k]
+        pv = dict(radius_flips=int((o["radii"].cpu().numpy() != st.radii).sum()),
+                  visibility_flips=int((o["visibility_filter"].cpu().numpy() != (st.radii > 0)).sum()))
+        for name, key, refimg in (("color", "render", st.color), ("depth", "rendered_depth", st.depth),
+                                  ("alpha", "rendered_alpha", st.alpha)):
+            pv[name + "_max"], pv[name + "_frac"] = image_err(o[key].detach().cpu().numpy(), refimg)
+        g = o["viewspace_points"].grad
+        pv["dL_dmeans2D"] = None if g is None else rel_l2(g.cpu().numpy(), ref["dL_dmeans2D"])
+        per_view[k] = pv
+
+    raw, _, _, _ = oracle_raw_grads(model, vlist, bg, W, H, cb)
+    m["per_view"] = per_view
+    for n in raw:
+        got = getattr(model, "_" + n).grad
+        if got.numel():
+            m["grad_" + n] = rel_l2(got.cpu().numpy(), raw[n])
+    return m

@@ -38,6 +38,24 @@ def test_dropin_surface_vs_oracle(P, W, H, fov, views):
         assert m[k] <= 2e-4, f"{k}: rel L2 {m[k]:.3e}"
 
 
+@pytest.mark.parametrize("P,W,H,fov,views", SIZES[:2])
+def test_default_render_node_vs_oracle(P, W, H, fov, views):
+    """the default render() node -- what an unchanged train.py gets -- faces the oracle at BASELINE's
+    sizes itself (round 4 checked it HIP-vs-HIP there): pending forwards launched as two-view batches with one depth sort
+    per pair, ONE batched backward for the six nodes, integer radii EXACT (the in-kernel activations are torch's bits)."""
+    import fullsize
+    m = fullsize.render_node_metrics(P, W, H, fov, views=views)
+    assert m["views"] == views and m["stats"]["lazy_views"] == views and m["stats"]["shared"] == views // 2
+    assert m["stats"]["launches"] == 1 and m["stats"]["batched_views"] == views
+    for k, pv in enumerate(m["per_view"]):
+        assert pv["radius_flips"] == 0 and pv["visibility_flips"] == 0, (k, pv)
+        for name, scale in (("color", 1.0), ("depth", 10.0), ("alpha", 1.0)):
+            assert pv[name + "_frac"] <= FLIP_FRAC and pv[name + "_max"] <= scale * FLIP_MAX, (k, name, pv)
+        assert pv["dL_dmeans2D"] is not None and pv["dL_dmeans2D"] <= 2e-4, (k, pv["dL_dmeans2D"])
+    for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+        assert m["grad_" + n] <= 2e-4, f"{n}: rel L2 {m['grad_' + n]:.3e}"
+
+
 # the fused path's knobs: (seg1_fraction, want_means2D).  (0.125, True): two binning rounds forced, first forward (no
 # prediction yet, the second round repairs many tiles), per-view screen-space gradients; ("auto", False): EXACTLY what
 # bench.py builds at the headline -- the rule of FusedRasterizer.fit_capacity (two rounds at 1M, prediction settled), no
@@ -57,7 +75,9 @@ def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views, seg1, m2d):
         assert all(pv["N_seg2"] == 0 for pv in m["per_view"]), "settled prediction: nothing left for the second round"
     flips = 0
     for k, pv in enumerate(m["per_view"]):
-        assert pv["radius_flips"] <= max(2, P // 100_000), (k, pv["radius_flips"])
+        # (round 5: the in-kernel activations are torch-ROCm's bits -- tests/test_gpu_round5.py -- so the integer radii of
+        # the benchmarked path are EXACT, not "within a few flips per view")
+        assert pv["radius_flips"] == 0, (k, pv["radius_flips"])
         flips += pv["radius_flips"]
         for name, scale in (("color", 1.0), ("depth", 10.0), ("alpha", 1.0)):
             assert pv[name + "_frac"] <= FLIP_FRAC and pv[name + "_max"] <= scale * FLIP_MAX, (k, name, pv)
@@ -76,7 +96,7 @@ def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views, seg1, m2d):
     for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
         assert m["grad_" + n] <= 2e-4, f"{n}: rel L2 {m['grad_' + n]:.3e}"
     assert m["stat_accum"] <= 2e-4
-    assert m["stat_denom_mismatch"] <= flips and m["stat_max_radii_mismatch"] <= 2 * flips + 4
+    assert m["stat_denom_mismatch"] == 0 and m["stat_max_radii_mismatch"] == 0
 
 
 def test_config2_500k_three_pairs_full_loop_with_the_stereo_loss():

@@ -42,3 +42,30 @@ def test_groups_schedule_never_exceeds_the_batch_limit():
         ref = fr2.render_batch([(c, k) for k, c in enumerate(cams)], bg)
     for a, b in zip(out, ref):
         assert torch.equal(a["render"], b["render"])
+
+
+def test_in_kernel_activations_are_torch_bits():
+    """the raw-parameter path evaluates exp / normalize / sigmoid inside its kernels; the reference feeds
+    its rasterizer torch.exp(_scaling), F.normalize(_rotation), torch.sigmoid(_opacity) (scene/gaussian_model.py:95-115).
+    Integer radii can only be exact when the two are the same BITS: the hook returns what the kernels compute."""
+    import ctypes as C
+    from binocular3dgs_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    P = 1_000_003
+    scaling = (-3.9 + 0.9 * torch.randn(P, 3, generator=g)).cuda()
+    rotation = torch.randn(P, 4, generator=g).cuda()
+    rotation[:5] = torch.tensor([[0.0, 0, 0, 0], [1e-20, 0, 0, 0], [1, 0, 0, 0], [3e18, 3e18, 3e18, 3e18], [-0.0, 2, 0, 0]]).cuda()
+    opacity = (3.0 * torch.randn(P, 1, generator=g)).cuda()
+    rp = _lib.B3gsRawParams()
+    rp.scaling, rp.rotation, rp.opacity = scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr()
+    s, q, o = torch.empty_like(scaling), torch.empty_like(rotation), torch.empty(P, device="cuda")
+    rc = _lib.lib().b3gs_debug_activations(P, C.byref(rp), s.data_ptr(), q.data_ptr(), o.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "b3gs_debug_activations")
+    want_s, want_q, want_o = torch.exp(scaling), torch.nn.functional.normalize(rotation), torch.sigmoid(opacity).reshape(-1)
+
+    def bits(t):
+        return t.view(torch.int32)
+    for name, got, want in (("exp", s, want_s), ("normalize", q, want_q), ("sigmoid", o, want_o)):
+        ok = (bits(got) == bits(want)) | (torch.isnan(got) & torch.isnan(want))
+        assert bool(ok.all()), (name, int((~ok).sum()), got[~ok][:4], want[~ok][:4])

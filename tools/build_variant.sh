@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../binocular3dgs_amd/csrc"
 mkdir -p ../../tools/ab /tmp/ab_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -mllvm -amdgpu-atomic-optimizer-strategy=None -Wall -Wno-unused-function"
 objs=""
-for f in api preprocess binning render optim loss densify knn; do
+for f in api preprocess binning render optim loss lossfn densify knn; do
   if [[ " $* " == *" $f.hip "* ]]; then
     /opt/rocm/bin/hipcc $FLAGS $extra -c $f.hip -o /tmp/ab_$name/$f.o
     objs="$objs /tmp/ab_$name/$f.o"

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 from binocular3dgs_amd import _lib, synth
 from binocular3dgs_amd.fused import FusedRasterizer
-P, W, H = 1_000_000, 800, 600
+P, W, H = (int(x) for x in os.environ.get("B3GS_TRACE_SHAPE", "1000000,800,600").split(","))
 model = synth.synth_model(P, seed=0, device="cuda", width=W, height=H)
 pairs = synth.synth_view_set(W, H, device="cuda")
 bg = torch.zeros(3, device="cuda")
@@ -42,7 +42,9 @@ t = buf[:n].reshape(-1, 4)
 t = t[t[:, 0] > 0]
 rs = (t[:, 1] >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF
 re = (t[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-it = t[:, 2].astype(np.int64)
+it = (t[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+n_half = ((t[:, 2] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64)
+n_pair = ((t[:, 2] >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.float64)
 t0 = rs.min()
 s_us, e_us = (rs - t0) / 100.0, (re - t0) / 100.0
 span = e_us.max()
@@ -61,6 +63,9 @@ if WHICH == "bwd":
     print("candidates evaluated %.3e, with a live lane %.3e (%.1f %%); live lanes per live candidate %.1f of 64 (%.1f %%)"
           % (it.sum(), nlive.sum(), 100.0 * nlive.sum() / max(it.sum(), 1), nlanes.sum() / max(nlive.sum(), 1),
              100.0 * nlanes.sum() / max(64.0 * nlive.sum(), 1)))
+    print("live candidates confined to one half of the quadrant (rows 0-3 / 4-7 / columns 0-3 / 4-7): %.1f %%; adjacent pairs "
+          "in complementary halves (what one loop trip could serve together): %.1f %% of the live candidates"
+          % (100.0 * n_half.sum() / max(nlive.sum(), 1), 100.0 * 2.0 * n_pair.sum() / max(nlive.sum(), 1)))
     frac = nlanes / np.maximum(64.0 * nlive, 1)
     w = nlive > 0
     print("per-wave live-lane fraction: p10 %.2f p50 %.2f p90 %.2f; waves below 1/2: %.1f %% holding %.1f %% of the live candidates"
@@ -71,7 +76,7 @@ print("waves started in the second half: %d, their mean duration %.1f us" % (lat
 # held by waves that had fewer candidates than the busiest wave of their tile
 full = buf[:n].reshape(-1, 4)
 if len(full) % 4 == 0:
-    wg_it = full[:, 2].astype(np.float64).reshape(-1, 4)
+    wg_it = (full[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.float64).reshape(-1, 4)
     wg_dur = ((full[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64) - ((full[:, 1] >> np.uint64(32)).astype(np.int64) & 0xFFFFFFFF)).astype(np.float64).reshape(-1, 4) / 100.0
     live = wg_it.max(1) > 0
     mx = wg_it[live].max(1, keepdims=True)
