@@ -111,7 +111,8 @@ EXPORTS = ("b3gs_abi_version", "b3gs_last_error", "b3gs_set_timing", "b3gs_timin
            # ABI 9: the training loop's statements one by one
            "b3gs_lossfn_workspace_floats", "b3gs_l1_loss_forward", "b3gs_l1_loss_backward", "b3gs_inverse_warp_forward",
            "b3gs_inverse_warp_backward", "b3gs_smooth_loss_forward", "b3gs_smooth_loss_backward", "b3gs_ssim_forward",
-           "b3gs_ssim_backward", "b3gs_opacity_decay", "b3gs_add_densification_stats", "b3gs_adam_step_at", "b3gs_debug_activations")
+           "b3gs_ssim_backward", "b3gs_opacity_decay", "b3gs_add_densification_stats", "b3gs_adam_step_at", "b3gs_debug_activations",
+           "b3gs_apply_staged_densify_stats")
 
 _lib = None
 
@@ -211,6 +212,8 @@ def lib():
                L.b3gs_smooth_loss_forward, L.b3gs_smooth_loss_backward, L.b3gs_ssim_forward, L.b3gs_ssim_backward,
                L.b3gs_opacity_decay, L.b3gs_add_densification_stats, L.b3gs_adam_step_at):
         fn.restype = C.c_int
+    L.b3gs_apply_staged_densify_stats.argtypes = [I64] + [V] * 9
+    L.b3gs_apply_staged_densify_stats.restype = C.c_int
     L.b3gs_debug_activations.argtypes = [I32, C.POINTER(B3gsRawParams), V, V, V, V]
     L.b3gs_debug_activations.restype = C.c_int
     L.b3gs_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

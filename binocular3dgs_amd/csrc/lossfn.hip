@@ -431,6 +431,30 @@ __global__ void __launch_bounds__(256) densify_stats_kernel(const float* __restr
   }
 }
 
+// Data-parallel tail (step.py): the chain rule folds a step's statistics into STAGING arrays; once the ranks' overflow
+// words have come back summed inside the first gradient range's all-reduce (`agreed`: != 0 when ANY rank overflowed), the
+// step's statistics are either added to the model's (agreed == 0) or thrown away -- and in the latter case this rank's
+// own sticky overflow word is raised too, so that its following steps are dropped like everybody else's until the host
+// has looked.  The staging arrays are left zero either way.
+__global__ void __launch_bounds__(256) apply_staged_stats_kernel(float* __restrict__ st_accum, float* __restrict__ st_denom,
+                                                                 float* __restrict__ st_maxrad, float* __restrict__ accum,
+                                                                 float* __restrict__ denom, float* __restrict__ maxrad, int64_t P,
+                                                                 const int32_t* __restrict__ agreed, int32_t* __restrict__ local_flag) {
+  const bool drop = *agreed != 0;
+  if (drop && local_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(local_flag, 1);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) {
+    const float a = st_accum[i], d = st_denom[i], r = st_maxrad[i];
+    if (a != 0.f || d != 0.f || r != 0.f) {
+      if (!drop) {
+        accum[i] += a;
+        denom[i] += d;
+        maxrad[i] = fmaxf(maxrad[i], r);
+      }
+      st_accum[i] = 0.f; st_denom[i] = 0.f; st_maxrad[i] = 0.f;
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t items, unsigned cap = 1024u) {
   const int64_t b = (items + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > (int64_t)cap ? cap : b));
@@ -558,4 +582,15 @@ extern "C" int b3gs_add_densification_stats(int64_t P, const float* viewspace_gr
   hipLaunchKernelGGL(densify_stats_kernel, dim3(grid_for(P, 8192u)), dim3(256), 0, (hipStream_t)stream, viewspace_grad, row_stride,
                      update_filter, P, xyz_gradient_accum, denom);
   return b3gs_launch_status("b3gs_add_densification_stats");
+}
+
+extern "C" int b3gs_apply_staged_densify_stats(int64_t P, float* staged_accum, float* staged_denom, float* staged_max_radii,
+                                               float* xyz_gradient_accum, float* denom, float* max_radii2D,
+                                               const int32_t* agreed_word, int32_t* local_overflow_flag, b3gs_stream_t stream) {
+  if (P < 0 || !agreed_word ||
+      (P > 0 && (!staged_accum || !staged_denom || !staged_max_radii || !xyz_gradient_accum || !denom || !max_radii2D)))
+    return b3gs_fail(B3GS_ERR_ARG, "b3gs_apply_staged_densify_stats", "NULL pointer or negative count");
+  hipLaunchKernelGGL(apply_staged_stats_kernel, dim3(grid_for(P > 0 ? P : 1, 8192u)), dim3(256), 0, (hipStream_t)stream, staged_accum,
+                     staged_denom, staged_max_radii, xyz_gradient_accum, denom, max_radii2D, P, agreed_word, local_overflow_flag);
+  return b3gs_launch_status("b3gs_apply_staged_densify_stats");
 }

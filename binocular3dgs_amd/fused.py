@@ -290,7 +290,7 @@ class FusedRasterizer:
             self._accumulate(pend, overwrite=False)
 
     def _accumulate(self, pend, overwrite: bool, grads=None, first: int = 0, count: Optional[int] = None,
-                    touched_rows: Optional[torch.Tensor] = None):
+                    touched_rows: Optional[torch.Tensor] = None, stats_target=None):
         """grads: a B3gsRawGrads whose pointers are indexed by the global Gaussian index (default: the parameters'
         .grad); [first, first+count): the Gaussians to process (default: all).  touched_rows (int64, ceil(P/64) words):
         sparse-row mode of B3gsRawGrads -- rows of Gaussians without any gradient are NOT stored, their bit is clear."""
@@ -305,8 +305,9 @@ class FusedRasterizer:
         count = self.P - first if count is None else count
         stats = None
         if getattr(m, "denom", None) is not None and m.denom.numel() == self.P:
-            stats = _lib.B3gsDensifyStats(m.xyz_gradient_accum.data_ptr(), m.denom.data_ptr(), m.max_radii2D.data_ptr(),
-                                          self.overflow_flag.data_ptr())
+            # stats_target: (accum, denom, max_radii) STAGING arrays of the data-parallel tail (step.py) instead of the model's
+            ta, td, tr = stats_target if stats_target is not None else (m.xyz_gradient_accum, m.denom, m.max_radii2D)
+            stats = _lib.B3gsDensifyStats(ta.data_ptr(), td.data_ptr(), tr.data_ptr(), self.overflow_flag.data_ptr())
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         for c0 in range(0, len(pend), MAX_BATCH):
             chunk = pend[c0:c0 + MAX_BATCH]
@@ -365,11 +366,11 @@ class FusedRasterizer:
         pend, self._deferred = self._deferred, None
         return pend
 
-    def accumulate_range(self, pend, grads, first: int, count: int, overwrite: bool = True):
+    def accumulate_range(self, pend, grads, first: int, count: int, overwrite: bool = True, stats_target=None):
         """Per-Gaussian chain rule of the views in `pend` (from take_deferred()) for the Gaussians
         [first, first+count) only, into `grads` (B3gsRawGrads, pointers indexed by the global Gaussian index).
         Call it for disjoint ranges covering all Gaussians."""
-        self._accumulate(pend, overwrite, grads, first, count)
+        self._accumulate(pend, overwrite, grads, first, count, stats_target=stats_target)
 
     def finish_views(self, pend, overwrite: bool = True):
         """Per-Gaussian chain rule of the views in `pend` (from take_deferred()) for ALL Gaussians into the parameters'

@@ -326,19 +326,30 @@ class RangeGradSlab:
         self.K = max(1, min(int(num_ranges), max(self.P, 1)))
         self.bounds = [(r * self.P) // self.K for r in range(self.K + 1)]
         self.row = sum(self.widths)
-        self.flat = torch.zeros(self.row * self.P, dtype=torch.float32, device=self.params[0].device)
+        # PAD floats behind range 0, part of ITS collective: word 0 carries this rank's overflow flag into the sum (a step
+        # is dropped by all replicas or by none without a collective of its own in front of the chain rule)
+        self.PAD = 64
+        self.flat = torch.zeros(self.row * self.P + self.PAD, dtype=torch.float32, device=self.params[0].device)
+        n0 = self.bounds[1] - self.bounds[0]
+        self.flag = self.flat[self.row * n0: self.row * n0 + 1]          # float: sum over the ranks of (overflow flag != 0)
+        self.flag_word = self.flag.view(torch.int32)                     # the same 4 bytes as the "!= 0" word the kernels read
 
     def rows(self, r: int):
         return self.bounds[r], self.bounds[r + 1] - self.bounds[r]
 
+    def _offset(self, r: int) -> int:
+        """first float of range r (ranges behind range 0 sit behind its pad)"""
+        return self.row * self.bounds[r] + (self.PAD if r > 0 else 0)
+
     def chunk(self, r: int) -> torch.Tensor:
         s, n = self.rows(r)
-        return self.flat[self.row * s: self.row * (s + n)]
+        o = self._offset(r)
+        return self.flat[o: o + self.row * n + (self.PAD if r == 0 else 0)]
 
     def grad_ptrs(self, r: int) -> List[int]:
         """address of the first row of range r for each tensor"""
         s, n = self.rows(r)
-        base, out, acc = self.flat.data_ptr() + 4 * self.row * s, [], 0
+        base, out, acc = self.flat.data_ptr() + 4 * self._offset(r), [], 0
         for w in self.widths:
             out.append(base + 4 * n * acc)
             acc += w
@@ -346,7 +357,7 @@ class RangeGradSlab:
 
     def tensor_view(self, r: int, k: int) -> torch.Tensor:
         s, n = self.rows(r)
-        off = self.row * s + n * sum(self.widths[:k])
+        off = self._offset(r) + n * sum(self.widths[:k])
         return self.flat[off: off + n * self.widths[k]].view((n,) + tuple(self.params[k].shape[1:]))
 
     def gather(self) -> List[torch.Tensor]:
@@ -449,6 +460,7 @@ class ViewShardedStep:
         # rows are valid.  After such a step `p.grad` holds STALE rows: use sparse_grad_rows=False to inspect it.
         self.sparse_grad_rows = bool(sparse_grad_rows)
         self.touched_rows = None
+        self._staged_stats = None         # pipelined data-parallel tail: (accum, denom, max_radii) staging arrays
         self._row_mask = None             # bitmap of the gradients now in the slab (None = dense)
         self._pending_views = None        # views whose chain rule reduce_and_update() still has to run (data parallel)
         self.tail_events = None           # bench: list that receives the HIP events of every pipelined tail
@@ -536,9 +548,9 @@ class ViewShardedStep:
 
     def reduce_and_update(self):
         """The exchange step of the data-parallel path (collectives over the gradient slab) + optimiser."""
-        self._agree_on_overflow()
-        if self.range_slab is not None:
+        if self.range_slab is not None:          # (the overflow word travels inside the first range's all-reduce)
             return self._reduce_and_update_pipelined()
+        self._agree_on_overflow()
         if self._pending_views is not None:          # chain rule of this rank's views, now that the overflow word is agreed
             # (the list is NOT cleared: a HIP graph that captured compute_grads() is replayed without re-running its Python)
             self.slab.rebind()
@@ -597,6 +609,24 @@ class ViewShardedStep:
         rs, fr, opt = self.range_slab, self.fused, self.optimizer
         group = group if group is not None else self.group
         collective = self._collective(group)
+        # One collective chain per step: this rank's overflow word rides in the pad of range 0 and comes back as the SUM over
+        # the ranks.  What must not happen before that sum is known -- the statistics of a step somebody else drops -- is
+        # staged: the chain rule folds the step's statistics into three zeroed arrays, b3gs_apply_staged_densify_stats adds
+        # them to the model's (or discards them, and raises this rank's sticky word) right behind the first range's
+        # all-reduce; the Adam launches of all ranges read the summed word.
+        m = self.model
+        staged = None
+        if fr is not None and getattr(m, "denom", None) is not None and m.denom.numel() == rs.P:
+            if self._staged_stats is None or self._staged_stats[0].numel() != rs.P:
+                self._staged_stats = tuple(torch.zeros(rs.P, dtype=torch.float32, device=rs.flat.device) for _ in range(3))
+            staged = self._staged_stats
+        if fr is not None:
+            rs.flag.copy_(fr.overflow_flag)          # int32 -> float: any set bit is a non-zero float
+        else:
+            rs.flag.zero_()
+        skip_keep = getattr(opt, "skip_flag", None)
+        if fr is not None and hasattr(opt, "skip_flag"):
+            opt.skip_flag = rs.flag_word
         ev = None
         if self.tail_events is not None:     # bench: issue / completion stamps of every range on the compute stream
             mk = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
@@ -610,19 +640,29 @@ class ViewShardedStep:
                                     rs.grad_ptrs(r), rs.widths):
                 setattr(gr, name, (ptr - 4 * w * first) if w else None)     # indexed by the GLOBAL Gaussian index
             if self._pending_views:
-                fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True)
+                fr.accumulate_range(self._pending_views, gr, first, count, overwrite=True, stats_target=staged)
             if ev:
                 ev["issued"][r].record()
             works.append(dist.all_reduce(rs.chunk(r), op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None)
         for r in range(rs.K):
             if works[r] is not None:
                 works[r].wait()                     # the compute stream waits for that range's all-reduce only
+            if r == 0 and staged is not None:
+                rc = _lib.lib().b3gs_apply_staged_densify_stats(
+                    rs.P, staged[0].data_ptr(), staged[1].data_ptr(), staged[2].data_ptr(), m.xyz_gradient_accum.data_ptr(),
+                    m.denom.data_ptr(), m.max_radii2D.data_ptr(), rs.flag_word.data_ptr(), fr.overflow_flag.data_ptr(),
+                    torch.cuda.current_stream(rs.flat.device).cuda_stream)
+                _lib.check(rc, "b3gs_apply_staged_densify_stats")
+            elif r == 0 and fr is not None:
+                fr.overflow_flag.bitwise_or_((rs.flag_word != 0).to(torch.int32))      # (no statistics: keep the word sticky)
             if ev:
                 ev["reduced"][r].record()
             if self.average and collective:
                 rs.chunk(r).div_(dist.get_world_size(group))
             first, count = rs.rows(r)
             opt.step_rows(first, count, rs.grad_ptrs(r), last=(r == rs.K - 1))
+        if fr is not None and hasattr(opt, "skip_flag"):
+            opt.skip_flag = skip_keep
         if ev:
             ev["end"].record()
             self.tail_events.append(ev)

@@ -456,6 +456,13 @@ int b3gs_opacity_decay(float* opacity, int64_t count, float factor, b3gs_stream_
  * xyz_gradient_accum += ||viewspace_grad[row, :2]|| and denom += 1.  row_stride: floats per row of viewspace_grad (3). */
 int b3gs_add_densification_stats(int64_t P, const float* viewspace_grad, int64_t row_stride, const uint8_t* update_filter,
                                  float* xyz_gradient_accum, float* denom, b3gs_stream_t stream);
+/* Data-parallel tail: statistics of a step staged by the chain rule (B3gsDensifyStats pointing at three zeroed [P] arrays)
+ * are added to the model's once the ranks agree that nobody overflowed -- `agreed_word` (device, any 32-bit pattern: the
+ * float SUM of the ranks' flags that travelled inside the first gradient range's all-reduce) == 0 -- and discarded
+ * otherwise, in which case *local_overflow_flag (may be NULL) gets bit 0 set.  The staging arrays are left zero. */
+int b3gs_apply_staged_densify_stats(int64_t P, float* staged_accum, float* staged_denom, float* staged_max_radii,
+                                    float* xyz_gradient_accum, float* denom, float* max_radii2D, const int32_t* agreed_word,
+                                    int32_t* local_overflow_flag, b3gs_stream_t stream);
 /* train.py:196-198 optimizer.step() for an optimiser that keeps torch.optim.Adam's state layout: b3gs_adam_step with the
  * step number given by the host (1-based, the value of state["step"] after its increment); no decay, no row mask. */
 int b3gs_adam_step_at(int32_t nseg, const B3gsAdamSegment* segs, int32_t step, float beta1, float beta2, float eps,
