@@ -166,13 +166,23 @@ def _worker_overflow(rank, world, port, out_dir, pipeline_ranges):
     def fn(k, pkg, spkg):
         gc, gd, ga = grads[mine[k]]
         return [(pkg["render"], gc), (pkg["rendered_depth"], gd), (pkg["rendered_alpha"], ga), (spkg["render"], gc)]
-    for _ in range(2):
-        st.step(pair_grad_fn=fn)
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append(int(t.numel()))
+        return real_all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
+    try:
+        for _ in range(2):
+            st.step(pair_grad_fn=fn)
+    finally:
+        dist.all_reduce = real_all_reduce
     torch.cuda.synchronize()
     after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     np.savez(os.path.join(out_dir, f"ovf{rank}.npz"), unchanged=bool(torch.equal(before, after)),
              denom=float(model.denom.sum()), accum=float(model.xyz_gradient_accum.sum()), flag=int(fr.overflow_flag.item()),
-             step=int(opt.step_count.item()))
+             step=int(opt.step_count.item()), collectives=np.array(calls))
     dist.destroy_process_group()
 
 
@@ -187,3 +197,9 @@ def test_an_overflow_on_one_rank_drops_the_step_and_its_statistics_on_every_rank
     for r in (r0, r1):
         assert bool(r["unchanged"]) and int(r["step"]) == 0 and int(r["flag"]) != 0
         assert float(r["denom"]) == 0.0 and float(r["accum"]) == 0.0
+        if pipeline_ranges:
+            # round 5: ONE collective chain per step -- the overflow word rides in the pad of the first gradient range (no
+            # 4-byte all-reduce in front of the chain rule); every collective of the two steps is a gradient range
+            assert len(r["collectives"]) == 2 * pipeline_ranges and int(r["collectives"].min()) > 1000, r["collectives"]
+        else:
+            assert sorted(set(r["collectives"].tolist()))[0] == 1          # (the un-pipelined tail keeps the 4-byte agreement)

@@ -26,3 +26,9 @@ d=json.load(open('gpurun_out/${tag}_default_bench_line.json'))
 print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('valu',{}).get('frac'), d.get('hbm_measured',{}).get('frac_of_peak'), {k:(v.get('iters_per_s') if isinstance(v,dict) else v) for k,v in d['extras'].items() if k!='dropin_what'})
 p=json.load(open('gpurun_out/${tag}_profiled_run_bench_line.json')); print('profiled run avg_launch_ms', p['roofline']['avg_launch_ms'], p['value'])"
 cat gpurun_out/${tag}_pmc_v.txt | tail -12
+# round 5: the reference's own loop with swapped imports only (bench_ref_schedule.py "unchanged"): device timeline + host profile;
+# the bin-first estimate
+python tools/unchanged_profile.py 500000 800 600 unchanged 2>&1 | grep -v -i warn > gpurun_out/${tag}_unchanged_500k_800x600_device_profile.txt
+python tools/unchanged_host_profile.py unchanged 2>&1 | grep -v -i warn | head -70 > gpurun_out/${tag}_unchanged_host_profile.txt
+python tools/binfirst_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_binfirst_probe.txt
+tools/prof_cmd.sh ${tag}_refsched_unchanged_500k bench_ref_schedule.py 500000,800,600 --surfaces=unchanged > gpurun_out/${tag}_refsched_unchanged_stdout.txt 2>&1
