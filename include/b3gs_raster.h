@@ -484,7 +484,7 @@ int b3gs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, 
 typedef struct B3gsDebugViews {
   const uint32_t* tiles_touched; /* [P] */
   const float* depths;           /* [P] */
-  const float* records;          /* [P,16] x,y,cxx,cxy,cyy,opacity,r,g,b,depth,ext_x,ext_y, 4 pad (never written) */
+  const float* records;          /* [P,16] x,y,cxx,cxy,cyy,opacity,r,g,b,depth,ext_x,ext_y, 4 pad (zero: written so that a slot is one unmasked 64-byte store) */
   const uint32_t* point_list;    /* [N] one word per instance, tile-major, depth-sorted: the Gaussian index, or
                                   *     (tile << packed_idx_bits) | index when packed_idx_bits >= 0 */
   const uint32_t* tile_ids;      /* [N] tile id per sorted instance; NULL when the words are packed */
