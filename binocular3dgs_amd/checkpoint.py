@@ -188,6 +188,11 @@ def restore(model, model_args: tuple, optimizer=None, optimizer_factory=None):
     model.denom = denom.detach().to(dev).clone()
     if optimizer is None and optimizer_factory is not None:
         optimizer = optimizer_factory(model)
+        # (the reference's order, scene/gaussian_model.py:90-92: training_setup() -- which zeroes the statistics -- first, the
+        # captured statistics after it)
+        model.max_radii2D = max_radii2D.detach().to(dev).clone()
+        model.xyz_gradient_accum = xyz_gradient_accum.detach().to(dev).clone()
+        model.denom = denom.detach().to(dev).clone()
     if optimizer is None:
         return None
     if isinstance(optimizer, torch.optim.Optimizer):

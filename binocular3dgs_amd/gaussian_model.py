@@ -196,8 +196,11 @@ class GaussianModel:
         classification launch, three prefix sums and one scatter launch (densify.py, csrc/densify.hip; the reference's row
         order; the split offsets are drawn with torch.randn on the device instead of torch.normal)."""
         from .densify import densify_and_prune
+        # `split_noise` (optional attribute, [2, P, 3] standard-normal samples addressed by the ORIGINAL Gaussian index, used
+        # once): replicas of a data-parallel run and lock-step tests hand every copy the same split offsets
+        noise, self.split_noise = getattr(self, "split_noise", None), None
         densify_and_prune(self, self.optimizer, max_grad, min_opacity, extent, max_screen_size,
-                          percent_dense=self.percent_dense)
+                          percent_dense=self.percent_dense, noise=noise)
         torch.cuda.empty_cache()
 
     def create_from_pcd(self, pcd, spatial_lr_scale: float):

@@ -27,7 +27,9 @@ class Adam(torch.optim.Adam):
         if weight_decay or amsgrad:
             raise NotImplementedError("binocular3dgs_amd.optim.Adam: weight_decay / amsgrad are not supported "
                                       "(scene/gaussian_model.py:163 uses neither)")
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        # (foreach / fused stay None, torch's defaults: state_dict() then carries exactly the hyper-parameters the reference's
+        # own torch.optim.Adam(l, lr=0.0, eps=1e-15) carries -- this class's step() consults neither)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
 
     def _init_state(self, p):
         st = self.state[p]

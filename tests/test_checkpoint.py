@@ -183,6 +183,41 @@ def test_restore_refuses_a_torch_optimizer_built_for_another_gaussian_count():
         assert p.shape[0] == m.get_xyz.shape[0] and np.array_equal(topt.state[p]["exp_avg"].numpy(), z[f"m_{n}"]), n
 
 
+def test_restore_with_training_args_is_the_reference_flow():
+    """train.py:41-43 / scene/gaussian_model.py:77-93: `restore(model_params, opt)` rebuilds the optimiser through
+    training_setup(opt) -- which zeroes the statistics -- and THEN installs the captured statistics and optimiser state."""
+    from types import SimpleNamespace
+    z, st = gold()
+    m = model_from_gold(z)
+    opt = FusedAdam(m.parameters(), lrs_model_order(st), eps=st["group_eps"])
+    load_moments(opt, z)
+    tup = m.capture(opt)
+    ta = SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                         position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+    m2 = GaussianModel(sh_degree=1)
+    m2.restore(tup, ta)
+    assert [g["name"] for g in m2.optimizer.param_groups] == list(REF)
+    assert isinstance(m2.optimizer, torch.optim.Adam)
+    assert torch.equal(m2.xyz_gradient_accum, m.xyz_gradient_accum) and m2.xyz_gradient_accum.abs().sum() > 0
+    assert torch.equal(m2.denom, m.denom) and torch.equal(m2.max_radii2D, m.max_radii2D)
+    by = dict(zip(st["group_names"], st["group_lrs"]))
+    for g in m2.optimizer.param_groups:
+        n = g["name"]
+        assert g["lr"] == by[n] and g["eps"] == st["group_eps"], n
+        e = m2.optimizer.state[g["params"][0]]
+        assert np.array_equal(e["exp_avg"].numpy(), z[f"m_{n}"]) and np.array_equal(e["exp_avg_sq"].numpy(), z[f"v_{n}"]), n
+        assert float(e["step"]) == 2.0
+    # the state_dict of the rebuilt optimiser is, key for key, what the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15) holds
+    sd = m2.optimizer.state_dict()
+    assert list(sd["param_groups"][0].keys()) == st["group_keys"]
+    ref_like = torch.optim.Adam([{"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 0.1, "name": "xyz"}], lr=0.0, eps=1e-15)
+    want = ref_like.state_dict()["param_groups"][0]
+    got = sd["param_groups"][0]
+    for k in want:
+        if k not in ("lr", "params"):
+            assert got[k] == want[k], (k, got[k], want[k])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scene"), reason="the reference tree exists in the build container only")
 def test_reference_restore_consumes_our_tuple():
     """Live check (build container): the reference's own GaussianModel.restore() takes the tuple this build captured and

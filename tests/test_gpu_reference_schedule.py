@@ -66,6 +66,42 @@ def test_reference_schedule_lockstep_hip_vs_oracle_backed_cpu():
     print(f"lockstep: worst rel-L2 {worst_rel:.2e}, worst |dPSNR| {worst_psnr:.2e} dB, P after densifications {densified}")
 
 
+def test_reference_schedule_lockstep_swapped_imports_vs_oracle_backed_cpu():
+    """Round 5: train.py:83-198 with the reference's statements and ONLY its imports swapped -- the loss
+    functions, inverse_warp_images, the GaussianModel methods, gaussians.optimizer, scene.getShiftedCamera each one HIP launch
+    behind the reference's signature (tests/ref_schedule.py::SwappedTrainer) -- LEADS; the oracle-backed CPU trainer (the same
+    loop with PyTorch ops, torch.optim.Adam and the torch densification) is handed its full state before every iteration and
+    both step.  210 iterations: decay start (60), binocular start and SH ramp (100, 200), three densifications.  Same bars as
+    the other lockstep runs: loss 1e-5 relative, IDENTICAL Gaussian counts, updated parameters 1e-3 relative L2, PSNR 0.01 dB."""
+    import ref_schedule as rs
+    torch.set_num_threads(8)
+    scene = rs.make_scene()
+    n = 210
+    hip, cpu = rs.SwappedTrainer(scene, iterations=ITERS, **KW), rs.Trainer(scene, "cpu", iterations=ITERS, **KW)
+    from binocular3dgs_amd.optim import Adam
+    assert isinstance(hip.opt, Adam) and isinstance(hip.opt, torch.optim.Adam)
+    worst_rel, worst_psnr, densified = 0.0, 0.0, []
+    for it in range(1, n + 1):
+        cpu.set_state(hip.get_state())
+        lh, lc = hip.step(it), cpu.step(it)
+        assert abs(lh - lc) <= 1e-5 * abs(lc) + 1e-7, (it, lh, lc)
+        assert (hip.last_newP is None) == (cpu.last_newP is None)
+        if hip.last_newP is not None:
+            assert int(hip.last_newP) == int(cpu.last_newP), (it, hip.last_newP, cpu.last_newP)
+            densified.append((it, int(hip.last_newP)))
+        a, b = _flat(hip), _flat(cpu)
+        assert a.shape == b.shape
+        rel = float((a - b).norm() / b.norm())
+        worst_rel = max(worst_rel, rel)
+        assert rel <= 1e-3, (it, rel)
+        if it % 30 == 0:
+            d = abs(hip.mean_psnr() - cpu.mean_psnr())
+            worst_psnr = max(worst_psnr, d)
+            assert d < 0.01, (it, d)
+    assert [i for i, _ in densified] == [100, 150, 200] and densified[-1][1] > densified[0][1]
+    print(f"lockstep swapped imports: worst rel-L2 {worst_rel:.2e}, worst |dPSNR| {worst_psnr:.2e} dB, P after densifications {densified}")
+
+
 @pytest.mark.parametrize("seg1,n", [pytest.param("auto", 160, id="rule"), pytest.param(0.125, 260, id="two_rounds_forced")])
 def test_reference_schedule_lockstep_fused_step_vs_oracle_backed_cpu(seg1, n):
     """The strict statement for the build's OWN step (row g1): FusedRasterizer pair batch + fused loss
