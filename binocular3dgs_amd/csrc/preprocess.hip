@@ -822,6 +822,14 @@ struct MultiViews {
 //           one LDS atomic per wave;
 //   phase 2 (compute, compacted): lane = list entry; the view loop runs only over the entry's touched views
 //           (row read + reset, chain rule, 23 gradients in registers), gradients written once.
+// (Round 5, measured and dropped: phase 1 at 131 MB in 69 us is neither a latency chain nor bound by cache-line look-ups --
+// all views' radii, then all views' rows in flight together (no control flow around the loads): 68.5 against 70.9 us; the
+// rows of a wave read as 160 consecutive 16-byte pieces and handed out through LDS, 40 line look-ups per (wave, view)
+// instead of 200: 78.9 us.  Probes: without the row reads 29.9 us (radii, statistics, list); without the statistics 62.7;
+// with ONE 8-byte read per row instead of five 69.7 -- the rows cost what their LINES cost, and with half of the Gaussians
+// visible at random nearly every line of the 6 x 40 MB is fetched: the pass already streams.  What would shrink it is
+// knowing the ~8 % touched rows without reading the others -- a bit per row set by the blend backward, one more atomic per
+// flush in the kernel that is half of the iteration; not built.)
 // ACC_PER_THREAD Gaussians per thread = 1024 per workgroup for big calls (1M Gaussians: 977 workgroups); calls over fewer
 // Gaussians -- a 100k scene, one range of the pipelined data-parallel tail -- take ONE per thread: with 1024 per workgroup
 // they were a quarter of a workgroup per CU and pure latency (100k Gaussians, 2 views: 76 us in the chain-rule kernel;
