@@ -97,6 +97,9 @@ class GaussianModel:
         self._accumulate_stats(grad, update_filter)
 
     def _accumulate_stats(self, grad, update_filter):
+        if self.xyz_gradient_accum.shape[0] != grad.shape[0] or self.denom.shape[0] != grad.shape[0]:
+            raise RuntimeError(f"add_densification_stats: the statistics hold {self.xyz_gradient_accum.shape[0]} rows for "
+                               f"{grad.shape[0]} Gaussians -- training_setup() (or restore()) allocates them, as in the reference")
         if update_filter.dtype != torch.bool:
             self.xyz_gradient_accum[update_filter] += torch.norm(grad[update_filter, :2], dim=-1, keepdim=True)
             self.denom[update_filter] += 1
