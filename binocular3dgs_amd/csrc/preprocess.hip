@@ -398,6 +398,11 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
         // a slot written 48 bytes out of 64 is a masked (read-modify-write) access at the memory side, a whole 64-byte slot
         // is not.  Same-box A/B at the headline: projection 240 -> 191 us per iteration (-20 %), 594-599 -> 610-613 iters/s,
         // for 16 more bytes per visible Gaussian and view.  (-DB3GS_PRE_PARTIAL_RECORD restores the 48-byte store.)
+        // tools/ubench/slot_store.hip, 6M slots: 48 of 64 bytes 156 us, these four 16-byte stores per lane 112 us, the
+        // quarters of a quad's four records transposed across its lanes (DPP) so that every instruction writes whole lines
+        // 64 us (a dense stream: 63).  The last step was built here too (64 VALU instructions per view, bit-identical
+        // records) and changes nothing -- 183.4 against 184.4 us: spread over this kernel's 180 us the stores are far from
+        // either rate; its time is the dependent chain per view at 5 waves per SIMD.  Not kept.
 #ifndef B3GS_PRE_PARTIAL_RECORD
         rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
