@@ -174,6 +174,29 @@ def test_adam_takes_gradients_torch_adam_would_take():
     oa.step(), ob2.step()
     for p, q in zip(mine, ref):
         assert _rel(p, q) <= 2e-6
+    # step hooks and the profiler range are torch's (this class skips torch's wrapper while neither is in use)
+    calls = []
+    small = torch.nn.Parameter(torch.ones(5, device="cuda"))
+    os_ = Adam([small], lr=0.1)
+    h1 = os_.register_step_pre_hook(lambda o, a, k: calls.append("pre"))
+    h2 = os_.register_step_post_hook(lambda o, a, k: calls.append("post"))
+    small.grad = torch.ones(5, device="cuda")
+    os_.step()
+    assert calls == ["pre", "post"] and float(small[0]) == pytest.approx(0.9, rel=1e-5)
+    h1.remove(), h2.remove()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        os_.step()
+        os_.zero_grad()
+    assert small.grad is None and any("Optimizer.step#Adam.step" in e.key for e in prof.key_averages())
+    assert calls == ["pre", "post"] and float(os_.state[small]["step"]) == 2.0
+    # a parameter replaced behind the optimiser's back (what a densification does) leaves the plan of checked tensors
+    new = torch.nn.Parameter(torch.ones(9, device="cuda"))
+    st = os_.state.pop(small)
+    os_.param_groups[0]["params"][0] = new
+    os_.state[new] = {"step": st["step"], "exp_avg": torch.zeros(9, device="cuda"), "exp_avg_sq": torch.zeros(9, device="cuda")}
+    new.grad = torch.ones(9, device="cuda")
+    os_.step()
+    assert [id(k) for k in os_._b3gs_plan] == [id(new)]
     # host parameters: no CPU path
     from binocular3dgs_amd._lib import B3gsError
     hp = torch.nn.Parameter(torch.zeros(3))
