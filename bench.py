@@ -69,6 +69,10 @@ def parse():
                          "ranks view by view (step.assign_views) -- value = global iters/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (drop-in, strong scaling, config 5)")
+    ap.add_argument("--dp-extras", type=int, default=int(os.environ.get("B3GS_BENCH_DP_EXTRAS", "0")),
+                    help="N > 1: also run the extras (strong scaling of configs[3] with split pairs over point-to-point "
+                         "messages, configs[4]).  Off by default: an extra that raises on ONE rank leaves the others inside a "
+                         "collective, and the headline line is printed last -- no multi-GPU node has run these paths yet")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # a PMC pass of this script over itself
     ap.add_argument("--no-optimizer", action="store_true")
@@ -581,7 +585,10 @@ def main():
         result = out
     # ---- extras: other workloads of BASELINE.json's configs, measured in the same process ---------------------------
     extras = {}
-    if not args.no_extras and not args.inner and args.path == "fused" and args.scaling == "weak" and args.views == 6:
+    if world > 1 and not args.dp_extras and not args.no_extras and rank == 0 and result is not None:
+        result["extras_skipped"] = "N > 1: the headline only (--dp-extras 1 adds strong_scaling_6_views and config5)"
+    if not args.no_extras and not args.inner and args.path == "fused" and args.scaling == "weak" and args.views == 6 \
+            and (world == 1 or args.dp_extras):
         del job
         torch.cuda.empty_cache()
         k = min(args.steps, 10)
