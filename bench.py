@@ -261,12 +261,22 @@ class Job:
             for t, s in zip(self._state_tensors(), self._snap):
                 t.copy_(s)
 
+    def overflow_on_any_rank(self) -> bool:
+        """FusedRasterizer.check_overflow() (grows this rank's buffers), agreed over the ranks: every rank repeats the step --
+        or leaves -- together, whatever its own views needed (a rank-local decision in front of a step with collectives
+        would strand the others)."""
+        over = 1 if (self.fused is not None and self.fused.check_overflow()) else 0
+        if self.dp:
+            t = torch.tensor([over], dtype=torch.int32, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            over = int(t.item())
+        return bool(over)
+
     def prepare(self, warmup):
         for _ in range(max(warmup, 1)):
             self.eager_step()
-        if self.fused is not None:
-            while self.fused.check_overflow():     # persistent binning capacity too small: grown, outside the timed region
-                self.eager_step()
+        while self.overflow_on_any_rank():         # persistent binning capacity too small: grown, outside the timed region
+            self.eager_step()
         self.snapshot()
         if not self.use_graph:
             return
@@ -354,7 +364,7 @@ class Job:
         finally:
             if was_enabled:
                 gc.enable()
-        if self.fused is not None and self.fused.check_overflow():
+        if self.overflow_on_any_rank():
             raise SystemExit("binning capacity overflow inside the timed region: result invalid")
         if self.dp:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
