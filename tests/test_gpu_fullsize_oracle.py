@@ -12,6 +12,8 @@ Two legs per size (tests/fullsize.py):
     densification statistics, and the tile lists: each tile's tight list is an order-preserving subsequence of the
     oracle's list and every dropped entry has alpha < 1/255 at every pixel of its tile.
 """
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -45,8 +47,10 @@ def test_default_render_node_vs_oracle(P, W, H, fov, views):
     per pair, ONE batched backward for the six nodes, integer radii EXACT (the in-kernel activations are torch's bits)."""
     import fullsize
     m = fullsize.render_node_metrics(P, W, H, fov, views=views)
-    assert m["views"] == views and m["stats"]["lazy_views"] == views and m["stats"]["shared"] == views // 2
-    assert m["stats"]["launches"] == 1 and m["stats"]["batched_views"] == views
+    assert m["views"] == views
+    if not any(k.startswith("B3GS_DROPIN_") for k in os.environ):     # (tools/switch_matrix.sh runs the numbers under every switch)
+        assert m["stats"]["lazy_views"] == views and m["stats"]["shared"] == views // 2
+        assert m["stats"]["launches"] == 1 and m["stats"]["batched_views"] == views
     for k, pv in enumerate(m["per_view"]):
         assert pv["radius_flips"] == 0 and pv["visibility_flips"] == 0, (k, pv)
         for name, scale in (("color", 1.0), ("depth", 10.0), ("alpha", 1.0)):
