@@ -40,6 +40,9 @@ import sys
 import tempfile
 import time
 
+# (the CPU oracle's OpenMP threads: sleeping waiters -- the GPU box's host is shared, spinning ones starve under its load)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
