@@ -69,7 +69,7 @@ def _count_launches(fn, steps=3):
     return n / steps
 
 
-def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, warmup: int = 8, seed: int = 0) -> dict:
+def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, warmup: int = 8, seed: int = 0, probe=None) -> dict:
     from binocular3dgs_amd import synth
     from binocular3dgs_amd.fused import FusedRasterizer
     from binocular3dgs_amd.fused_loss import binocular_loss_fused
@@ -301,6 +301,8 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
+    if probe is not None:                  # (tools/ab_interleaved.py: A/B measurements interleaved on the warmed-up step)
+        return probe(step)
     best = None
     for _ in range(3):                     # (the best of three runs: the two-view loop is a few hundred microseconds of
         #                                     host work per iteration on a host shared with other jobs)

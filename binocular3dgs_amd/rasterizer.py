@@ -451,9 +451,13 @@ _ORDER_HINT = os.environ.get("B3GS_DROPIN_ORDER_HINT", "1") != "0"
 # B3GS_DROPIN_LAZY=0: every render() launches its forward before it returns (see _LazyOut / _launch_forward)
 _LAZY_FWD = os.environ.get("B3GS_DROPIN_LAZY", "1") != "0"
 _LAZY_MAX = max(1, min(8, int(os.environ.get("B3GS_DROPIN_LAZY_MAX", "2"))))    # renders per batched forward (a pair)
-# B3GS_DROPIN_LAZY_IDLE=1: a render waits for its partner even when the device has nothing queued (default: it only waits
-# while the stream is busy -- an idle device gains more from starting this view's forward now than from the shared launch)
-_LAZY_WHEN_IDLE = os.environ.get("B3GS_DROPIN_LAZY_IDLE", "0") == "1"
+# B3GS_DROPIN_LAZY_IDLE=0: a render waits for its partner only while the stream is busy or while an adaptive rule (see
+# _RasterizeRaw.forward) finds that starting at once does not overlap anything.  Default 1 = always wait: measured INTERLEAVED
+# inside one process (tools/ab_interleaved.py lazy: blocks of 40 iterations cycling through the settings, medians of 12 --
+# separate runs on the shared host differ by +-15 %), train.py's loop at 500k Gaussians: always 793 / 576 iters/s
+# (504x378 / 800x600), the adaptive rule 744 / 543, never waiting 779 / 564; render() + fused loss: 893 / 700, 891 / 716, 787 / 632.
+# (The rule had become the default earlier in round 5 on the strength of separate runs.)
+_LAZY_WHEN_IDLE = os.environ.get("B3GS_DROPIN_LAZY_IDLE", "1") != "0"
 
 
 class _DropinState:

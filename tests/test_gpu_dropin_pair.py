@@ -74,11 +74,12 @@ def _forward_mode(request):
     returns, which is what the depth-order hint / adoption mechanism they pin is about."""
     import binocular3dgs_amd.rasterizer as R
     R._flush_pending()
+    old = R._LAZY_FWD, R._LAZY_WHEN_IDLE
     R._LAZY_FWD = request.node.name.startswith("test_lazy")
     R._LAZY_WHEN_IDLE = True      # (these tests pin the pending-forward machinery itself: it must engage on an idle device too)
     yield
     R._flush_pending()
-    R._LAZY_FWD, R._LAZY_WHEN_IDLE = True, False
+    R._LAZY_FWD, R._LAZY_WHEN_IDLE = old
 
 
 def _render_pair(model, cam, scam, bg, hint, inplace):
