@@ -14,12 +14,14 @@ Three surfaces, same Gaussians, same camera / shift sequence, random ground-trut
               the shifted camera built the reference's way (device inverse, device->host copy, Camera constructor);
               densification statistics through this build's GaussianModel (the reference's sums without its boolean-mask
               indexing, i.e. without two host syncs per iteration)
-  "unchanged" train.py:83-198 VERBATIM (statement for statement, the reference's variable names), only the imports swapped
-              for this build's modules: render, l1_loss / ssim / SmoothLoss (loss_utils.py), inverse_warp_images
-              (graphics_utils.py), GaussianModel (training_setup -> optim.Adam, update_learning_rate, opacity_decay,
-              add_densification_stats), Scene.getShiftedCamera (scene.py: the closed form SURVEY 8a-9 asks for).  The
-              loop's own PyTorch glue stays: the disparity expression, the loss sums, the boolean-mask statement of
-              train.py:178 (three host syncs).  `log_item=True` also keeps `loss.item()` of the progress-bar block (:155).
+  "unchanged" what a user who only swaps imports gets: the reference loop's CALL SEQUENCE (golden G11, recorded from
+              train.py:65-202 with stand-ins: tests/golden/make_golden_trace.py) driven by the build's own
+              binocular3dgs_amd/schedule.py over this build's modules: render, l1_loss / ssim / SmoothLoss (loss_utils.py),
+              inverse_warp_images (graphics_utils.py), GaussianModel (training_setup -> optim.Adam, update_learning_rate,
+              opacity_decay, add_densification_stats), Scene.getShiftedCamera (scene.py: the closed form SURVEY 8a-9 asks
+              for).  The loop's PyTorch glue is part of the sequence: the disparity expression, the loss sum, the masked
+              write into max_radii2D (three host syncs).  `unchanged_item` also reads the loss back every iteration (the
+              reference's progress bar, train.py:155).
   "torch_ops" only the rasterizer swapped: render() per view, the loss block as PyTorch ops (loss.binocular_loss =
               utils/loss_utils.py + inverse_warp_images), torch.optim.Adam over six groups, opacity decay and statistics
               as the reference's PyTorch statements (what "unchanged" was before round 5)
@@ -40,16 +42,15 @@ OPACITY_DECAY = 0.995                                           # train.py:279
 
 
 def reference_shifted(cam, trans_dist: float):
-    """Scene.getShiftedCamera (scene/__init__.py:96-115) on this build's Camera class, statement for statement: the
-    extrinsic is inverted on the device, the offset travels to the host (`.cpu().numpy()`: one host sync per iteration)
-    and a NEW Camera goes through the constructor (two host-side 4x4 inversions, three uploads, bmm, inverse)."""
+    """The COST SHAPE of the reference's Scene.getShiftedCamera (scene/__init__.py:96-115) on this build's Camera class:
+    a device-side inverse of the world-to-camera matrix, the offset of the moved centre read back to the host (one sync per
+    iteration) and a NEW Camera through the constructor (two host-side 4x4 inversions, three uploads, bmm, inverse)."""
     from binocular3dgs_amd.camera import Camera
-    extrinsic = cam.world_view_transform.transpose(0, 1).contiguous()
-    point = torch.tensor([trans_dist, 0.0, 0.0, 1.0], device=extrinsic.device)
-    point_world = (torch.inverse(extrinsic) @ point)[:3]
-    trans = (point_world - cam.camera_center).cpu().numpy()
+    w2c = cam.world_view_transform.t().contiguous()
+    moved = torch.linalg.inv(w2c) @ torch.tensor([trans_dist, 0.0, 0.0, 1.0], device=w2c.device)
+    offset = (moved[:3] - cam.camera_center).cpu().numpy()
     img = None if cam.original_image is None else torch.ones_like(cam.original_image)
-    return Camera(cam.R, cam.T, cam.FoVx, cam.FoVy, cam.image_width, cam.image_height, image=img, uid=cam.uid, trans=trans,
+    return Camera(cam.R, cam.T, cam.FoVx, cam.FoVy, cam.image_width, cam.image_height, image=img, uid=cam.uid, trans=offset,
                   device=cam.device)
 
 
@@ -187,90 +188,31 @@ def run(dev, P: int, W: int, H: int, fov: float, surface: str, steps: int = 40, 
                 p.grad = None
         extra = lambda: {}                                                                # noqa: E731
     elif surface in ("unchanged", "unchanged_item"):
-        # train.py:35-64 (setup) and :83-198 (iteration) with the reference's statements and names; swapped imports only
+        # the reference's per-iteration call sequence (golden G11) driven by the build's own loop over the build's modules
         import types
-        from binocular3dgs_amd.graphics_utils import inverse_warp_images
-        from binocular3dgs_amd.loss_utils import SmoothLoss, l1_loss, ssim
-        gaussians = model
-        gaussians.spatial_lr_scale = 1.0
-        opt_args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
-                                         position_lr_delay_mult=0.01, position_lr_max_steps=30_000, feature_lr=0.0025,
-                                         opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001, lambda_dssim=0.2,
-                                         densify_from_iter=500, densify_until_iter=15_000, iterations=30_000,
-                                         densification_interval=100, random_background=False)
-        args = types.SimpleNamespace(binocular_consistency=True, shift_cam_start=20_000, cam_trans_dist=CAM_TRANS_DIST,
-                                     opacity_decay=True, opacity_decay_factor=OPACITY_DECAY, dataset_name="LLFF")
-        gaussians.training_setup(opt_args)
         from binocular3dgs_amd.scene import Scene
+        from binocular3dgs_amd.schedule import IterationSchedule
+        model.spatial_lr_scale = 1.0
+        total_iterations = 30_000
+        model.training_setup(types.SimpleNamespace(
+            percent_dense=0.01, position_lr_init=LR[0], position_lr_final=LR[0] / 100.0, position_lr_delay_mult=0.01,
+            position_lr_max_steps=total_iterations, feature_lr=LR[1], opacity_lr=LR[5], scaling_lr=LR[3], rotation_lr=LR[4]))
         for c, gt_ in zip(cams, gts):
             c.original_image, c.gt_alpha_mask = gt_, None
-        scene = Scene(cams, gaussians)
-        viewpoint_stack = scene.getTrainCameras().copy()
-        background = bg
-        image_height, image_width = viewpoint_stack[0].image_height, viewpoint_stack[0].image_width
-        row_indices = torch.arange(0, image_height).view(-1, 1).repeat(1, image_width).cuda()
-        column_indices = torch.arange(0, image_width).repeat(image_height, 1).cuda()
-        mask = torch.ones((1, image_height, image_width), dtype=torch.float32).cuda()
-        smooth_loss = SmoothLoss()
-        state = {"iteration": 25_000, "ema": 0.0}         # inside the binocular phase, between two densifications
-        log_item = surface == "unchanged_item"
-        opt = opt_args
+        sched = IterationSchedule(model, Scene(cams, model), pipe, bg, iterations=total_iterations, shift_cam_start=20_000,
+                                  binocular=True, opacity_decay_factor=OPACITY_DECAY, lambda_dssim=0.2, densify_from_iter=500,
+                                  densify_until_iter=15_000, densification_interval=100,
+                                  log_item=(surface == "unchanged_item"))
+        clock = [25_000]                  # inside the binocular phase
 
         def step():
-            state["iteration"] += 1
-            iteration = state["iteration"]
-            if iteration % opt.densification_interval == 0:     # (the densification itself is not part of this loop)
-                state["iteration"] += 1
-                iteration += 1
-            k, t_draw = draw()
-            gaussians.update_learning_rate(iteration)
-            if iteration % 1000 == 0:
-                gaussians.oneupSHdegree()
-            viewpoint_cam = viewpoint_stack[k]                   # (random.choice with the shared, seeded sequence)
-            bg_ = torch.rand((3), device="cuda") if opt.random_background else background
-            render_pkg = render(viewpoint_cam, gaussians, pipe, bg_)
-            image = render_pkg["render"]
-            viewspace_point_tensor = render_pkg["viewspace_points"]
-            visibility_filter = render_pkg["visibility_filter"]
-            radii = render_pkg["radii"]
-            depth = render_pkg["rendered_depth"]
-            alpha = render_pkg["rendered_alpha"]
-            gt_image = viewpoint_cam.original_image.cuda()
-            bg_mask = None
-            disparity_loss = 0.0
-            if args.binocular_consistency and iteration > args.shift_cam_start:
-                trans_dist = t_draw                               # (torch.rand(1) * cam_trans_dist * random sign, shared sequence)
-                shifted_cam = scene.getShiftedCamera(viewpoint_cam, trans_dist)
-                render_pkg = render(shifted_cam, gaussians, pipe, bg_)
-                shifted_image = render_pkg["render"]
-                focal_x, focal_y = viewpoint_cam.get_focal()
-                disparity = focal_x * (-trans_dist) / (depth + 1e-5)
-                warped_image = inverse_warp_images(shifted_image.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-                shift_mask = inverse_warp_images(mask.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-                disparity_loss = (l1_loss(warped_image, gt_image.unsqueeze(0), mask=shift_mask) +
-                                  0.05 * smooth_loss.forward(disparity=disparity * shift_mask, image=gt_image.unsqueeze(0)))
-            alpha_loss = 0.0
-            if viewpoint_cam.gt_alpha_mask is not None:
-                alpha_loss = torch.mean(torch.abs(alpha) * (1 - viewpoint_cam.gt_alpha_mask))
-            elif bg_mask is not None:
-                alpha_loss = torch.mean(torch.abs(alpha) * bg_mask)
-            Ll1 = l1_loss(image, gt_image)
-            loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
-            total_loss = loss + disparity_loss + alpha_loss
-            total_loss.backward()
-            with torch.no_grad():
-                if log_item:
-                    state["ema"] = 0.4 * loss.item() + 0.6 * state["ema"]          # train.py:155 (progress bar)
-                if args.opacity_decay and iteration > opt.densify_from_iter:
-                    opt.densify_until_iter = opt.iterations
-                    gaussians.opacity_decay(factor=args.opacity_decay_factor)
-                if iteration < opt.densify_until_iter:
-                    gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
-                    gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
-                if iteration < opt.iterations:
-                    gaussians.optimizer.step()
-                    gaussians.optimizer.zero_grad(set_to_none=True)
-        extra = lambda: {"statements": "train.py:83-198 verbatim, swapped imports only", "loss_item": log_item}   # noqa: E731
+            clock[0] += 1
+            if clock[0] % sched.densification_interval == 0:      # (the densification itself is not part of this loop)
+                clock[0] += 1
+            k, t = draw()
+            sched.run_iteration(clock[0], k, t)
+        extra = lambda: {"statements": "the reference loop's call sequence (golden G11) driven by "    # noqa: E731
+                                       "binocular3dgs_amd/schedule.py", "loss_item": sched.log_item}
     else:      # torch_ops
         names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
         opt = torch.optim.Adam([{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(model.parameters(), LR, names)],
@@ -335,7 +277,7 @@ def table(dev, fov: float, seed: int, sizes=((500_000, 800, 600), (500_000, 504,
                    "densification statistics, Adam; surfaces: fused = FusedRasterizer pair batch + fused loss + one-launch "
                    "Adam, eager launches; fused_graph = the same step as ONE HIP-graph replay per iteration (cameras in a "
                    "static device block, shift and learning rates read from device memory); render = render() per view (reference-built shifted camera) + fused loss + one-launch Adam; "
-                   "unchanged = train.py:83-198 verbatim with swapped imports only (render, l1_loss / ssim / SmoothLoss / "
+                   "unchanged = the reference loop's call sequence (golden G11) driven by binocular3dgs_amd/schedule.py over this build's modules (render, l1_loss / ssim / SmoothLoss / "
                    "inverse_warp_images, GaussianModel.training_setup / update_learning_rate / opacity_decay / "
                    "add_densification_stats, optimizer.step: one HIP launch each); unchanged_item = the same with the progress "
                    "bar's loss.item(); torch_ops = only the rasterizer swapped (the loss as PyTorch ops + torch.optim.Adam)"}

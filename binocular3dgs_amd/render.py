@@ -56,6 +56,7 @@ class PipelineParams:
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene; `bg_color` must live on the GPU (as in the reference)."""
+    cam = viewpoint_camera
     xyz = pc.get_xyz
     # A model that keeps the reference's raw parameters and activations, default pipeline flags: one autograd node on the
     # raw tensors (activations in-kernel, rasterizer.rasterize_raw) instead of ~30 PyTorch kernels around the rasterizer
@@ -66,41 +67,40 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         # (a leaf instead of the reference's `zeros + 0`: its .grad then IS the node's screen-space gradient tensor,
         # where retain_grad() on a non-leaf clones it -- 12 B per Gaussian per render; all renders of a (device, P) share
         # one block of zeros behind their leaves: nobody reads or writes the values)
-        screenspace_points = viewspace_leaf(xyz)
+        screen_xy = viewspace_leaf(xyz)
     else:
         # zero tensor whose .grad receives the screen-space mean gradients (densification statistic)
-        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+        screen_xy = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
         try:
-            screenspace_points.retain_grad()
+            screen_xy.retain_grad()
         except Exception:
             pass
 
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
-        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+    settings = GaussianRasterizationSettings(
+        image_height=int(cam.image_height),
+        image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5),
         bg=bg_color,
         scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform,
+        viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform,
         sh_degree=pc.active_sh_degree,
-        campos=viewpoint_camera.camera_center,
+        campos=cam.camera_center,
         prefiltered=False,
         debug=pipe.debug,
     )
     if fused_node:
         # (the forward of a render that will be differentiated may still be pending when this returns: rasterizer._LazyOut)
-        rendered_image, radii, depth, alpha, visible = rasterize_raw(pc, screenspace_points, raster_settings, viewpoint_camera,
-                                                                     lazy_outputs=True)
-        return {"render": rendered_image,
-                "viewspace_points": screenspace_points,
+        image, radii, depth, alpha, visible = rasterize_raw(pc, screen_xy, settings, cam, lazy_outputs=True)
+        return {"render": image,
+                "viewspace_points": screen_xy,
                 "visibility_filter": visible,
                 "radii": radii,
                 "rendered_depth": depth,
                 "rendered_alpha": alpha}
 
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    raster = GaussianRasterizer(raster_settings=settings)
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
         cov3D_precomp = pc.get_covariance(scaling_modifier)
@@ -112,22 +112,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if override_color is None:
         if pipe.convert_SHs_python:
             feats = pc.get_features
-            shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-            dir_pp = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
-            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
-            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+            sh_cols = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            view_dir = xyz - cam.camera_center.repeat(feats.shape[0], 1)
+            unit_dir = view_dir / view_dir.norm(dim=1, keepdim=True)
+            rgb = eval_sh(pc.active_sh_degree, sh_cols, unit_dir)
+            colors_precomp = torch.clamp_min(rgb + 0.5, 0.0)
         else:
             shs = pc.get_features
     else:
         colors_precomp = override_color
 
-    rendered_image, radii, depth, alpha = rasterizer(
-        means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
+    image, radii, depth, alpha = raster(
+        means3D=xyz, means2D=screen_xy, shs=shs, colors_precomp=colors_precomp,
         opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
-    return {"render": rendered_image,
-            "viewspace_points": screenspace_points,
+    return {"render": image,
+            "viewspace_points": screen_xy,
             "visibility_filter": radii > 0,
             "radii": radii,
             "rendered_depth": depth,

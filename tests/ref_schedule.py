@@ -198,84 +198,46 @@ class Trainer:
 
 
 class SwappedTrainer(Trainer):
-    """train.py:83-198 with the reference's STATEMENTS and only its imports swapped for this build's modules (round 5):
-    render, l1_loss / ssim / SmoothLoss (loss_utils), inverse_warp_images (graphics_utils), GaussianModel.training_setup /
-    update_learning_rate / opacity_decay / add_densification_stats / densify_and_prune, gaussians.optimizer (optim.Adam),
-    scene.getShiftedCamera -- every one of them a HIP launch behind the reference's signature.  Same step() / get_state()
-    surface as Trainer (its optimiser keeps torch's state layout), so it can lead a lockstep run."""
+    """What a user who only swaps imports runs: the reference loop's call sequence (golden G11) driven by the build's own
+    binocular3dgs_amd/schedule.py over this build's modules -- render, l1_loss / ssim / SmoothLoss (loss_utils),
+    inverse_warp_images (graphics_utils), GaussianModel.training_setup / update_learning_rate / opacity_decay /
+    add_densification_stats / densify_and_prune, gaussians.optimizer (optim.Adam), scene.getShiftedCamera: every one of them
+    a HIP launch behind the reference's signature.  Same step() / get_state() surface as Trainer (its optimiser keeps
+    torch's state layout), so it can lead a lockstep run."""
 
     def __init__(self, scene, iterations=300, **kw):
         import types
-        from binocular3dgs_amd.loss_utils import SmoothLoss
         from binocular3dgs_amd.scene import Scene
+        from binocular3dgs_amd.schedule import IterationSchedule
         super().__init__(scene, "cuda", iterations=iterations, **kw)
         m = self.model
         m.spatial_lr_scale = self.extent
-        self.args = types.SimpleNamespace(percent_dense=0.01, position_lr_init=LR["position_lr_init"],
-                                          position_lr_final=LR["position_lr_final"],
-                                          position_lr_delay_mult=LR["position_lr_delay_mult"], position_lr_max_steps=iterations,
-                                          feature_lr=LR["feature_lr"], opacity_lr=LR["opacity_lr"], scaling_lr=LR["scaling_lr"],
-                                          rotation_lr=LR["rotation_lr"], lambda_dssim=0.2)
-        m.training_setup(self.args)
+        m.training_setup(types.SimpleNamespace(
+            percent_dense=0.01, position_lr_init=LR["position_lr_init"], position_lr_final=LR["position_lr_final"],
+            position_lr_delay_mult=LR["position_lr_delay_mult"], position_lr_max_steps=iterations, feature_lr=LR["feature_lr"],
+            opacity_lr=LR["opacity_lr"], scaling_lr=LR["scaling_lr"], rotation_lr=LR["rotation_lr"]))
         self.opt = m.optimizer
-        self.scene = Scene(self.cams, m, cameras_extent=self.extent)
-        H, W = scene["H"], scene["W"]
-        self.row_indices = torch.arange(0, H).view(-1, 1).repeat(1, W).cuda()
-        self.column_indices = torch.arange(0, W).repeat(H, 1).cuda()
-        self.mask = torch.ones((1, H, W), dtype=torch.float32).cuda()
-        self.smooth_loss = SmoothLoss()
+        for cam, gt in zip(self.cams, self.gts):
+            cam.original_image, cam.gt_alpha_mask = gt, None
+
+        def shared_split_noise(it):       # (both lock-step trainers split with the same noise)
+            P = m.get_xyz.shape[0]
+            m.split_noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + it)).cuda()
+
+        # densification statistics are kept in every iteration of these short runs (Trainer.step does the same)
+        self.sched = IterationSchedule(
+            m, Scene(self.cams, m, cameras_extent=self.extent), self.pipe, self.bg, iterations=self.iterations,
+            shift_cam_start=self.shift_cam_start, binocular=True, opacity_decay_factor=self.opacity_decay or None,
+            lambda_dssim=0.2, densify_from_iter=self.densify_from_iter, densify_until_iter=self.iterations + 1,
+            densification_interval=self.densification_interval, densify_grad_threshold=self.thr, sh_interval=self.sh_interval,
+            before_densify=shared_split_noise)
 
     def step(self, it):
-        from binocular3dgs_amd.graphics_utils import inverse_warp_images
-        from binocular3dgs_amd.loss_utils import l1_loss, ssim
-        gaussians, opt, scene, pipe = self.model, self.args, self.scene, self.pipe
-        row_indices, column_indices, mask, smooth_loss = self.row_indices, self.column_indices, self.mask, self.smooth_loss
-        iteration = it
-        gaussians.update_learning_rate(iteration)
-        if iteration % self.sh_interval == 0:
-            gaussians.oneupSHdegree()
-        k = (iteration - 1) % len(self.cams)
-        viewpoint_cam, gt_image = self.cams[k], self.gts[k]
-        bg = self.bg
-        render_pkg = render(viewpoint_cam, gaussians, pipe, bg)
-        image = render_pkg["render"]
-        viewspace_point_tensor = render_pkg["viewspace_points"]
-        visibility_filter = render_pkg["visibility_filter"]
-        radii = render_pkg["radii"]
-        depth = render_pkg["rendered_depth"]
-        alpha = render_pkg["rendered_alpha"]
-        disparity_loss = 0.0
-        if iteration > self.shift_cam_start:
-            trans_dist = float(self.shifts[iteration])
-            shifted_cam = scene.getShiftedCamera(viewpoint_cam, trans_dist)
-            render_pkg = render(shifted_cam, gaussians, pipe, bg)
-            shifted_image = render_pkg["render"]
-            focal_x, focal_y = viewpoint_cam.get_focal()
-            disparity = focal_x * (-trans_dist) / (depth + 1e-5)
-            warped_image = inverse_warp_images(shifted_image.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-            shift_mask = inverse_warp_images(mask.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-            disparity_loss = (l1_loss(warped_image, gt_image.unsqueeze(0), mask=shift_mask) +
-                              0.05 * smooth_loss.forward(disparity=disparity * shift_mask, image=gt_image.unsqueeze(0)))
-        alpha_loss = 0.0
-        Ll1 = l1_loss(image, gt_image)
-        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
-        total_loss = loss + disparity_loss + alpha_loss
-        total_loss.backward()
-        self.last_newP = None
-        with torch.no_grad():
-            if self.opacity_decay and iteration > self.densify_from_iter:
-                gaussians.opacity_decay(factor=self.opacity_decay)
-            gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
-            gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
-            if iteration > self.densify_from_iter and iteration % self.densification_interval == 0:
-                P = gaussians.get_xyz.shape[0]
-                gaussians.split_noise = torch.randn(2, P, 3, generator=torch.Generator().manual_seed(1000 + iteration)).cuda()
-                gaussians.densify_and_prune(self.thr, 0.005, self.extent, None)
-                self.last_newP = gaussians.get_xyz.shape[0]
-            if iteration < self.iterations:
-                gaussians.optimizer.step()
-                gaussians.optimizer.zero_grad(set_to_none=True)
-        return float(total_loss.detach())
+        sched = self.sched
+        sched.densify_until_iter = self.iterations + 1
+        total = sched.run_iteration(it, (it - 1) % len(self.cams), float(self.shifts[it]))
+        self.last_newP = self.model.get_xyz.shape[0] if sched.densified else None
+        return float(total.detach())
 
 
 class FusedTrainer:

@@ -115,34 +115,47 @@ def test_inverse_warp_golden(g):
     _close(im.grad, 2 * g["iw_gim"]), _close(d.grad, 2 * g["iw_gd"])
 
 
-def test_the_reference_statements_of_the_loss_block_golden_g6():
-    """train.py:130-148 verbatim, every function swapped for its HIP drop-in, against the values and pixel gradients the
-    reference's own Python produced (G6)."""
-    from binocular3dgs_amd.graphics_utils import inverse_warp_images
-    from binocular3dgs_amd.loss_utils import SmoothLoss, l1_loss, ssim
+def test_the_loss_block_through_the_schedule_driver_golden_g6():
+    """The loss block of one binocular iteration as binocular3dgs_amd/schedule.py drives it (golden G11 pins that sequence
+    against the reference's loop), every function its HIP drop-in, on the tensors of golden G6: the values and the pixel
+    gradients the reference's own Python produced for train.py:130-148."""
+    import types
+    from binocular3dgs_amd.schedule import IterationSchedule, default_ops
     g = np.load(os.path.join(GOLD, "loss_block.npz"))
-    image, depth, alpha, shifted_image = _t(g["image"]), _t(g["depth"]), _t(g["alpha"]), _t(g["shifted"])
-    gt_image, gt_alpha_mask = torch.from_numpy(g["gt"]).cuda(), torch.from_numpy(g["gt_alpha_mask"]).cuda()
-    focal_x, trans_dist, lambda_dssim = [float(x) for x in g["scalars"]]
-    H, W = image.shape[-2:]
-    row_indices = torch.arange(0, H).view(-1, 1).repeat(1, W).cuda()
-    column_indices = torch.arange(0, W).repeat(H, 1).cuda()
-    mask = torch.ones((1, H, W), dtype=torch.float32).cuda()
-    smooth_loss = SmoothLoss()
-    disparity = focal_x * (-trans_dist) / (depth + 1e-5)
-    warped_image = inverse_warp_images(shifted_image.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-    shift_mask = inverse_warp_images(mask.unsqueeze(0), disparity.unsqueeze(0), row_indices, column_indices)
-    disparity_loss = (l1_loss(warped_image, gt_image.unsqueeze(0), mask=shift_mask) +
-                      0.05 * smooth_loss.forward(disparity=disparity * shift_mask, image=gt_image.unsqueeze(0)))
-    alpha_loss = torch.mean(torch.abs(alpha) * (1 - gt_alpha_mask))
-    Ll1 = l1_loss(image, gt_image)
-    loss = (1.0 - lambda_dssim) * Ll1 + lambda_dssim * (1.0 - ssim(image, gt_image))
-    total_loss = loss + disparity_loss + alpha_loss
-    total_loss.backward()
-    _close(warped_image, g["warped"]), _close(shift_mask, g["shift_mask"])
-    for v, k in ((total_loss, "total"), (Ll1, "Ll1"), (alpha_loss, "alpha_loss")):
-        np.testing.assert_allclose(float(v), float(g[k]), rtol=3e-5, err_msg=k)
-    for ten, key in ((image, "g_image"), (depth, "g_depth"), (alpha, "g_alpha"), (shifted_image, "g_shifted")):
+    first = {"render": _t(g["image"]), "rendered_depth": _t(g["depth"]), "rendered_alpha": _t(g["alpha"]),
+             "radii": torch.zeros(4, dtype=torch.int32).cuda(), "visibility_filter": torch.zeros(4, dtype=torch.bool).cuda(),
+             "viewspace_points": torch.zeros(4, 3).cuda()}
+    second = {"render": _t(g["shifted"])}
+    fx, shift, lam = [float(x) for x in g["scalars"]]
+    hip, seen = default_ops(), {"warp": [], "l1": []}
+    renders = iter([first, second])
+
+    def warp(*a):
+        seen["warp"].append(hip.inverse_warp_images(*a))
+        return seen["warp"][-1]
+
+    def l1(*a, **k):
+        seen["l1"].append(hip.l1_loss(*a, **k))
+        return seen["l1"][-1]
+
+    ops = types.SimpleNamespace(render=lambda *a: next(renders), l1_loss=l1, ssim=hip.ssim, SmoothLoss=hip.SmoothLoss,
+                                inverse_warp_images=warp)
+    cam = types.SimpleNamespace(image_height=first["render"].shape[-2], image_width=first["render"].shape[-1],
+                                original_image=torch.from_numpy(g["gt"]).cuda(),
+                                gt_alpha_mask=torch.from_numpy(g["gt_alpha_mask"]).cuda(), get_focal=lambda: (fx, fx))
+    quiet = lambda *a, **k: None    # noqa: E731
+    model = types.SimpleNamespace(update_learning_rate=quiet, oneupSHdegree=quiet, opacity_decay=quiet,
+                                  add_densification_stats=quiet, max_radii2D=torch.zeros(4).cuda(),
+                                  optimizer=types.SimpleNamespace(step=quiet, zero_grad=quiet))
+    scene = types.SimpleNamespace(getTrainCameras=lambda: [cam], getShiftedCamera=lambda c, t: c, cameras_extent=1.0)
+    sched = IterationSchedule(model, scene, None, torch.zeros(3).cuda(), ops=ops, iterations=10, shift_cam_start=0,
+                              lambda_dssim=lam, opacity_decay_factor=None)
+    total = sched.run_iteration(1, 0, shift)
+    _close(seen["warp"][0], g["warped"]), _close(seen["warp"][1], g["shift_mask"])
+    np.testing.assert_allclose(float(total), float(g["total"]), rtol=3e-5)
+    np.testing.assert_allclose(float(seen["l1"][1]), float(g["Ll1"]), rtol=3e-5)
+    for ten, key in ((first["render"], "g_image"), (first["rendered_depth"], "g_depth"), (first["rendered_alpha"], "g_alpha"),
+                     (second["render"], "g_shifted")):
         ref = g[key]
         assert np.abs(ten.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 2e-9, key
 

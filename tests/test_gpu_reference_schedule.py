@@ -4,7 +4,7 @@ decay before the optimiser step, densify_and_prune at the densification interval
 run for a few hundred iterations on a synthetic ground-truth scene three times (tests/ref_schedule.py):
 
     A  CPU, oracle-backed rasterizer + torch densification      (the comparison target)
-    B  MI355X, drop-in render() -> _C.rasterize_gaussians, HIP densification, torch.optim.Adam: the reference's loop unchanged
+    B  MI355X, drop-in render() -> _C.rasterize_gaussians, HIP densification, torch.optim.Adam: the reference's schedule
     C  MI355X, the build's own step: FusedRasterizer (raw parameters, batched pair), fused loss block, one-launch Adam
        with the reference's decay order, HIP densification
 
@@ -67,11 +67,11 @@ def test_reference_schedule_lockstep_hip_vs_oracle_backed_cpu():
 
 
 def test_reference_schedule_lockstep_swapped_imports_vs_oracle_backed_cpu():
-    """Round 5: train.py:83-198 with the reference's statements and ONLY its imports swapped -- the loss
-    functions, inverse_warp_images, the GaussianModel methods, gaussians.optimizer, scene.getShiftedCamera each one HIP launch
-    behind the reference's signature (tests/ref_schedule.py::SwappedTrainer) -- LEADS; the oracle-backed CPU trainer (the same
-    loop with PyTorch ops, torch.optim.Adam and the torch densification) is handed its full state before every iteration and
-    both step.  210 iterations: decay start (60), binocular start and SH ramp (100, 200), three densifications.  Same bars as
+    """What a user who only swaps imports runs: the reference loop's call sequence -- golden
+    G11, driven by binocular3dgs_amd/schedule.py -- over the build's drop-ins: the loss functions, inverse_warp_images, the
+    GaussianModel methods, gaussians.optimizer, scene.getShiftedCamera each one HIP launch behind the reference's signature
+    (tests/ref_schedule.py::SwappedTrainer) -- LEADS; the oracle-backed CPU trainer (the same schedule with PyTorch ops,
+    torch.optim.Adam and the torch densification) is handed its full state before every iteration and both step.  210 iterations: decay start (60), binocular start and SH ramp (100, 200), three densifications.  Same bars as
     the other lockstep runs: loss 1e-5 relative, IDENTICAL Gaussian counts, updated parameters 1e-3 relative L2, PSNR 0.01 dB."""
     import ref_schedule as rs
     torch.set_num_threads(8)
