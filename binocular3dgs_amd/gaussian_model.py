@@ -106,14 +106,15 @@ class GaussianModel:
             return
         if grad.is_cuda and grad.dtype == torch.float32 and grad.dim() == 2 and grad.stride(1) == 1 and \
                 self.xyz_gradient_accum.is_contiguous() and self.denom.is_contiguous():
-            from . import _lib
-            f = update_filter if update_filter.is_contiguous() else update_filter.contiguous()
-            from ._cuda import device_guard, raw_stream
-            with device_guard(grad.device):
-                rc = _lib.lib().b3gs_add_densification_stats(grad.shape[0], grad.data_ptr(), grad.stride(0), f.data_ptr(),
-                                                             self.xyz_gradient_accum.data_ptr(), self.denom.data_ptr(),
-                                                             raw_stream(grad.device))
-            _lib.check(rc, "b3gs_add_densification_stats")
+            # (the compiled entry checks that the mask has one element per row and lives on the gradient's device --
+            # a short mask raises IndexError like the reference's indexing, a host mask raises instead of being read as a
+            # device pointer)
+            from . import _C
+            from .rasterizer import touch_pending
+            touch_pending(update_filter)
+            if update_filter.device != grad.device:
+                update_filter = update_filter.to(grad.device)        # (the reference accepts a CPU mask)
+            _C.add_densification_stats(grad, update_filter, self.xyz_gradient_accum, self.denom)
             return
         m = update_filter.unsqueeze(-1)
         n = torch.norm(grad[:, :2], dim=-1, keepdim=True)
@@ -169,15 +170,8 @@ class GaussianModel:
         if not o.is_cuda:
             o.data = self.inverse_opacity_activation(self.get_opacity * factor)
             return
-        from . import _lib
-        d = o.data
-        if not (d.is_contiguous() and d.dtype == torch.float32):
-            raise _lib.B3gsError("opacity_decay: _opacity must be a contiguous float32 tensor")
-        from ._cuda import device_guard, raw_stream
-        with device_guard(d.device):
-            rc = _lib.lib().b3gs_opacity_decay(d.data_ptr(), d.numel(), float(factor), raw_stream(d.device))
-        _lib.check(rc, "b3gs_opacity_decay")
-        torch.autograd.graph.increment_version(o)
+        from . import _C
+        _C.opacity_decay(o, float(factor))        # (in place through the raw pointer; bumps the version counter)
 
     def reset_opacity(self):
         """scene/gaussian_model.py:210-213 (commented out of this fork's train.py:188-193, kept for the interface):

@@ -1,5 +1,5 @@
 """`torch.optim.Adam`-compatible optimiser whose `step()` is ONE launch of libb3gs_raster.so for all parameter groups
-(`b3gs_adam_step_at`, csrc/optim.hip) -- what sits behind `gaussians.optimizer.step()` / `.zero_grad(set_to_none=True)` of
+(`b3gs_adam_step_at`, csrc/optim.hip, reached through the compiled `_C` module: csrc/host/optim.cpp) -- what sits behind `gaussians.optimizer.step()` / `.zero_grad(set_to_none=True)` of
 an unchanged train.py:196-198 and behind the optimiser-state surgery of scene/gaussian_model.py:258-340.
 
 It IS a torch.optim.Adam (subclass): `param_groups` (the reference's six named groups, scene/gaussian_model.py:154-161),
@@ -16,8 +16,7 @@ import torch
 from torch.optim.optimizer import _global_optimizer_post_hooks as _global_post_hooks
 from torch.optim.optimizer import _global_optimizer_pre_hooks as _global_pre_hooks
 
-from . import _lib
-from ._cuda import device_guard, raw_stream
+from . import _C, _lib
 
 
 def _hooked_step(self, closure):
@@ -127,8 +126,6 @@ class Adam(torch.optim.Adam):
                     ent = plan[p] = (p.data_ptr(), st, m, v)
                 if g.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients")
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous()
                 step_t = st["step"]
                 step_t += 1
                 key = (p.device.index, b1, b2, eps, int(step_t))
@@ -136,35 +133,10 @@ class Adam(torch.optim.Adam):
                 if b is None:
                     b = buckets[key] = []
                 b.append((p, g, ent[2], ent[3], lr))
-        L = _lib.lib()
-        cache = self.__dict__.setdefault("_b3gs_segs", {})
-        for (di, b1, b2, eps, step), segs_py in buckets.items():
-            dev = torch.device("cuda", di)
-            stream = raw_stream(dev)
-            with device_guard(dev):
-                for c0 in range(0, len(segs_py), 8):
-                    chunk = segs_py[c0:c0 + 8]
-                    # the ctypes array of a chunk is kept while its tensors stay where they are (a field write costs ~1 us:
-                    # nine fields x six tensors per step otherwise); only gradient pointers and learning rates move
-                    sig = tuple((p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, _g, m, v, _lr in chunk)
-                    ent = cache.get((di, c0))
-                    if ent is None or ent[0] != sig:
-                        segs = (_lib.B3gsAdamSegment * len(chunk))()
-                        for k, (p, _g, m, v, _lr) in enumerate(chunk):
-                            n = p.numel()
-                            s = segs[k]
-                            s.param = (p.data_ptr() or None) if n else None
-                            s.exp_avg, s.exp_avg_sq = ((m.data_ptr() or None), (v.data_ptr() or None)) if n else (None, None)
-                            s.count, s.row_len, s.first_row, s.lr_dev = n, 0, 0, None
-                        ent = cache[(di, c0)] = (sig, segs)
-                    segs = ent[1]
-                    for k, (p, g, _m, _v, lr) in enumerate(chunk):
-                        segs[k].grad = (g.data_ptr() or None) if p.numel() else None
-                        segs[k].lr = lr
-                    _lib.check(L.b3gs_adam_step_at(len(chunk), segs, step, b1, b2, eps, stream), "b3gs_adam_step_at")
-        # the kernel wrote through raw pointers: autograd's version counters have to hear about it (saved-tensor checks;
-        # the depth-order hint of rasterizer._RasterizeRaw keys on the position tensor's version)
-        for segs_py in buckets.values():
-            for p, _g, _m, _v, _lr in segs_py:
-                torch.autograd.graph.increment_version(p)
+        # one call into the compiled module per bucket (csrc/host/optim.cpp: adam_step_at fills the B3gsAdamSegment array, launches
+        # up to 8 tensors at a time and bumps the parameters' version counters -- the kernel wrote through raw pointers, and
+        # saved-tensor checks / the depth-order hint of rasterizer._RasterizeRaw key on the position tensor's version)
+        for (_di, b1, b2, eps, step), segs_py in buckets.items():
+            _C.adam_step_at([e[0] for e in segs_py], [e[1] for e in segs_py], [e[2] for e in segs_py], [e[3] for e in segs_py],
+                            [e[4] for e in segs_py], step, b1, b2, eps)
         return loss

@@ -8,25 +8,27 @@
                                             opacities=, scales=, rotations=, cov3D_precomp=)  (:85-93)
 
 and the two `_C` functions of the un-vendored extension:
-`_C.rasterize_gaussians(...)`, `_C.rasterize_gaussians_backward(...)` (+ `_C.mark_visible`).
-The arithmetic lives in libb3gs_raster.so (hand-written HIP for gfx950) behind the C ABI of
-include/b3gs_raster.h; this module only moves pointers.  No CPU / PyTorch fallback exists:
-CPU tensors raise.
+`_C.rasterize_gaussians(...)`, `_C.rasterize_gaussians_backward(...)` (+ `_C.mark_visible`) -- `_C` is the COMPILED module
+binocular3dgs_amd/_C*.so (csrc/host/*.cpp: host-only C++ against the torch headers, like the reference's own extension),
+which also holds the autograd node of this surface and the launch assembly of the raw-parameter node below; it calls
+libb3gs_raster.so (hand-written HIP for gfx950) through the C ABI of include/b3gs_raster.h.  This file keeps POLICY only:
+which renders share a launch, which capacity a sync-free forward gets, when its N is checked.  No CPU / PyTorch fallback
+exists: CPU tensors raise.
 """
 from __future__ import annotations
 
-import ctypes as C
 import atexit
 import contextlib
 import os
 import threading
 import weakref
-from typing import NamedTuple, Optional
+from typing import NamedTuple
 
 import torch
 from torch import nn
 
 from . import _lib
+from . import _C            # the compiled module (fails loudly when it has not been built: python -m binocular3dgs_amd.build)
 from ._cuda import device_guard, raw_stream
 
 
@@ -56,59 +58,7 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None or t.numel() == 0 else t.data_ptr()
-
-
 _stream = raw_stream
-
-
-def _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
-           projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug):
-    """Validate like the upstream binding and fill the C struct.  Returns (struct, keepalive)."""
-    means3D = _dev_f32(means3D, "means3D")
-    if means3D.dim() != 2 or means3D.shape[1] != 3:
-        raise ValueError("means3D must have dimensions (num_points, 3)")
-    P = means3D.shape[0]
-    dev = means3D.device
-    keep = [means3D]
-
-    def opt(t, name, shape_tail):
-        if t is None or t.numel() == 0:
-            return None
-        t = _dev_f32(t, name)
-        if t.shape[0] != P or tuple(t.shape[1:]) not in shape_tail:
-            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected ({P}, {shape_tail})")
-        keep.append(t)
-        return t
-
-    sh_t = None
-    M = 0
-    if sh is not None and sh.numel() != 0:
-        sh_t = _dev_f32(sh, "sh")
-        if sh_t.dim() != 3 or sh_t.shape[0] != P or sh_t.shape[2] != 3:
-            raise ValueError("sh must have dimensions (num_points, K, 3)")
-        M = sh_t.shape[1]
-        keep.append(sh_t)
-    colors_t = opt(colors, "colors_precomp", [(3,)])
-    opacity_t = _dev_f32(opacity, "opacities").reshape(-1)
-    if opacity_t.numel() != P:
-        raise ValueError("opacities must have num_points elements")
-    scales_t = opt(scales, "scales", [(3,)])
-    rot_t = opt(rotations, "rotations", [(4,)])
-    cov_t = opt(cov3D_precomp, "cov3D_precomp", [(6,)])
-    bg = _dev_f32(background, "bg").reshape(-1)
-    vm = _dev_f32(viewmatrix, "viewmatrix").reshape(-1)
-    pm = _dev_f32(projmatrix, "projmatrix").reshape(-1)
-    cp = _dev_f32(campos, "campos").reshape(-1)
-    if bg.numel() != 3 or vm.numel() != 16 or pm.numel() != 16 or cp.numel() != 3:
-        raise ValueError("bg/campos must have 3 and viewmatrix/projmatrix 16 elements")
-    keep += [opacity_t, bg, vm, pm, cp]
-    sc = _lib.B3gsScene(P, int(degree), int(M), int(image_width), int(image_height), float(tan_fovx),
-                        float(tan_fovy), float(scale_modifier), int(bool(prefiltered)), int(bool(debug)),
-                        _ptr(bg), _ptr(means3D), _ptr(sh_t), _ptr(colors_t), _ptr(opacity_t), _ptr(scales_t),
-                        _ptr(rot_t), _ptr(cov_t), _ptr(vm), _ptr(pm), _ptr(cp))
-    return sc, keep, dev, P, M
 
 
 class _LazyN:
@@ -243,202 +193,54 @@ _lazy = _LazyN()
 atexit.register(_lazy.flush_at_exit)
 
 
-class _CModule:
-    """Stands in for the `_C` torch-extension module of the upstream package."""
-    last_lazy_token = None   # set by a sync-free forward: what _RasterizeGaussians.backward confirms
-
-    @staticmethod
-    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
-                            campos, prefiltered, debug, lazy_num_rendered=False):
-        """-> (num_rendered, color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P] int32,
-               geomBuffer, binningBuffer, imgBuffer)   (uint8 state tensors, opaque)
-
-        lazy_num_rendered (not part of the upstream signature; set by the autograd surface, which never shows
-        num_rendered to its caller): sync-free forward, see _LazyN -- the returned count is then the CAPACITY of the
-        binning buffer (what the backward needs to find its arrays), not N."""
-        L = _lib.lib()
-        if means3D.dim() == 2 and means3D.shape[0] == 0:
-            # no Gaussians: the upstream binding skips the rasterizer and returns its zero-initialised images
-            # (`torch::full(..., 0.0)` in rasterize_points.cu: NOT the background), num_rendered 0, empty state
-            dev0 = _dev_f32(means3D, "means3D").device
-            f0 = dict(dtype=torch.float32, device=dev0)
-            H0, W0 = int(image_height), int(image_width)
-            e8 = torch.empty(0, dtype=torch.uint8, device=dev0)
-            return (0, torch.zeros((3, H0, W0), **f0), torch.zeros((1, H0, W0), **f0), torch.zeros((1, H0, W0), **f0),
-                    torch.empty((0,), dtype=torch.int32, device=dev0), e8, e8.clone(), e8.clone())
-        sc, keep, dev, P, _ = _scene(background, means3D, colors, opacity, scales, rotations, scale_modifier,
-                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
-                                     image_width, sh, degree, campos, prefiltered, debug)
-        H, W = int(image_height), int(image_width)
-        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), P, W, H)
-        if lazy_num_rendered and _lazy.enabled and not debug and P > 0:
-            _lazy.poll()
-            cap = _lazy.capacity.get(key)
-            if cap is not None:
-                u8 = dict(dtype=torch.uint8, device=dev)
-                geom = torch.empty((L.b3gs_geometry_bytes(P),), **u8)
-                binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
-                img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
-                n_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-                with device_guard(dev):
-                    rc = L.b3gs_forward_capacity(C.byref(sc), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
-                                                 color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii),
-                                                 n_dev.data_ptr(), _stream(dev))
-                    _lib.check(rc, "b3gs_forward_capacity")
-                    _CModule.last_lazy_token = _lazy.track(key, cap, n_dev)
-                del keep
-                return cap, color, depth, alpha, radii, geom, binning, img
-        bufs = {}
-
-        def mk(key):
-            def fn(_user, nbytes):
-                t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
-                bufs[key] = t
-                return t.data_ptr()
-            return _lib.ALLOC_FN(fn)
-
-        cbs = [mk("geom"), mk("binning"), mk("img")]
-        n = C.c_int32(0)
-        with device_guard(dev):
-            rc = L.b3gs_forward(C.byref(sc), cbs[0], None, cbs[1], None, cbs[2], None, color.data_ptr(),
-                                depth.data_ptr(), alpha.data_ptr(), _ptr(radii), C.byref(n), _stream(dev))
-        _lib.check(rc, "b3gs_forward")
-        del keep
-        if P > 0:
-            _lazy.note(key, int(n.value))     # every exact render teaches the capacity of its shape
-        return (int(n.value), color, depth, alpha, radii, bufs["geom"],
-                bufs.get("binning", torch.empty(0, dtype=torch.uint8, device=dev)), bufs["img"])
-
-    @staticmethod
-    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
-                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
-                                     dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                     imageBuffer, alpha, debug, opacities=None):
-        """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6],
-               dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])
-
-        `opacities` is not part of the upstream signature (the kernels read opacity from the saved
-        geometry state); it is accepted so the scene struct can be validated the same way."""
-        L = _lib.lib()
-        P = means3D.shape[0]
+def _module_node(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, differentiated):
+    """The autograd node of the module surface (csrc/host/raster.cpp: RasterizeFn) + the sync-free-N policy around it.
+    differentiated: the caller will run backward() on this render -- only then may the forward skip the read-back of
+    num_rendered (_LazyN: a binning buffer of known capacity, N checked at the entry of the node's backward); a render nobody
+    differentiates (evaluation) takes the exact synchronous forward."""
+    P = means3D.shape[0] if means3D.dim() == 2 else 0
+    key, cap = None, 0
+    if P > 0 and means3D.is_cuda:
         dev = means3D.device
-        if P == 0:      # (see rasterize_gaussians: nothing was rendered)
-            f0 = dict(dtype=torch.float32, device=dev)
-            M0 = sh.shape[1] if (sh is not None and sh.dim() == 3) else 0
-            has_sr0 = scales is not None and scales.dim() == 2 and scales.shape[1] == 3
-            return (torch.zeros((0, 3), **f0), torch.zeros((0, 3), **f0), torch.zeros((0, 1), **f0), torch.zeros((0, 3), **f0),
-                    torch.zeros((0, 6), **f0), torch.zeros((0, M0, 3), **f0), torch.zeros((0, 3) if has_sr0 else (0, 3), **f0),
-                    torch.zeros((0, 4), **f0))
-        if opacities is None:
-            opacities = torch.empty((P, 1), dtype=torch.float32, device=dev)  # unused by the backward kernels
-        H, W = dL_dout_color.shape[-2], dL_dout_color.shape[-1]
-        sc, keep, dev, P, M = _scene(background, means3D, colors, opacities, scales, rotations, scale_modifier,
-                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree,
-                                     campos, False, debug)
-        dC = _dev_f32(dL_dout_color, "dL_dout_color")
-        dD = None if dL_dout_depth is None or dL_dout_depth.numel() == 0 else _dev_f32(dL_dout_depth, "dL_dout_depth")
-        dA = None if dL_dout_alpha is None or dL_dout_alpha.numel() == 0 else _dev_f32(dL_dout_alpha, "dL_dout_alpha")
-        f = dict(dtype=torch.float32, device=dev)
-        dL_dmeans2D = torch.empty((P, 3), **f)
-        dL_dcolors = torch.empty((P, 3), **f)
-        dL_dopacity = torch.empty((P, 1), **f)
-        dL_dmeans3D = torch.empty((P, 3), **f)
-        dL_dcov3D = torch.empty((P, 6), **f)
-        dL_dsh = torch.empty((P, M, 3), **f)
-        has_sr = sc.scales is not None
-        dL_dscales = torch.empty((P, 3) if has_sr else (0, 3), **f)
-        dL_drot = torch.empty((P, 4) if has_sr else (0, 4), **f)
-        radii_i = radii.to(torch.int32).contiguous()
-        with device_guard(dev):
-            rc = L.b3gs_backward(C.byref(sc), int(R), _ptr(radii_i), _ptr(geomBuffer), _ptr(binningBuffer),
-                                 _ptr(imageBuffer), _ptr(dC), _ptr(dD), _ptr(dA), _ptr(dL_dmeans2D),
-                                 _ptr(dL_dcolors), _ptr(dL_dopacity), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                                 _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drot), _stream(dev))
-        _lib.check(rc, "b3gs_backward")
-        del keep
-        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drot
-
-    @staticmethod
-    def mark_visible(means3D, viewmatrix, projmatrix):
-        L = _lib.lib()
-        m = _dev_f32(means3D, "means3D")
-        vm = _dev_f32(viewmatrix, "viewmatrix")
-        pm = _dev_f32(projmatrix, "projmatrix")
-        present = torch.zeros((m.shape[0],), dtype=torch.bool, device=m.device)
-        with torch.cuda.device(m.device):
-            rc = L.b3gs_mark_visible(m.shape[0], _ptr(m), _ptr(vm), _ptr(pm), _ptr(present), _stream(m.device))
-        _lib.check(rc, "b3gs_mark_visible")
-        return present
-
-
-_C = _CModule()
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), P, int(rs.image_width), int(rs.image_height))
+        if differentiated and _lazy.enabled and not rs.debug:
+            _lazy.poll()
+            cap = _lazy.capacity.get(key) or 0
+    color, radii, depth, alpha, n_info = _C.rasterize_gaussians_autograd(
+        means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg, rs.viewmatrix, rs.projmatrix,
+        rs.campos, int(rs.image_height), int(rs.image_width), rs.tanfovx, rs.tanfovy, rs.scale_modifier, int(rs.sh_degree),
+        bool(rs.prefiltered), bool(rs.debug), cap)
+    if cap:
+        tok = _lazy.track(key, cap, n_info)
+        node = color.grad_fn
+        if node is not None:
+            # truncated tile lists raise at the ENTRY of the node's backward: no gradient leaves it
+            node.register_prehook(lambda grads, _tok=tok: _lazy.confirm(_tok))
+    elif key is not None:
+        _lazy.note(key, int(n_info))          # every exact render teaches the capacity of its shape
+    return color, radii, depth, alpha
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    # will this render be differentiated?  (grad mode is invisible inside autograd.Function.forward, and
-    # ctx.needs_input_grad reflects requires_grad even under torch.no_grad())
+    # will this render be differentiated?
     differentiated = torch.is_grad_enabled() and any(
         torch.is_tensor(t) and t.requires_grad
         for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, differentiated)
+    return _module_node(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        differentiated)
 
 
-class _RasterizeGaussians(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, differentiated=None):
-        """`differentiated` (set by rasterize_gaussians(); absent when the Function is applied directly with the
-        upstream's nine arguments): the caller will run backward() on this render -- only then may the forward skip the
-        read-back of num_rendered (_LazyN); otherwise it is the exact synchronous forward."""
-        rs = raster_settings
-        ctx.n_inputs = 9 if differentiated is None else 10
-        # sync-free only when this render will be differentiated: its backward then checks N before any gradient is
-        # produced; a render nobody differentiates (evaluation) takes the exact synchronous forward
-        _CModule.last_lazy_token = None
-        num_rendered, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(
-            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, lazy_num_rendered=bool(differentiated))
-        ctx.lazy_token, _CModule.last_lazy_token = _CModule.last_lazy_token, None
-        ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom,
-                              binning, img, alpha)
-        ctx.mark_non_differentiable(radii)
-        return color, radii, depth, alpha
+class _RasterizeGaussians:
+    """Upstream's `_RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+    cov3Ds_precomp, raster_settings)`: the node itself is C++ (`_C.rasterize_gaussians_autograd`); applied directly with the
+    upstream's nine arguments it is the exact synchronous forward."""
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        rs = ctx.raster_settings
-        _lazy.confirm(ctx.lazy_token)   # raises when this render's tile lists were truncated: no gradient leaves here
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, alpha = \
-            ctx.saved_tensors
-        if grad_color is None:
-            grad_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32,
-                                     device=means3D.device)
-        empty = torch.empty(0, device=means3D.device)
-        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-         grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
-            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color,
-            empty if grad_depth is None else grad_depth, empty if grad_alpha is None else grad_alpha, sh,
-            rs.sh_degree, rs.campos, geom, ctx.num_rendered, binning, img, alpha, rs.debug)
-        needs = ctx.needs_input_grad
-
-        def pick(g, had_input, i):
-            return g if (had_input and needs[i]) else None
-
-        return (pick(grad_means3D, True, 0), pick(grad_means2D, True, 1), pick(grad_sh, sh.numel() != 0, 2),
-                pick(grad_colors_precomp, colors_precomp.numel() != 0, 3), pick(grad_opacities, True, 4),
-                pick(grad_scales, scales.numel() != 0, 5), pick(grad_rotations, rotations.numel() != 0, 6),
-                pick(grad_cov3Ds_precomp, cov3Ds_precomp.numel() != 0, 7), None, None)[:ctx.n_inputs]
+    def apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+              differentiated=None):
+        return _module_node(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                            bool(differentiated))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -559,8 +361,8 @@ def _will_execute(node) -> bool:
 
 class _PendingFwd:
     """One render() whose forward is still to be launched: everything b3gs_forward_raw_batch needs, already allocated."""
-    __slots__ = ("ctx", "sc", "geom", "binning", "img", "out", "radii", "words", "cap", "key", "hint", "trusted", "zkey",
-                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P", "ring", "row", "handed")
+    __slots__ = ("ctx", "view", "geom", "binning", "img", "out", "radii", "words", "cap", "key", "hint", "trusted", "zkey",
+                 "stream_id", "stream", "fkey", "xyz_id", "vis", "key_bits", "dev", "P", "ring", "row", "handed", "fresh")
 
 
 def _meta_funcs():
@@ -607,6 +409,17 @@ class _LazyOut(torch.Tensor):
             return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
 
 
+def touch_pending(*tensors):
+    """For consumers that do NOT go through torch's function dispatch -- the entry points of the compiled `_C` module read
+    raw pointers: a pending output among `tensors` launches what is pending first (what `_LazyOut.__torch_function__` does
+    for every torch function)."""
+    if _pending_fwd:
+        for t in tensors:
+            if type(t) is _LazyOut:
+                _flush_pending()
+                return
+
+
 @_locked
 def _flush_pending(di=None):
     """Launch the pending forwards (of one device, or of all)."""
@@ -618,38 +431,30 @@ def _flush_pending(di=None):
 
 def _launch_forward(lst):
     """ONE b3gs_forward_raw_batch for the pending renders `lst` (same parameters, stream, image size, key width)."""
-    L = _lib.lib()
     p0 = lst[0]
     n = len(lst)
-    fv = (_lib.B3gsForwardView * n)()
+    specs, order_from = [], []
     for k, p in enumerate(lst):
-        color, depth, alpha = p.out
-        fv[k].view = C.pointer(p.sc)
-        fv[k].geometry, fv[k].binning, fv[k].image = p.geom.data_ptr(), p.binning.data_ptr(), p.img.data_ptr()
-        fv[k].binning_capacity = p.cap
-        fv[k].out_color, fv[k].out_depth, fv[k].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
-        fv[k].radii, fv[k].device_num_rendered = p.radii.data_ptr(), p.words.data_ptr()
-        fv[k].depth_order_from, fv[k].seg1_fraction = -1, 0.0
-        fv[k].high_water, fv[k].overflow_flag = None, p.words[1:].data_ptr()
-        fv[k].depth_key_bits = p.key_bits
-        fv[k].fresh_image = 1
-        if p.vis is not None:
-            fv[k].visible = p.vis.data_ptr()          # (torch.bool is one byte, 0 / 1)
+        frm, trusted, hint_geom = -1, 0, None
         if (k > 0 and _ORDER_HINT and _lazy.trust_hints and p.zkey and p.zkey == lst[k - 1].zkey
-                and fv[k - 1].depth_order_from == -1):
+                and order_from[k - 1] == -1):
             # the host knows that this view's z row is its predecessor's (camera_depth_key): one depth sort for both; the
             # projection compares the keys and a difference drops the step (bit 3) and ends the trust
-            fv[k].depth_order_from, fv[k].hint_trusted = k - 1, 1
+            frm, trusted = k - 1, 1
             _stats["shared"] += 1
         if p.hint is not None and n == 1:
-            fv[k].depth_order_hint, fv[k].hint_mismatch = p.hint["geom"].data_ptr(), p.words[2:].data_ptr()
-            fv[k].hint_trusted = int(p.trusted)
+            hint_geom, trusted = p.hint["geom"], int(p.trusted)
             _stats["hinted"] += 1
             _stats["trusted"] += int(p.trusted)
+        order_from.append(frm)
+        # (view, geometry, binning, capacity, image, out, radii, words, visible, key bits, order from, hint, trusted, fresh image,
+        #  seg1 fraction): csrc/host/raster.cpp raw_forward_launch fills the B3gsForwardView array from these
+        specs.append((p.view, p.geom, p.binning, p.cap, p.img, p.out, p.radii, p.words, p.vis, p.key_bits, frm, hint_geom,
+                      trusted, p.fresh, 0.0))
     other = raw_stream(p0.dev) != p0.stream_id
     cur = torch.cuda.current_stream(p0.dev) if other else None
     with device_guard(p0.dev), (torch.cuda.stream(_stream_obj(p0)) if other else contextlib.nullcontext()):
-        _lib.check(L.b3gs_forward_raw_batch(n, fv, C.byref(p0.ctx.rp), 3, p0.stream_id), "b3gs_forward_raw_batch")
+        _C.raw_forward_launch(specs, p0.stream_id)
         try:
             if n > 1 and all(q.ring is p0.ring and q.row == p0.row + k for k, q in enumerate(lst)):
                 toks = _lazy.track_rows([q.key for q in lst], [q.cap for q in lst], p0.ring[p0.row:p0.row + n])
@@ -684,7 +489,7 @@ def _launch_forward(lst):
     if _ORDER_HINT:
         # (what a later render may adopt: the order of a view that SORTED -- a view that borrowed its neighbour's order inside
         # this batch has no sorted arrays of its own)
-        p = [q for k, q in enumerate(lst) if fv[k].depth_order_from == -1][-1]
+        p = [q for k, q in enumerate(lst) if order_from[k] == -1][-1]
         _order_hint[_dev_index(p.dev)] = dict(P=p.P, key_bits=p.key_bits, geom=p.geom, xyz=p.xyz_id, words=p.words, zkey=p.zkey,
                                               stream=p.stream_id)
 
@@ -891,8 +696,6 @@ def _launch_backward(jobs, self_acc, task_state=None):
     """Blend backward + per-Gaussian chain rule of `jobs` (renders of the SAME parameter tensors), at most 8 views per
     launch.  self_acc: the gradients are added to (or become) `.grad` of the parameters and of every render's
     `viewspace_points` leaf, nothing is returned; otherwise (one job) fresh tensors are returned for autograd."""
-    L = _lib.lib()
-    ctx0 = jobs[0].ctx
     params = jobs[-1].saved[:6]
     dev, P = params[0].device, params[0].shape[0]
     f32 = dict(dtype=torch.float32, device=dev)
@@ -922,42 +725,16 @@ def _launch_backward(jobs, self_acc, task_state=None):
         assert len(jobs) == 1
         overwrite = True
         grads = [torch.empty_like(t) for t in params]
-    gr = _lib.B3gsRawGrads()
-    gr.xyz, gr.features_dc = grads[0].data_ptr(), grads[1].data_ptr()
-    gr.features_rest = grads[2].data_ptr() if grads[2].numel() else None
-    gr.scaling, gr.rotation, gr.opacity = grads[3].data_ptr(), grads[4].data_ptr(), grads[5].data_ptr()
-    gr.touched_rows = None
-    m2d_out = []
-    with device_guard(dev):
-        s = _stream(dev)
-        for c0 in range(0, len(jobs), 8):
-            chunk = jobs[c0:c0 + 8]
-            n = len(chunk)
-            while len(pool) < n:
-                pool.append(torch.zeros((max(L.b3gs_backward_scratch_floats(P), 1),), **f32))
-            bv = (_lib.B3gsBlendView * n)()
-            av = (_lib.B3gsFusedView * n)()
-            for k, j in enumerate(chunk):
-                radii, geom, binning, img = j.saved[6:10]
-                g_m2d = torch.empty((P, 3), **f32) if j.needs_m2d else None
-                m2d_out.append(g_m2d)
-                bv[k].view = C.pointer(j.ctx.sc)
-                bv[k].geometry, bv[k].binning, bv[k].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
-                bv[k].dL_dcolor = j.gc.data_ptr()
-                bv[k].dL_ddepth = None if j.gd is None else j.gd.data_ptr()
-                bv[k].dL_dalpha = None if j.ga is None else j.ga.data_ptr()
-                bv[k].scratch, bv[k].binning_capacity = pool[k].data_ptr(), j.ctx.cap
-                av[k].view = C.pointer(j.ctx.sc)
-                av[k].radii, av[k].geometry, av[k].scratch = radii.data_ptr(), geom.data_ptr(), pool[k].data_ptr()
-                av[k].dL_dmeans2D = None if g_m2d is None else g_m2d.data_ptr()
-                av[k].densify_stats = 0
-            _lib.check(L.b3gs_blend_backward_batch(n, bv, s), "b3gs_blend_backward_batch")
-            # overwrite mode: every row of every gradient tensor is stored (zeros for Gaussians without a contribution);
-            # accumulate mode: only the rows that received something are touched
-            _lib.check(L.b3gs_backward_raw_accumulate(n, av, C.byref(ctx0.rp), C.byref(gr), 1 if (overwrite and c0 == 0) else 0,
-                                                      None, s), "b3gs_backward_raw_accumulate")
-            _stats["launches"] += 1
-            _stats["batched_views"] += n
+    while len(pool) < min(len(jobs), 8):      # (one zeroed scratch block per view of a batched launch; left zero by it)
+        pool.append(torch.zeros((max(_C.backward_scratch_floats(P), 1),), **f32))
+    # blend backward + chain rule, at most 8 views per launch pair (csrc/host/raster.cpp raw_backward_launch).  overwrite
+    # mode: every row of every gradient tensor is stored (zeros for Gaussians without a contribution); accumulate mode:
+    # only the rows that received something are touched
+    m2d_out = _C.raw_backward_launch(
+        [(j.ctx.view, j.saved[6], j.saved[7], j.saved[8], j.saved[9], j.gc, j.gd, j.ga, j.needs_m2d, j.ctx.cap) for j in jobs],
+        pool, grads, overwrite, cur_id)
+    _stats["launches"] += (len(jobs) + 7) // 8
+    _stats["batched_views"] += len(jobs)
     _mark_busy(_dev_index(dev), cur_id)
     # the chain rule uses view 0's depth-sort key arrays as scratch -- a later forward must not adopt "sorted
     # keys" from a geometry buffer whose backward has run (include/b3gs_raster.h, depth_order_hint)
@@ -1001,20 +778,9 @@ class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     @_locked
     def forward(ctx, xyz, f_dc, f_rest, scaling, rotation, opacity, means2D, cfg):
-        L = _lib.lib()
         dev, P = xyz.device, xyz.shape[0]
         W, H = cfg["W"], cfg["H"]
         K = f_dc.shape[1] + f_rest.shape[1]
-        sc = _lib.B3gsScene(P, int(cfg["sh_degree"]), int(K), W, H, float(cfg["tanfovx"]), float(cfg["tanfovy"]),
-                            float(cfg["scale_modifier"]), 0, int(bool(cfg["debug"])), cfg["bg"].data_ptr(), None, None, None,
-                            None, None, None, None, cfg["viewmatrix"].data_ptr(), cfg["projmatrix"].data_ptr(),
-                            cfg["campos"].data_ptr())
-        rp = _lib.B3gsRawParams()
-        rp.xyz, rp.features_dc = xyz.data_ptr(), f_dc.data_ptr()
-        rp.features_rest = f_rest.data_ptr() if f_rest.numel() else None
-        rp.scaling, rp.rotation, rp.opacity = scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr()
-        u8 = dict(dtype=torch.uint8, device=dev)
-        f32 = dict(dtype=torch.float32, device=dev)
         di = _dev_index(dev)
         key = ("raw", di, P, W, H)
         lazy = bool(cfg["differentiated"]) and _lazy.enabled and not cfg["debug"]
@@ -1060,16 +826,18 @@ class _RasterizeRaw(torch.autograd.Function):
         if pend and not (wait and pend[0].fkey == fkey):
             _flush_pending(di)        # something else is rendered first: what is pending goes now
             pend = None
-        geom = torch.empty((L.b3gs_geometry_bytes(P),), **u8)
-        # recycled allocator memory: B3gsForwardView::fresh_image tells the library to read nothing from it (the batched
-        # forward otherwise trusts a tile-order array it finds behind a signature in a PERSISTENT image buffer)
-        img = torch.empty((L.b3gs_image_bytes(W, H),), **u8)
-        out = torch.empty((5, H, W), **f32)          # colour | depth | alpha
-        color, depth, alpha = out[0:3], out[3:4], out[4:5]
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        # render()'s `visibility_filter` = radii > 0: written by the projection (B3gsForwardView::visible)
-        vis = cfg["vis"] = torch.empty((P,), dtype=torch.bool, device=dev) if cfg.get("lazy_outputs") else None
         cap = _lazy.capacity.get(key) or max(1 << 20, 12 * P)
+        # everything one view needs, in ONE call into the compiled module (csrc/host/raster.cpp raw_prepare): the camera
+        # half of B3gsScene + the six parameter pointers (`view`), geometry / image state / binning buffers, the outputs
+        # ([5,H,W]: colour | depth | alpha) and render()'s `visibility_filter` = radii > 0 (written by the projection,
+        # B3gsForwardView::visible).  The image state is recycled allocator memory: `fresh_image` tells the library to read
+        # nothing from it.  A render that will wait for its partner gets NaN images (see _LazyOut) unless it completes the batch
+        nan_fill = wait and len(pend or ()) + 1 < _LAZY_MAX
+        view, geom, img, out, color, depth, alpha, radii, vis, binning = _C.raw_prepare(
+            xyz, f_dc, f_rest, scaling, rotation, opacity, cfg["bg"], cfg["viewmatrix"], cfg["projmatrix"], cfg["campos"], W, H,
+            cfg["tanfovx"], cfg["tanfovy"], cfg["scale_modifier"], int(cfg["sh_degree"]), bool(cfg["debug"]), cap,
+            bool(cfg.get("lazy_outputs")), nan_fill)
+        cfg["vis"] = vis
         # the previous raw forward of the same position tensor (same storage, same version counter): probably the same
         # Gaussians -- its depth order is offered to the library, which verifies key by key
         hint = _order_hint.get(di) if _ORDER_HINT else None
@@ -1086,45 +854,33 @@ class _RasterizeRaw(torch.autograd.Function):
                 hint = None
         ctx.lazy_token = None
         if wait:
-            if len(pend or ()) + 1 < _LAZY_MAX:                            # (not for the render that completes the batch)
-                out.fill_(float("nan"))                                    # see _LazyOut: nobody may read these unnoticed
             p = _PendingFwd()
-            p.ctx, p.sc, p.geom, p.img, p.out, p.radii, p.cap, p.key = ctx, sc, geom, img, (color, depth, alpha), radii, cap, key
-            p.binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+            p.ctx, p.view, p.geom, p.img, p.out, p.radii, p.cap, p.key = ctx, view, geom, img, out, radii, cap, key
+            p.binning, p.fresh = binning, 1
             p.words, p.ring, p.row = _zero_words(dev, with_row=True)
             p.hint, p.trusted, p.zkey, p.key_bits = hint, trusted, zkey, _lazy.key_bits
             p.stream_id, p.stream, p.fkey, p.dev, p.P = stream_id, None, fkey, dev, P
             p.xyz_id, p.vis = (xyz.data_ptr(), xyz._version), vis
             p.handed = None
-            binning = p.binning
-            ctx.rp = rp
             cfg["pending"] = p
             lst = _pending_fwd.setdefault(di, [])
             lst.append(p)
             if len(lst) >= _LAZY_MAX:
                 _flush_pending(di)
         else:
+            first = True
             while True:
-                binning = torch.empty((L.b3gs_binning_bytes(P, cap),), **u8)
+                if not first:
+                    binning = _C.raw_binning(view, cap)
+                first = False
                 words = _zero_words(dev)                                   # [N, overflow word, key mismatch, spare], zero
-                fv = (_lib.B3gsForwardView * 1)()
-                fv[0].view = C.pointer(sc)
-                fv[0].geometry, fv[0].binning, fv[0].image = geom.data_ptr(), binning.data_ptr(), img.data_ptr()
-                fv[0].binning_capacity = cap
-                fv[0].out_color, fv[0].out_depth, fv[0].out_alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
-                fv[0].radii, fv[0].device_num_rendered = radii.data_ptr(), words.data_ptr()
-                fv[0].depth_order_from, fv[0].seg1_fraction = -1, 0.0
-                fv[0].high_water, fv[0].overflow_flag = None, words[1:].data_ptr()
-                fv[0].depth_key_bits = _lazy.key_bits
-                fv[0].fresh_image = 1
-                fv[0].visible = None if vis is None else vis.data_ptr()
-                if hint is not None and P > 0:
-                    fv[0].depth_order_hint, fv[0].hint_mismatch = hint["geom"].data_ptr(), words[2:].data_ptr()
-                    fv[0].hint_trusted = int(trusted)
+                key_bits = _lazy.key_bits
+                use_hint = hint is not None and P > 0
+                if use_hint:
                     _stats["hinted"] += 1
                     _stats["trusted"] += int(trusted)
-                with device_guard(dev):
-                    _lib.check(L.b3gs_forward_raw_batch(1, fv, C.byref(rp), 3, _stream(dev)), "b3gs_forward_raw_batch")
+                _C.raw_forward_launch([(view, geom, binning, cap, img, out, radii, words, vis, key_bits, -1,
+                                        hint["geom"] if use_hint else None, int(trusted) if use_hint else 0, 1, 0.0)], stream_id)
                 if lazy and key in _lazy.capacity:
                     ctx.lazy_token = _lazy.track(key, cap, words[:2])
                     break
@@ -1149,9 +905,9 @@ class _RasterizeRaw(torch.autograd.Function):
                     ck.record()
                     am["check"] = ck
             if _ORDER_HINT:
-                _order_hint[di] = dict(P=P, key_bits=fv[0].depth_key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
+                _order_hint[di] = dict(P=P, key_bits=key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
                                        words=words, zkey=zkey, stream=stream_id)
-        ctx.cfg, ctx.sc, ctx.rp = cfg, sc, rp
+        ctx.cfg, ctx.view = cfg, view
         ctx.save_for_backward(xyz, f_dc, f_rest, scaling, rotation, opacity, radii, geom, binning, img)
         ctx.cap = cap
         ctx.m2d_leaf = means2D

@@ -98,3 +98,69 @@ def test_argument_errors_are_reported_without_touching_a_device():
     assert L.b3gs_forward_capacity(C.byref(sc), None, None, 0, None, None, None, None, None, None, None) == ERR_ARG
     assert b"2^24" in L.b3gs_last_error()
     assert L.b3gs_knn_workspace_bytes(1000) > 0 and L.b3gs_loss_workspace_floats(800, 600) == 8 * 64 + 9 * 800 * 600
+
+
+# ---- the compiled python module over the C ABI (binocular3dgs_amd/_C*.so, csrc/host/*.cpp) ------------------------------
+def test_compiled_module_loads_and_exports_the_upstream_surface():
+    """`_C` is a COMPILED extension module (as the reference's diff_gaussian_rasterization._C is), linked against
+    libb3gs_raster.so; it loads without a GPU and exports the upstream functions plus this build's nodes / launch assembly."""
+    import importlib.machinery
+    from binocular3dgs_amd import _C, _lib
+    from binocular3dgs_amd.build import build, ext_path
+    build()
+    assert os.path.samefile(_C.__file__, ext_path())
+    assert _C.__file__.endswith(tuple(importlib.machinery.EXTENSION_SUFFIXES))
+    assert _C.abi_version() == _lib.ABI_VERSION == _C.ABI_VERSION
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible",             # upstream's three
+                 "rasterize_gaussians_autograd", "rasterize_gaussians_capacity", "raw_prepare", "raw_binning",
+                 "raw_forward_launch", "raw_backward_launch", "l1_loss", "ssim", "smooth_loss", "inverse_warp_images",
+                 "adam_step_at", "opacity_decay", "add_densification_stats"):
+        assert callable(getattr(_C, name)), name
+    import diff_gaussian_rasterization as drop_in
+    from binocular3dgs_amd import rasterizer
+    assert drop_in._C is _C and rasterizer._C is _C
+    assert _C.B3gsError is _lib.B3gsError
+    assert _C.geometry_bytes(1000) == _lib.lib().b3gs_geometry_bytes(1000)
+    assert _C.backward_scratch_floats(1000) == _lib.lib().b3gs_backward_scratch_floats(1000)
+
+
+def test_compiled_module_refuses_host_tensors_and_bad_shapes_without_a_device():
+    """No CPU path anywhere behind `_C`: host tensors raise B3gsError (never a silent fallback); shape errors keep the python
+    types the reference-shaped wrappers promised (ValueError / IndexError)."""
+    import torch
+    from binocular3dgs_amd import _C, _lib
+    from binocular3dgs_amd.graphics_utils import inverse_warp_images
+    from binocular3dgs_amd.loss_utils import SmoothLoss, l1_loss, ssim
+    z = torch.zeros
+    with pytest.raises(_lib.B3gsError, match="HIP device only"):
+        l1_loss(z(3, 4, 4), z(3, 4, 4))
+    with pytest.raises(_lib.B3gsError, match="HIP device only"):
+        ssim(z(3, 16, 16), z(3, 16, 16))
+    with pytest.raises(_lib.B3gsError, match="window_size=11"):
+        ssim(z(3, 16, 16), z(3, 16, 16), window_size=7)
+    with pytest.raises(ValueError):
+        ssim(z(16, 16), z(16, 16))
+    with pytest.raises(IndexError):
+        ssim(z(3, 16, 16), z(3, 16, 16), size_average=False)
+    with pytest.raises(ValueError, match="SmoothLoss expects"):
+        SmoothLoss().forward(z(1, 2, 8, 8), z(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="3x3"):
+        SmoothLoss().forward(z(1, 1, 2, 8), z(1, 3, 2, 8))
+    with pytest.raises(ValueError, match="inverse_warp_images expects"):
+        inverse_warp_images(z(1, 3, 8, 8), z(1, 8, 8))
+    with pytest.raises(_lib.B3gsError, match="HIP device only"):
+        inverse_warp_images(z(1, 3, 8, 8), z(1, 1, 8, 8))
+    e = torch.empty(0)
+    m = torch.eye(4)
+    with pytest.raises(_lib.B3gsError, match="no CPU path"):
+        _C.rasterize_gaussians(z(3), z(5, 3), e, z(5, 1), z(5, 3), z(5, 4), 1.0, e, m, m, 0.5, 0.5, 16, 16, z(5, 4, 3), 1, z(3),
+                               False, False)
+    with pytest.raises(_lib.B3gsError, match="no CPU path"):
+        _C.mark_visible(z(5, 3), m, m)
+    p = torch.nn.Parameter(z(4, 3))
+    with pytest.raises(_lib.B3gsError, match="no CPU path"):
+        _C.adam_step_at([p], [z(4, 3)], [z(4, 3)], [z(4, 3)], [0.1], 1, 0.9, 0.999, 1e-15)
+    with pytest.raises(ValueError):
+        _C.adam_step_at([p], [], [], [], [], 1, 0.9, 0.999, 1e-15)
+    with pytest.raises(IndexError):
+        _C.add_densification_stats(z(5, 3), torch.zeros(4, dtype=torch.bool), z(5, 1), z(5, 1))

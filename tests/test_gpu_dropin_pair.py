@@ -602,8 +602,17 @@ def test_lazy_pair_is_one_two_view_forward_with_the_results_of_two_single_ones()
         assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) < 1e-4
 
 
+def _as4(t, R):
+    """[C,H,W] -> [1,C,H,W] WITHOUT a torch function on the pending tensor (a view made under the dispatch guard, so that the
+    compiled entry point is really the first consumer) -- still a _LazyOut."""
+    with torch._C.DisableTorchFunctionSubclass():
+        v = t.unsqueeze(0)
+    return v.as_subclass(R._LazyOut) if type(v) is not R._LazyOut else v
+
+
 @pytest.mark.parametrize("how", ["operator", "function", "method", "index", "repr", "numpy", "detach", "backward", "other_model",
-                                 "no_grad_render", "other_size", "other_stream", "custom_function", "deepcopy", "conv"])
+                                 "no_grad_render", "other_size", "other_stream", "custom_function", "deepcopy", "conv",
+                                 "compiled_l1", "compiled_ssim", "compiled_warp", "compiled_smooth"])
 def test_lazy_forward_runs_at_the_first_use_of_an_output(how):
     """Whatever touches a pending output first makes the forward run before it: the values are those of an eager render."""
     import binocular3dgs_amd.rasterizer as R
@@ -650,6 +659,26 @@ def test_lazy_forward_runs_at_the_first_use_of_an_output(how):
         import copy
         got = copy.deepcopy(pkg["rendered_depth"].detach())
         assert not bool(torch.isnan(got).any())
+        got = img
+    elif how.startswith("compiled_"):
+        # the loss functions are entry points of the compiled `_C` module: they read raw pointers without going through torch's
+        # function dispatch -- their python fronts launch what is pending first (rasterizer.touch_pending)
+        from binocular3dgs_amd.graphics_utils import inverse_warp_images
+        from binocular3dgs_amd.loss_utils import SmoothLoss, l1_loss, ssim
+        other = torch.rand(3, H, W, device="cuda")
+        if how == "compiled_l1":
+            v, ref = l1_loss(img, other), (want["render"] - other).abs().mean()
+        elif how == "compiled_ssim":
+            v, ref = ssim(img, other), ssim(want["render"].detach(), other)
+        elif how == "compiled_smooth":
+            d = pkg["rendered_depth"]
+            assert type(d) is R._LazyOut
+            v = SmoothLoss().forward(disparity=_as4(d, R), image=other[None])
+            ref = SmoothLoss().forward(want["rendered_depth"].detach()[None], other[None])
+        else:
+            v = inverse_warp_images(_as4(img, R), torch.zeros(1, 1, H, W, device="cuda")).mean()
+            ref = want["render"][..., :-1].sum() / want["render"].numel()    # (a zero shift keeps every column but the last)
+        assert not bool(torch.isnan(v)) and abs(float(v) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref))), (float(v), float(ref))
         got = img
     elif how == "conv":
         k = torch.zeros(3, 1, 1, 1, device="cuda") + 1.0
