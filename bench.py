@@ -136,7 +136,7 @@ class Job:
     """One workload on this rank: model, view set, step object, optional HIP graph."""
 
     def __init__(self, args, dev, rank, world, dp, P, W, H, fov, views, scaling, path="fused", graph=True, loss="synthetic",
-                 scale_mult=1.0, seg1_fraction="auto"):
+                 scale_mult=1.0, seg1_fraction="auto", reference_binning=False):
         from binocular3dgs_amd import synth
         from binocular3dgs_amd.render import PipelineParams
         from binocular3dgs_amd.step import FusedAdam, ShardedAdam, ViewShardedStep
@@ -181,7 +181,8 @@ class Job:
             # materialised unless asked for
             model.init_densification_stats()
             fused = FusedRasterizer(model, W, H, num_slots=max(local_views, 1), want_means2D=bool(args.viewspace_grads),
-                                    schedule="serial" if args.serial_views else args.schedule, seg1_fraction=seg1_fraction)
+                                    schedule="serial" if args.serial_views else args.schedule, seg1_fraction=seg1_fraction,
+                                    reference_binning=reference_binning)
             fused.groups = int(getattr(args, "groups", 2))
         self.fused = fused
         pipe_ranges = args.pipeline_ranges if dp and fused is not None and args.optimizer == "b3gs" else 0
@@ -661,6 +662,25 @@ def main():
                         "kernels, which walk the same list prefixes as with two rounds (bit-identical images); SURVEY 8(d)'s "
                         "roofline unit -- bytes per instance HANDED to the blend backward -- is 3.3x larger here for the same "
                         "kernel time"}
+            del j
+            torch.cuda.empty_cache()
+            # north_star: "tile/bin indices bit-exact".  The headline bins tightly (lists = order-preserving subsequences of the
+            # reference's); this is the SAME step with the reference's binning rule behind the same batched kernels
+            # (FusedRasterizer(reference_binning=True), B3gsForwardView::reference_binning): N, point_list, tile ids and ranges
+            # equal the oracle's bit for bit (tests/test_gpu_fullsize_oracle.py::test_fused_path_with_reference_binning_...)
+            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", reference_binning=True)
+            j.prepare(max(args.warmup, 3))
+            k3 = min(args.steps, 10)
+            el = j.timed_best(k3)
+            ms3, inst3 = j.kernel_times(k3)
+            extras["headline_reference_binning"] = {
+                "iters_per_s": round(k3 / el, 2), "ms_per_step": round(el / k3 * 1e3, 3), "steps": k3,
+                "binning_rounds": 2 if j.fused.seg1_fraction > 0 else 1,
+                "instances_handed_per_view": None if inst3 is None else int(inst3 / 6),
+                "stage_ms_per_view": {k_: round(v_, 4) for k_, v_ in ms3.items()},
+                "what": "the headline step with the REFERENCE's binning rule (every tile of the ceil(3 sigma) rectangle) on the "
+                        "fused path: tile lists bit-identical to the oracle's, same images and gradients, more instances to "
+                        "emit, sort and walk"}
             del j
             torch.cuda.empty_cache()
             dargs = argparse.Namespace(**vars(args))

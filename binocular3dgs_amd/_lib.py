@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("B3GS_LIB") or os.path.join(_HERE, "libb3gs_raster.so")   # B3GS_LIB: A/B builds of the kernels
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 OK = 0
 ERR_NAMES = {-1: "B3GS_ERR_ARG", -2: "B3GS_ERR_ALLOC", -3: "B3GS_ERR_HIP", -4: "B3GS_ERR_CAPACITY",
              -5: "B3GS_ERR_NO_DEVICE"}
@@ -58,7 +58,7 @@ class B3gsForwardView(C.Structure):
                 ("device_num_rendered", C.c_void_p), ("depth_order_from", C.c_int32), ("seg1_fraction", C.c_float),
                 ("high_water", C.c_void_p), ("overflow_flag", C.c_void_p), ("depth_key_bits", C.c_int32),
                 ("fresh_image", C.c_int32), ("depth_order_hint", C.c_void_p), ("hint_mismatch", C.c_void_p),
-                ("hint_trusted", C.c_int32), ("visible", C.c_void_p)]
+                ("hint_trusted", C.c_int32), ("visible", C.c_void_p), ("reference_binning", C.c_int32)]
 
 
 class B3gsLossIO(C.Structure):

@@ -295,11 +295,6 @@ int b3gs_forward_capacity(const B3gsScene* sc, char* geometry, char* binning, in
                                radii, device_num_rendered, 3, (hipStream_t)stream);
 }
 
-static int env_tight() {
-  static const int v = getenv("B3GS_NO_TIGHT") ? 0 : 1;   // (A/B switch, read once per process)
-  return v;
-}
-
 int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* geometry, char* binning,
                      int64_t binning_capacity, char* image, float* out_color, float* out_depth, float* out_alpha,
                      int32_t* radii, int32_t* device_num_rendered, int phases, b3gs_stream_t stream) {
@@ -309,7 +304,7 @@ int b3gs_forward_raw(const B3gsScene* view, const B3gsRawParams* params, char* g
   sx.sc = *view;
   sx.raw = *params;
   sx.raw_mode = 1;
-  sx.tight = env_tight();
+  sx.tight = 1;       // (the single-view entry point has no switch: b3gs_forward_raw_batch(1, ...) does)
   return forward_capacity_impl(sx, geometry, binning, binning_capacity, image, out_color, out_depth, out_alpha, radii,
                                device_num_rendered, phases, (hipStream_t)stream);
 }
@@ -326,7 +321,7 @@ int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B
   bb.cls_size = 0;
   pb.n = bb.n = nviews;
   pb.raw_mode = 1;
-  pb.tight = env_tight();
+  pb.tight = views[0].reference_binning ? 0 : 1;      // (B3gsForwardView::reference_binning, ABI 10)
   for (int k = 0; k < nviews; k++) {
     const B3gsForwardView& fv = views[k];
     int rc = check_raw(fv.view, params);

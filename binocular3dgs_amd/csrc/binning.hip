@@ -612,7 +612,7 @@ __device__ __forceinline__ void radix_rowscan_body(const SortBatch& sb, uint32_t
   const uint32_t nblk = job.nblk;
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
-  const uint32_t used = min(nblk, (n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE);   // columns the histogram pass wrote
+  const uint32_t used = min(nblk, (uint32_t)(((uint64_t)n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE));   // columns the histogram pass wrote
   uint32_t* row = job.hist + (size_t)bx * hist_stride(nblk);
   uint32_t carry = 0;
   for (uint32_t b0 = 0; b0 < used; b0 += 256) {
@@ -758,10 +758,12 @@ template <bool HAS_VAL, int BITS>
 __global__ void __launch_bounds__(B3GS_SORT_THREADS) radix_scatter(SortBatch sb, int pass_shift) {
   __shared__ ScatterShared<HAS_VAL> sh;
   const SortJob& job = sb.j[blockIdx.y];
+  if (sort_job_idle(job)) return;      // (a gated-off job's pointers are not read; the body checked this first)
   const uint32_t off = job.off_ptr ? min(*job.off_ptr, job.n_cap) : 0u;
   const uint32_t n = job.n_ptr ? min(*job.n_ptr, job.n_cap - off) : job.n_cap - off;
   uint32_t tile;
-  if (!xcd_band_tile(blockIdx.x, min(job.nblk, (n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE), &tile)) return;
+  // (tile count in 64 bits like radix_hist: n + tile - 1 must not wrap for n near 2^32)
+  if (!xcd_band_tile(blockIdx.x, min(job.nblk, (uint32_t)(((uint64_t)n + B3GS_SORT_TILE - 1) / B3GS_SORT_TILE)), &tile)) return;
   radix_scatter_body<HAS_VAL, BITS>(sb, pass_shift, tile, blockIdx.y, sh);
 }
 

@@ -9,10 +9,17 @@
 // (binocular3dgs_amd/loss_utils.py, graphics_utils.py) wraps them as autograd.Functions.
 //
 // Scalar results: every workgroup leaves one partial sum, the workgroup that arrives last folds them IN INDEX ORDER
-// (deterministic, no float atomics, no second launch) and resets the arrival counter.  Hand-off per the CDNA4 rules for
-// data that crosses XCDs inside one launch: plain store -> agent-scope release fence -> s_waitcnt vmcnt(0) -> relaxed
-// agent-scope ticket; the last workgroup: agent-scope acquire fence -> barrier -> plain loads.
+// (deterministic, no float atomics, no second launch) and resets the arrival counter.  Hand-off for data that crosses XCDs
+// inside one launch (their L2s are not coherent with each other), as arrive_last() below implements it: the partial sum is a
+// relaxed agent-scope (sc1, write-through) store -> s_waitcnt vmcnt(0) -> relaxed agent-scope ticket -- deliberately NO
+// release fence, whose L2 write-back costs microseconds per workgroup; the last workgroup: ONE agent-scope acquire fence
+// (thread 0) -> barrier -> plain loads.  This contract is what gfx942 / gfx950 guarantee for sc1 stores; other targets must
+// not compile this file silently.
 #include "loss_common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "lossfn.hip: the write-through + vmcnt(0) hand-off of arrive_last() is specified for gfx942 / gfx950 only"
+#endif
 
 namespace {
 using namespace b3gs_loss;

@@ -91,8 +91,12 @@ class _RasterizeBatch(torch.autograd.Function):
 class FusedRasterizer:
     def __init__(self, model, width: int, height: int, num_slots: int = 2, binning_capacity: Optional[int] = None,
                  want_means2D: bool = True, concurrent: bool = True, schedule: Optional[str] = None,
-                 seg1_fraction="auto"):
+                 seg1_fraction="auto", reference_binning: bool = False):
         self.model = model
+        # reference_binning: bin every tile of the reference's 3-sigma rectangle instead of the tiles the alpha >= 1/255
+        # footprint reaches (B3gsForwardView::reference_binning, ABI 10): tile lists bit-identical to the reference's rule
+        # (north_star: "tile/bin indices bit-exact") at the price of ~3x the instances; images and gradients are the same
+        self.reference_binning = bool(reference_binning)
         self.W, self.H = int(width), int(height)
         p = model.get_xyz
         if not p.is_cuda:
@@ -235,6 +239,7 @@ class FusedRasterizer:
                     donor = getattr(sp["cam"], "same_depth_as", None)
                     arr[k].depth_order_from = -1
                     arr[k].seg1_fraction = self.seg1_fraction
+                    arr[k].reference_binning = int(self.reference_binning)
                     arr[k].high_water = self.high_water[sp["slot"]:sp["slot"] + 1].data_ptr()
                     arr[k].overflow_flag = self.overflow_flag.data_ptr()
                     arr[k].depth_key_bits = sp.get("key_bits", self.depth_key_bits)

@@ -140,5 +140,6 @@ def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0
         delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
     else:
         delay_rate = 1.0
-    t = np.clip(step / max_steps, 0, 1)
+    t = min(max(step / max_steps, 0.0), 1.0)
+    # (numpy's float64 exp / log, as the reference: golden G7 pins the values bit for bit)
     return float(delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))

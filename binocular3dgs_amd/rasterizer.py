@@ -337,13 +337,16 @@ def _refresh_probes():
 def _mark_busy(di, stream_id):
     """An event behind the work this module just queued on the CURRENT stream (id `stream_id`; see the wait decision in
     _RasterizeRaw.forward)."""
+    if _LAZY_WHEN_IDLE:
+        return              # (only the eager-on-idle rule, B3GS_DROPIN_LAZY_IDLE=0, ever asks)
     key = (di, stream_id)
     ev = _S.busy.get(key)
     if ev is None:
         if len(_S.busy) > 16:
             _S.busy.clear()
         ev = _S.busy[key] = torch.cuda.Event()
-    ev.record()
+    # (ADVICE r5: Event.record() without an argument means the current stream of the CURRENT device -- name the stream)
+    ev.record(torch.cuda.ExternalStream(stream_id, device=torch.device("cuda", di)))
 
 
 def _stream_obj(p):
@@ -902,7 +905,7 @@ class _RasterizeRaw(torch.autograd.Function):
                     ck = am.get("ck_event")
                     if ck is None:
                         ck = am["ck_event"] = torch.cuda.Event()
-                    ck.record()
+                    ck.record(torch.cuda.ExternalStream(stream_id, device=dev))
                     am["check"] = ck
             if _ORDER_HINT:
                 _order_hint[di] = dict(P=P, key_bits=key_bits, geom=geom, xyz=(xyz.data_ptr(), xyz._version),
@@ -981,9 +984,10 @@ def rasterize_raw(pc, means2D, raster_settings, camera=None, lazy_outputs=False)
     outputs out as _LazyOut (render() does): -> (color, radii, depth, alpha, visibility) where the forward may still be
     pending."""
     rs = raster_settings
-    dev = pc._xyz.device
-    t = [_dev_f32(x, n).reshape(-1) for x, n in ((rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"), (rs.projmatrix, "projmatrix"),
-                                                 (rs.campos, "campos"))]
+    # (the compiled module reads these four through their data pointers: a float32, contiguous device tensor of the right
+    # size goes as it is -- the usual case, a camera's own matrices -- anything else is converted first)
+    t = [x if (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()) else _dev_f32(x, n)
+         for x, n in ((rs.bg, "bg"), (rs.viewmatrix, "viewmatrix"), (rs.projmatrix, "projmatrix"), (rs.campos, "campos"))]
     if t[0].numel() != 3 or t[1].numel() != 16 or t[2].numel() != 16 or t[3].numel() != 3:
         raise ValueError("bg/campos must have 3 and viewmatrix/projmatrix 16 elements")
     params = (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)
@@ -991,7 +995,6 @@ def rasterize_raw(pc, means2D, raster_settings, camera=None, lazy_outputs=False)
                scale_modifier=rs.scale_modifier, viewmatrix=t[1], projmatrix=t[2], campos=t[3], sh_degree=rs.sh_degree,
                debug=rs.debug, zkey=camera_depth_key(camera) if (camera is not None and _ORDER_HINT) else False,
                differentiated=torch.is_grad_enabled() and any(p.requires_grad for p in params + (means2D,)))
-    del dev
     if not lazy_outputs:
         return _RasterizeRaw.apply(*params, means2D, cfg)
     cfg["lazy_outputs"] = True

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define B3GS_ABI_VERSION 9
+#define B3GS_ABI_VERSION 10
 #define B3GS_TILE 16 /* 16x16-pixel tiles: the binning granularity (bit-exact with the oracle) */
 
 typedef enum B3gsStatus {
@@ -226,6 +226,12 @@ typedef struct B3gsForwardView {
   /* ABI 8 (may be NULL): [P] bytes <- radii > 0, render()'s `visibility_filter` (gaussian_renderer/__init__.py:99), written
    * by the projection next to the radius instead of by a compare kernel per render afterwards. */
   uint8_t* visible;
+  /* ABI 10 -- which tiles a Gaussian is binned into.  0 (default): the tiles its alpha >= 1/255 footprint can reach
+   * ("tight" binning: same images, shorter lists -- every list is an order-preserving subsequence of the reference's).
+   * != 0: every tile of the reference's rectangle (radius = ceil(3 sigma)): point_list / ranges
+   * are then the reference's bit for bit, as on the b3gs_forward() surface.  All views of a batch use views[0]'s value.
+   * (Until ABI 9 this was a process-wide environment switch read inside the library.) */
+  int32_t reference_binning;
 } B3gsForwardView;
 int b3gs_forward_raw_batch(int32_t nviews, const B3gsForwardView* views, const B3gsRawParams* params, int phases,
                            b3gs_stream_t stream);

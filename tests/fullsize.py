@@ -209,12 +209,15 @@ def oracle_raw_grads(model, vlist, bg, W, H, per_view_cb=None):
     return {n: raw[n].grad.numpy() for n in raw}, st_norm, st_cnt, st_rad
 
 
-def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fraction=0.125, want_means2D=True):
+def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fraction=0.125, want_means2D=True,
+                  reference_binning=False):
     """All views of one iteration through FusedRasterizer.render_batch (the bench.py path) against the oracle.
     seg1_fraction: 0.125 = two-round binning forced on, first forward (no open-tile prediction yet: the second round
     repairs); "auto" = what bench.py builds (the deterministic rule of FusedRasterizer.fit_capacity, prediction settled by
     its forward); 0.0 = one round.  want_means2D=False is bench.py's setting (no per-view screen-space gradient tensors:
-    the densification statistics consume them inside the chain-rule pass)."""
+    the densification statistics consume them inside the chain-rule pass).  reference_binning=True (with one round): the
+    fused path bins by the reference's rectangle rule (B3gsForwardView::reference_binning) -- its lists are then compared with
+    the oracle's BIT FOR BIT ("lists_exact") instead of as subsequences."""
     from binocular3dgs_amd import synth
     from binocular3dgs_amd.debug import state_views
     from binocular3dgs_amd.fused import FusedRasterizer
@@ -232,7 +235,8 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fra
         if scam is not None:
             vlist.append((scam, slot, False, (gc2, None, None)))
             slot += 1
-    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=want_means2D, seg1_fraction=seg1_fraction)
+    fr = FusedRasterizer(model, W, H, num_slots=len(vlist), want_means2D=want_means2D, seg1_fraction=seg1_fraction,
+                         reference_binning=reference_binning)
     if seg1_fraction == "auto":
         fr.fit_capacity([(c, s) for c, s, _, _ in vlist], bg)
     else:
@@ -275,7 +279,15 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fra
         # two-word layout starts); the first N entries are the lists
         fv = state_views(P, W, H, sl.capacity, sl.geom, sl.binning, sl.img)
         pv["N_seg2"] = int(fv["counts"][2])
-        if check_lists and (k < 2 or k == len(vlist) - 1):
+        if check_lists and reference_binning:
+            n1 = int(fv["counts"][0])
+            pv["lists_exact"] = dict(
+                n_equal=n1 == int(st.N) and int(fv["counts"][2] if fr.seg1_fraction > 0 else 0) == 0,
+                point_list_equal=bool(np.array_equal(fv["point_list"][:n1].cpu().numpy().astype(np.uint32), st.point_list)),
+                tile_ids_equal=bool(np.array_equal(fv["tile_ids"][:n1].cpu().numpy().astype(np.uint64), st.keys >> np.uint64(32))),
+                ranges_equal=bool(np.array_equal(fv["ranges"].cpu().numpy().astype(np.uint32), st.ranges)),
+                tiles_touched_equal=bool(np.array_equal(fv["tiles_touched"].cpu().numpy().astype(np.uint32), st.tiles_touched)))
+        elif check_lists and (k < 2 or k == len(vlist) - 1):
             pv["lists"] = _tight_list_metrics(P, W, H, st, fv, radii)
         if sl.means2D_grad is not None:
             pv["dL_dmeans2D"] = rel_l2(sl.means2D_grad.cpu().numpy(), ref["dL_dmeans2D"])

@@ -103,6 +103,26 @@ def test_benchmarked_fused_path_vs_oracle(P, W, H, fov, views, seg1, m2d):
     assert m["stat_denom_mismatch"] == 0 and m["stat_max_radii_mismatch"] == 0
 
 
+def test_fused_path_with_reference_binning_has_the_oracles_tile_lists_bit_for_bit():
+    """north_star: "tile/bin indices bit-exact".  The benchmarked fused path bins tightly by default (lists = order-preserving
+    subsequences, above); with FusedRasterizer(reference_binning=True) -- B3gsForwardView::reference_binning, ABI 10; what
+    bench.py's `extras.headline_reference_binning` times -- the batched raw-parameter forward bins by the reference's
+    rectangle rule and EVERY view's N, tiles_touched, point_list, tile ids and ranges equal the oracle's bit for bit at the
+    headline size (1M Gaussians @ 800x600, 3 + 3 views), images and gradients inside the same bars."""
+    import fullsize
+    m = fullsize.fused_metrics(1_000_000, 800, 600, 60.0, views=6, seg1_fraction=0.0, want_means2D=False, reference_binning=True)
+    assert m["views"] == 6 and m["seg1_fraction"] == 0.0
+    for k, pv in enumerate(m["per_view"]):
+        assert pv["radius_flips"] == 0, (k, pv["radius_flips"])
+        assert pv["lists_exact"] == dict(n_equal=True, point_list_equal=True, tile_ids_equal=True, ranges_equal=True,
+                                         tiles_touched_equal=True), (k, pv["lists_exact"])
+        for name, scale in (("color", 1.0), ("depth", 10.0), ("alpha", 1.0)):
+            assert pv[name + "_frac"] <= FLIP_FRAC and pv[name + "_max"] <= scale * FLIP_MAX, (k, name, pv)
+    for n in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+        assert m["grad_" + n] <= 2e-4, f"{n}: rel L2 {m['grad_' + n]:.3e}"
+    assert m["stat_denom_mismatch"] == 0 and m["stat_max_radii_mismatch"] == 0
+
+
 def test_config2_500k_three_pairs_full_loop_with_the_stereo_loss():
     """BASELINE configs[2]: ~500k Gaussians, 3 input views + their 3 binocular-shifted partners at 800x600, the full
     loop on one MI355X with the depth / alpha outputs feeding the stereo-consistency loss.
