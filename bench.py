@@ -72,10 +72,13 @@ def parse():
                          "ranks view by view (step.assign_views) -- value = global iters/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements (drop-in, strong scaling, config 5)")
-    ap.add_argument("--dp-extras", type=int, default=int(os.environ.get("B3GS_BENCH_DP_EXTRAS", "0")),
-                    help="N > 1: also run the extras (strong scaling of configs[3] with split pairs over point-to-point "
-                         "messages, configs[4]).  Off by default: an extra that raises on ONE rank leaves the others inside a "
-                         "collective, and the headline line is printed last -- no multi-GPU node has run these paths yet")
+    ap.add_argument("--dp-extras", type=int, default=int(os.environ.get("B3GS_BENCH_DP_EXTRAS", "1")),
+                    help="N > 1: also run the strong-scaling legs (configs[3] with split pairs over point-to-point messages, "
+                         "configs[4]) after the headline has been measured.  On by default since round 6: every leg runs in "
+                         "collectively agreed phases (a rank that raises makes all ranks drop the leg) under "
+                         "--dp-extras-deadline, which prints the headline line anyway should a leg hang.  0 = headline only")
+    ap.add_argument("--dp-extras-deadline", type=float, default=float(os.environ.get("B3GS_BENCH_DP_DEADLINE", "240")),
+                    help="N > 1: seconds the strong-scaling / configs[4] legs may take before the headline line is printed without them")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # a PMC pass of this script over itself
     ap.add_argument("--no-optimizer", action="store_true")
@@ -438,6 +441,60 @@ def _spawn_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def agreed_leg(fn, dev, world, what):
+    """One extra measurement of an N > 1 run, in phases every rank leaves TOGETHER: `fn` is a generator that yields after
+    every phase that may raise on one rank alone (construction / allocation, warm-up, the timed steps) and finally returns
+    its result.  After each phase a status word is all-reduced (MAX); when any rank raised, every rank drops the leg at that
+    point -- nobody is left waiting inside a collective of a step the failing rank never reached.  -> (result | None, error)."""
+    gen, res, err = fn(), None, None
+    while True:
+        failed = 0.0
+        try:
+            next(gen)
+        except StopIteration as stop:
+            res = stop.value
+        except Exception as exc:      # noqa: BLE001
+            failed, err = 1.0, f"{what}: {exc!r}"
+        done = res is not None or failed
+        if world > 1:
+            word = torch.tensor([failed, 0.0 if done else 1.0], device=dev)
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)
+            if float(word[0]) > 0:
+                gen.close()
+                return None, err or f"{what}: another rank raised"
+            if float(word[1]) == 0:
+                return res, None
+        elif failed:
+            return None, err
+        elif done:
+            return res, None
+
+
+class Deadline:
+    """The legs of an N > 1 run that no multi-GPU node has ever executed (strong scaling over split pairs, configs[4]) run
+    AFTER the headline has been measured: should one of them hang inside a collective, the headline line is printed all the
+    same when the deadline passes (rank 0), and every rank leaves with exit code 0."""
+
+    def __init__(self, seconds, rank, make_line):
+        import threading
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 5.0), self._fire)
+        self.timer.daemon = True
+        self.rank, self.make_line = rank, make_line
+        self.timer.start()
+
+    def _fire(self):
+        if self.rank == 0:
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(self.make_line(), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.inner:
@@ -566,7 +623,9 @@ def main():
                 "pixgauss_pairs_per_s": (None if not pairs_per_view or ms["render_bwd"] <= 0
                                          else round(pairs_per_view / (ms["render_bwd"] / 1e3), 1))}
         out = {
-            "metric": "train iters/s (fwd+bwd), 1M Gaussians @ 800x600, 6 views/iter",
+            "metric": ("train iters/s (fwd+bwd), 1M Gaussians @ 800x600, 6 views/iter" if world == 1 or args.scaling != "weak" else
+                       f"train iters/s (fwd+bwd), 1M Gaussians @ 800x600, weak scaling: {world} x 6 views per step "
+                       f"(an 'iter' = 6 views; every rank renders its own 3 + 3)"),
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -600,34 +659,60 @@ def main():
     # ---- extras: other workloads of BASELINE.json's configs, measured in the same process ---------------------------
     extras = {}
     if world > 1 and not args.dp_extras and not args.no_extras and rank == 0 and result is not None:
-        result["extras_skipped"] = "N > 1: the headline only (--dp-extras 1 adds strong_scaling_6_views and config5)"
+        result["extras_skipped"] = "N > 1 with --dp-extras 0: the headline only"
     if not args.no_extras and not args.inner and args.path == "fused" and args.scaling == "weak" and args.views == 6 \
             and (world == 1 or args.dp_extras):
         del job
         torch.cuda.empty_cache()
         k = min(args.steps, 10)
+        deadline = None
         if world > 1:
-            j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "strong")
-            j.prepare(2)
-            el = j.timed_best(k)
-            extras["strong_scaling_6_views"] = {"iters_per_s": round(k / el, 2), "ms_per_step": round(el / k * 1e3, 3),
-                                                "views_per_rank": [len(b) for b in j.stepper.blocks], "steps": k,
-                                                "config": "BASELINE configs[3]: the SAME 3 input + 3 shifted views per iter, "
-                                                          "view-granular over the ranks"}
-            del j
+            # BASELINE configs[3] -- the SAME 3 + 3 views per iteration spread over the ranks (strong scaling) -- is part of the
+            # DEFAULT N > 1 line.  It runs after the headline was measured, in collectively agreed phases, under a deadline
+            # that prints the headline line anyway if the leg hangs (`--dp-extras-deadline`, seconds)
+            def line_without_extras():
+                if result is not None:
+                    result["extras"] = dict(extras, deadline="an N > 1 extra did not finish in time: the line was printed by "
+                                                             "the deadline, the extras measured until then are listed")
+                return json.dumps(result)
+            deadline = Deadline(args.dp_extras_deadline, rank, line_without_extras)
+
+            def strong_leg():
+                fault = os.environ.get("B3GS_BENCH_TEST_FAULT", "")       # (tests only: "raise:<rank>" / "hang:<rank>")
+                if fault == f"raise:{rank}":
+                    raise RuntimeError("test fault: this rank cannot build the strong-scaling job")
+                if fault == f"hang:{rank}":
+                    time.sleep(3600)
+                j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "strong")
+                yield
+                j.prepare(2)
+                yield
+                el = j.timed_best(k)
+                return {"iters_per_s": round(k / el, 2), "ms_per_step": round(el / k * 1e3, 3),
+                        "views_per_rank": [len(b) for b in j.stepper.blocks], "steps": k, "scaling": "strong",
+                        "config": "BASELINE configs[3]: the SAME 3 input + 3 shifted views per iter, view-granular over the "
+                                  "ranks (pairs split over two ranks exchange the shifted image over xGMI)"}
+            res, err = agreed_leg(strong_leg, dev, world, "strong_scaling_6_views")
+            extras["strong_scaling_6_views"] = res if res is not None else {"error": err}
             torch.cuda.empty_cache()
         P5, W5 = (2_000_000, 1600) if not os.environ.get("B3GS_BENCH_SMALL_EXTRAS") else (40_000, 320)
-        j = Job(args, dev, rank, world, dp, P5, W5, W5, 50.0, 8, "strong")
-        j.prepare(2)
         k5 = min(args.steps, 5)
-        el = j.timed_best(k5)
-        extras["config5_2M_1600x1600_8_views"] = {
-            "iters_per_s": round(k5 / el, 2), "ms_per_step": round(el / k5 * 1e3, 3), "mpix_per_s": round(8 * W5 * W5 * k5 / el / 1e6, 1),
-            "views_per_rank": [len(b) for b in j.stepper.blocks], "steps": k5,
-            "instances_N_binned_view0": (j.fused.num_rendered()[0] if j.local_views else None),
-            "config": "BASELINE configs[4]: 2M Gaussians @ 1600x1600, FoV 50, 8 input views per iter, view-granular"}
-        del j
+
+        def config5_leg():
+            j = Job(args, dev, rank, world, dp, P5, W5, W5, 50.0, 8, "strong")
+            yield
+            j.prepare(2)
+            yield
+            el = j.timed_best(k5)
+            return {"iters_per_s": round(k5 / el, 2), "ms_per_step": round(el / k5 * 1e3, 3),
+                    "mpix_per_s": round(8 * W5 * W5 * k5 / el / 1e6, 1), "views_per_rank": [len(b) for b in j.stepper.blocks],
+                    "steps": k5, "instances_N_binned_view0": (j.fused.num_rendered()[0] if j.local_views else None),
+                    "config": "BASELINE configs[4]: 2M Gaussians @ 1600x1600, FoV 50, 8 input views per iter, view-granular"}
+        res, err = agreed_leg(config5_leg, dev, world, "config5_2M_1600x1600_8_views")
+        extras["config5_2M_1600x1600_8_views"] = res if res is not None else {"error": err}
         torch.cuda.empty_cache()
+        if deadline is not None:
+            deadline.cancel()
         if world == 1:
             # the instance-heavy regime SURVEY 8(d) says the 40 %-of-HBM target was written for: 3x larger splats
             j = Job(args, dev, rank, world, dp, P, W, H, args.fov, 6, "weak", scale_mult=3.0)

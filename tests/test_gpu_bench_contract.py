@@ -76,7 +76,8 @@ def test_ranks_sharing_the_gpu_run_the_multi_gpu_control_flow(world, dp_extras):
     # N > 1 default: replicated one-launch Adam behind the range-pipelined all-reduce tail
     assert x["optimizer"] == "FusedAdam" and x["ranges"] == 4 and d["config"]["dp_tail_ranges"] == 4
     assert x["tail_ms"] > 0 and len(x["all_reduce_window_ms"]) == 4 and x["exchange_bytes_per_rank"] > 0
-    if not dp_extras:      # the default at N > 1: the headline only (an extra that fails on one rank would strand the others)
+    assert "weak scaling" in d["metric"] and f"{world} x 6 views" in d["metric"]
+    if not dp_extras:      # opt-out: the headline only
         assert "extras" not in d and "extras_skipped" in d
         return
     ex = d["extras"]
@@ -84,6 +85,36 @@ def test_ranks_sharing_the_gpu_run_the_multi_gpu_control_flow(world, dp_extras):
     assert ex["strong_scaling_6_views"]["views_per_rank"] == ([3, 3] if world == 2 else [1, 1, 1, 1, 1, 1, 0, 0])
     assert ex["strong_scaling_6_views"]["iters_per_s"] > 0
     assert ex["config5_2M_1600x1600_8_views"]["views_per_rank"] == ([4, 4] if world == 2 else [1] * 8)
+
+
+@pytest.mark.parametrize("fault", ["raise:1", "hang:1"])
+def test_a_rank_that_fails_or_hangs_in_a_strong_scaling_leg_does_not_take_the_headline_down(fault):
+    """The strong-scaling legs are part of the DEFAULT N > 1 line (round 6).  A rank that raises while building its leg: the
+    status word every rank all-reduces after each phase makes ALL ranks drop that leg (`error` in its place), the next leg and
+    the headline are unaffected.  A rank that hangs: the deadline prints the headline line with what was measured until then
+    and every rank exits with code 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, B3GS_BENCH_BACKEND="gloo", B3GS_BENCH_SINGLE_DEVICE="1", B3GS_BENCH_SMALL_EXTRAS="1",
+               B3GS_BENCH_TEST_FAULT=fault)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--gaussians", "30000", "--width", "208", "--height", "144", "--dp-extras-deadline", "25"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["rccl_ranks"] == 2
+    ex = d["extras"]
+    if fault.startswith("raise"):
+        assert "error" in ex["strong_scaling_6_views"] and "iters_per_s" not in ex["strong_scaling_6_views"]
+        assert ex["config5_2M_1600x1600_8_views"]["views_per_rank"] == [4, 4]
+    else:
+        assert "deadline" in ex and "strong_scaling_6_views" not in ex
 
 
 def test_sharded_adam_stays_selectable_for_n_ranks():
