@@ -120,8 +120,8 @@ def resolve_defaults(args, world):
     section 6); one rank: Adam on flat buffers with sparse gradient rows."""
     if args.optimizer is None:
         args.optimizer = "b3gs" if world > 1 else "sharded"
-    if args.pipeline_ranges < 0:
-        args.pipeline_ranges = 4 if (args.optimizer == "b3gs" and (world > 1 or args.dp_path)) else 0
+    if args.pipeline_ranges < 0 and not (args.optimizer == "b3gs" and (world > 1 or args.dp_path)):
+        args.pipeline_ranges = 0        # (stays -1 = "from P" for the pipelined tail: step.auto_pipeline_ranges, 2 at 1M)
     return args
 
 
@@ -199,7 +199,7 @@ class Job:
         if hasattr(opt, "force_collective"):
             opt.force_collective = bool(args.dp_path)
         self.local_views = len(self.stepper.views)
-        self.pipe_ranges = pipe_ranges
+        self.pipe_ranges = self.stepper.pipeline_ranges      # (what "auto" resolved to)
         del nlocal
 
         def grad_fn(i, pkg, spkg):

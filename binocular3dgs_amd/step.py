@@ -313,6 +313,15 @@ class ShardedAdam:
         self._flatten(list(new_params), full_m, full_v)
 
 
+def auto_pipeline_ranges(P: int, row_floats: int = 23) -> int:
+    """How many Gaussian ranges the pipelined data-parallel tail cuts the gradients into: one all-reduce per ~48 MB, at most
+    four.  Every extra range costs a chain-rule launch pair and an Adam launch over a shorter slice (1M Gaussians, one rank:
+    chain rule 0.12 ms in one pass, 0.24 ms in four ranges) and buys overlap of the collective with its neighbours' compute;
+    below a few tens of MB a ring all-reduce over xGMI is latency-bound and splitting it only adds launches.  92 B per
+    Gaussian at K = 4: 500k -> 1 range, 1M -> 2, 2M -> 4."""
+    return max(1, min(4, round(4 * row_floats * P / float(48 << 20))))
+
+
 class RangeGradSlab:
     """Gradient buffer laid out RANGE-major for the pipelined data-parallel tail: the Gaussians are cut into K
     index ranges and all six tensors' gradients of a range are contiguous, so one all-reduce per range can start
@@ -453,8 +462,13 @@ class ViewShardedStep:
         # reduce_and_update() then walks K Gaussian ranges -- chain rule of range r+1 overlaps the all-reduce of
         # range r, Adam of range r overlaps the all-reduce of range r+1 -- instead of accumulate -> all-reduce ->
         # Adam back to back (the all-reduce of 92 B/Gaussian is ~20 % of an iteration on 8 GPUs).
+        # pipeline_ranges: 0 = off, K >= 1 = that many ranges (K = 1: one all-reduce, still with the overflow word in-band and
+        # the statistics staged -- no blocking agreement collective in front of the chain rule), "auto" / < 0 = from P
+        if pipeline_ranges == "auto" or (isinstance(pipeline_ranges, int) and pipeline_ranges < 0):
+            pipeline_ranges = auto_pipeline_ranges(model.get_xyz.shape[0], sum(p.numel() for p in model.parameters()) //
+                                                   max(model.get_xyz.shape[0], 1))
         self.pipeline_ranges = int(pipeline_ranges) if (fused is not None and isinstance(optimizer, FusedAdam)) else 0
-        self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges > 1 else None
+        self.range_slab = RangeGradSlab(model.parameters(), self.pipeline_ranges) if self.pipeline_ranges >= 1 else None
         # Sparse gradient rows (single rank, fused path, HIP Adam): ~80 % of the Gaussians receive no gradient in an
         # iteration; their slab rows are then neither written (chain-rule pass) nor read (Adam) -- a bitmap says which
         # rows are valid.  After such a step `p.grad` holds STALE rows: use sparse_grad_rows=False to inspect it.

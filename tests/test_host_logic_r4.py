@@ -77,9 +77,12 @@ def test_bench_defaults_for_one_and_for_n_ranks():
     a = bench.resolve_defaults(ns(optimizer="sharded"), 8)
     assert (a.optimizer, a.pipeline_ranges) == ("sharded", 0)
     a = bench.resolve_defaults(ns(optimizer="b3gs", dp_path=True), 1)
-    assert (a.optimizer, a.pipeline_ranges) == ("b3gs", 4)
+    assert (a.optimizer, a.pipeline_ranges) == ("b3gs", -1)
     a = bench.resolve_defaults(ns(optimizer="b3gs", pipeline_ranges=2), 4)
     assert a.pipeline_ranges == 2
+    # the rule behind -1: one all-reduce per ~48 MB of gradients (92 B per Gaussian), at most four
+    from binocular3dgs_amd.step import auto_pipeline_ranges
+    assert [auto_pipeline_ranges(P) for P in (30_000, 500_000, 1_000_000, 2_000_000, 8_000_000)] == [1, 1, 2, 4, 4]
 
 
 def test_densification_statistics_without_boolean_indexing_keep_the_reference_bits():
