@@ -73,7 +73,7 @@ def test_bench_defaults_for_one_and_for_n_ranks():
     a = bench.resolve_defaults(ns(), 1)
     assert (a.optimizer, a.pipeline_ranges) == ("sharded", 0)
     a = bench.resolve_defaults(ns(), 8)
-    assert (a.optimizer, a.pipeline_ranges) == ("b3gs", 4)
+    assert (a.optimizer, a.pipeline_ranges) == ("b3gs", -1)
     a = bench.resolve_defaults(ns(optimizer="sharded"), 8)
     assert (a.optimizer, a.pipeline_ranges) == ("sharded", 0)
     a = bench.resolve_defaults(ns(optimizer="b3gs", dp_path=True), 1)
