@@ -17,11 +17,13 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  by this script on a short copy of the same workload (N=1 only; null when rocprofv3 is unavailable);
                  `valu` = the kernel's real bound: VALU issue-slot utilisation from the SQ counters
   hbm_measured   whole-iteration HBM bytes from the same PMC passes
-  reference_algorithm_equivalent   SURVEY 8(d)'s whole-view byte model of the REFERENCE algorithm (6 radix passes over
-                 64-bit keys, reference binning rule) divided by this implementation's kernel time: how fast a
-                 reference-shaped implementation would have to stream to match -- not bytes this code moves
-  extras         dropin_iters_per_s (the reference-shaped render() surface, N=1), strong scaling of the same 6 views
-                 over the ranks (configs[3]), configs[4] (2M Gaussians @ 1600x1600, 8 views, view-granular)
+  extras         dropin_iters_per_s (the reference-shaped render() surface, N=1), headline_one_round_binning,
+                 headline_reference_binning (the reference's binning rule on the fused path: tile lists bit-identical to the
+                 oracle's), module_surface, dp1_rccl_path, reference_schedule; at N > 1 (after the headline, in collectively
+                 agreed phases, under --dp-extras-deadline): strong scaling of the same 6 views over the ranks (configs[3]),
+                 configs[4] (2M Gaussians @ 1600x1600, 8 views, view-granular);
+                 reference_algorithm_equivalent_no_credit: SURVEY 8(d)'s whole-view byte model of the REFERENCE algorithm
+                 divided by this implementation's kernel time -- not bytes this code moves, no credit claimed
   cpu_baseline   oracle/tile_ref.c (kind "port") on the host cores, one full-size iteration
 """
 from __future__ import annotations
@@ -599,7 +601,13 @@ def main():
         achieved = bytes_launch / (dur_ms / 1e3) / 1e9 if dur_ms > 0 else 0.0
         R, Wt = byte_model(P, V, N_ref, HW, Tn)
         view_ms = sum(ms.values())
-        roof = {"kernel": dom + "_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        #  the dominant kernel is bound by VALU issue slots, and says so; achieved / peak / frac stay the
+        # contract's HBM figures (SURVEY 8d algorithmic bytes against the 8 TB/s peak), the flat valu_* scalars its real bound
+        roof = {"kernel": dom + "_kernel", "bound": "valu",
+                "bound_note": "achieved / peak / unit / frac are the HBM-side figures the contract asks for (algorithmic bytes per "
+                              "launch / launch time against 8 TB/s); the kernel itself is bound by VALU issue slots: valu_issue_frac, "
+                              "valu_useful_frac (PMC passes)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": int(bytes_launch), "avg_launch_ms": round(dur_ms, 4), "views_per_launch": lv,
                 "instances_per_launch": None if inst_per_launch is None else int(inst_per_launch),
@@ -647,15 +655,15 @@ def main():
             "stage_ms_per_view": {k: round(v, 4) for k, v in ms.items()},
             **({"exchange": exchange} if exchange is not None else {}),
             "roofline": roof,
-            "reference_algorithm_equivalent": {
-                "what": "SURVEY 8(d) byte model of the REFERENCE algorithm (64-bit keys, 6 radix passes, reference binning "
-                        "rule N) per view / this implementation's per-view kernel time: the streaming rate a "
-                        "reference-shaped implementation would need to match; NOT bytes this code moves",
-                "bytes_per_view": R + Wt, "read_bytes_per_view": R, "kernel_ms_per_view": round(view_ms, 4),
-                "equivalent_GBps": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
-                "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0},
         }
         result = out
+        ref_equiv = {
+            "what": "NO CREDIT CLAIMED: SURVEY 8(d) byte model of the REFERENCE algorithm (64-bit keys, 6 radix passes, reference "
+                    "binning rule N) per view / this implementation's per-view kernel time -- the streaming rate a "
+                    "reference-shaped implementation would need to match; NOT bytes this code moves",
+            "bytes_per_view": R + Wt, "read_bytes_per_view": R, "kernel_ms_per_view": round(view_ms, 4),
+            "equivalent_GBps": round((R + Wt) / (view_ms / 1e3) / 1e9, 1) if view_ms > 0 else 0.0,
+            "read_frac_of_peak": round(R / (view_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if view_ms > 0 else 0.0}
     # ---- extras: other workloads of BASELINE.json's configs, measured in the same process ---------------------------
     extras = {}
     if world > 1 and not args.dp_extras and not args.no_extras and rank == 0 and result is not None:
@@ -843,6 +851,7 @@ def main():
             torch.cuda.empty_cache()
     if rank == 0:
         if extras:
+            extras["reference_algorithm_equivalent_no_credit"] = ref_equiv
             extras["timing"] = "every extra: the better of two runs of the same K steps from the same snapshot"
             result["extras"] = extras
             o1 = extras.get("headline_one_round_binning")

@@ -32,7 +32,7 @@ def test_default_line_has_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "bytes_per_launch", "avg_launch_ms"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "render_bwd_kernel"
+    assert r["bound"] == "valu" and "HBM" in r["bound_note"] and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "render_bwd_kernel"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is None        # --no-pmc
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] / 1e3) / 1e9) < 0.02 * r["achieved"] + 0.1
     # 44 B per processed tile instance + 28 B per pixel and view
