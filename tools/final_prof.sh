@@ -32,3 +32,7 @@ python tools/unchanged_profile.py 500000 800 600 unchanged 2>&1 | grep -v -i war
 python tools/unchanged_host_profile.py unchanged 2>&1 | grep -v -i warn | head -70 > gpurun_out/${tag}_unchanged_host_profile.txt
 python tools/binfirst_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_binfirst_probe.txt
 tools/prof_cmd.sh ${tag}_refsched_unchanged_500k bench_ref_schedule.py 500000,800,600 --surfaces=unchanged > gpurun_out/${tag}_refsched_unchanged_stdout.txt 2>&1
+# round 6: the surface north_star names literally (device timeline), and the reference loop's call sequence under the three forward
+# policies, interleaved in one process (the protocol the verdict's bars are stated in)
+python tools/module_surface_profile.py 2>&1 | grep -v -i warn > gpurun_out/${tag}_module_surface_profile.txt
+(python tools/ab_interleaved.py lazy 500000 504 378; python tools/ab_interleaved.py lazy 500000 800 600) 2>&1 | grep -v -i warn > gpurun_out/${tag}_ab_interleaved.txt
