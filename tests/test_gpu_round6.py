@@ -29,7 +29,8 @@ def test_module_surface_and_loss_functions_run_on_cpp_autograd_nodes():
     color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=model.get_xyz, means2D=m2d, shs=model.get_features,
                                                         opacities=model.get_opacity, scales=model.get_scaling,
                                                         rotations=model.get_rotation)
-    assert "RasterizeFn" in type(color.grad_fn).__name__ and "CppNode" in type(color.grad_fn).__name__
+    # (a C++ node shows in python as `CppFunction`; its name() is the C++ type: torch::autograd::CppNode<b3::RasterizeFn>)
+    assert type(color.grad_fn).__name__ == "CppFunction" and "CppNode<b3::RasterizeFn>" in color.grad_fn.name()
     assert radii.dtype == torch.int32 and not radii.requires_grad and depth.grad_fn is color.grad_fn
     gt = torch.rand(3, H, W, device="cuda")
     a, b = l1_loss(color, gt), ssim(color, gt)
@@ -37,7 +38,7 @@ def test_module_surface_and_loss_functions_run_on_cpp_autograd_nodes():
     c = SmoothLoss().forward(disparity=d4, image=gt[None])
     w = inverse_warp_images(color[None], 0.3 * d4)
     for t, name in ((a, "L1Fn"), (b, "SsimFn"), (c, "SmoothFn"), (w, "WarpFn")):
-        assert name in type(t.grad_fn).__name__ and "CppNode" in type(t.grad_fn).__name__, type(t.grad_fn).__name__
+        assert type(t.grad_fn).__name__ == "CppFunction" and f"CppNode<b3::{name}>" in t.grad_fn.name(), t.grad_fn.name()
     (a + 0.2 * (1 - b) + 0.05 * c + w.mean() + alpha.mean()).backward()
     assert m2d.grad is not None and float(m2d.grad.abs().max()) > 0 and model._xyz.grad is not None
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
