@@ -1019,15 +1019,27 @@ namespace {
 // One workgroup per XCD class c: sort the class's cls_size default positions by decreasing tile work (counting sort
 // over 256 buckets of work / max work; the order inside a bucket is arbitrary: it only schedules).
 constexpr int ORDER_CACHE = 4096;
-__global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint32_t* __restrict__ order, int cls_size) {
+// view_groups > 1: the views of the batch are cut into that many consecutive groups and the order is group-major,
+// longest-tile-first inside a group (256 / groups work levels each): the tiles in flight then belong to n / groups views, whose
+// 64-byte records and 40-byte scratch rows (104 MB per view at 1M Gaussians) are what L2 and the 256-MB Infinity Cache have to
+// hold -- all six views of the headline are 624 MB.  Round 6, same box, alternating: 662 iters/s with one group, 669-672 with two,
+// 667-671 with three, 668-670 with six (blend backward 86-92 -> 83-84 us per view); scratch rows padded to 64 bytes -- a larger
+// footprint, no line-straddling atomics -- made the same kernel 7 % SLOWER, which is what pointed here.
+__global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint32_t* __restrict__ order, int cls_size,
+                                                          int view_groups) {
   __shared__ uint32_t hist[256], cursor[256], s_max[4], tmp[8];
   const int c = (int)blockIdx.x;
   const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint32_t levels = 256u / (uint32_t)view_groups;
+  // work (low 24 bits) | group of the tile's view (high bits)
   auto work_of = [&](int q) -> uint32_t {
     const int bid = 8 * q + c;
+    int k = 0;
+    for (int j = 1; j < batch.n; j++) k = bid >= batch.v[j].block_base ? j : k;
     const BlendView bv = select_view(batch, bid);
     const int tile = tile_of_block(bid - bv.block_base, bv.ntiles);
-    return tile < bv.ntiles ? bv.tile_work[tile] : 0u;
+    const uint32_t wk = tile < bv.ntiles ? min(bv.tile_work[tile], 0xFFFFFFu) : 0u;
+    return wk | ((uint32_t)(k * view_groups / batch.n) << 24);
   };
   // the work of the class's tiles is read once into LDS (the three passes below recompute nothing); classes larger than
   // the cache fall back to reading it again
@@ -1036,14 +1048,17 @@ __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint
   __syncthreads();
   auto work_at = [&](int q) -> uint32_t { return q < ORDER_CACHE ? s_work[q] : work_of(q); };
   uint32_t m = 0;
-  for (int q = (int)threadIdx.x; q < cls_size; q += 256) m = max(m, work_at(q));
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) m = max(m, work_at(q) & 0xFFFFFFu);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
   if (lane == 0) s_max[w] = m;
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const float scale = 255.0f / (float)max(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), 1u);
-  for (int q = (int)threadIdx.x; q < cls_size; q += 256) atomicAdd(&hist[255u - (uint32_t)((float)work_at(q) * scale)], 1u);
+  const float scale = (float)(levels - 1u) / (float)max(max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])), 1u);
+  auto bucket_of = [&](uint32_t wk) -> uint32_t {   // group-major, heaviest first inside the group
+    return (wk >> 24) * levels + (levels - 1u) - (uint32_t)((float)(wk & 0xFFFFFFu) * scale);
+  };
+  for (int q = (int)threadIdx.x; q < cls_size; q += 256) atomicAdd(&hist[bucket_of(work_at(q))], 1u);
   __syncthreads();
   {   // exclusive scan of the 256 bucket counts (bucket 0 = heaviest)
     const uint32_t v = hist[threadIdx.x];
@@ -1061,7 +1076,7 @@ __global__ void __launch_bounds__(256) blend_order_kernel(BlendBatch batch, uint
   }
   __syncthreads();
   for (int q = (int)threadIdx.x; q < cls_size; q += 256) {
-    const uint32_t b = 255u - (uint32_t)((float)work_at(q) * scale);
+    const uint32_t b = bucket_of(work_at(q));
     order[(size_t)c * cls_size + atomicAdd(&cursor[b], 1u)] = (uint32_t)q;
   }
   if (c == 0 && threadIdx.x == 0) {   // the next forward of this batch shape may reuse the order
@@ -1085,7 +1100,11 @@ void b3gs_launch_blend_backward(BlendBatch batch, hipStream_t s) {
   batch.order = nullptr;
   batch.cls_size = total / 8;
   if (lpt && order && order_fits(batch, total, &batch.sig_off, &batch.sig)) {
-    hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(256), 0, s, batch, order, batch.cls_size);
+    // default: at most three views per group (6 views: two groups; pairs stay together); B3GS_BWD_VIEW_GROUPS overrides (A/B)
+    static const int groups_env = getenv("B3GS_BWD_VIEW_GROUPS") ? atoi(getenv("B3GS_BWD_VIEW_GROUPS")) : 0;
+    const int want = groups_env > 0 ? groups_env : (batch.n + 2) / 3;
+    const int groups = want < 1 ? 1 : (want > batch.n ? batch.n : want);
+    hipLaunchKernelGGL(blend_order_kernel, dim3(8), dim3(256), 0, s, batch, order, batch.cls_size, groups);
     batch.order = order;
   }
   // B3GS_BWD_TRACE=1: per-wave {cycles, wall start|end, iterations, live iterations} (tools/bwd_trace.py)

@@ -3,7 +3,8 @@
 warmed-up step of bench_ref_schedule.py's surfaces: blocks of 40 iterations cycle through the settings, so all of them see the
 same host; median and best block per setting.  (Two runs of the same code differ by +-15 % on the shared host of the GPU box:
 separate runs cannot resolve a 10 % effect.)  Experiments:
-  lazy   the pending pair forward of render(): adaptive rule (default) | always wait for the partner | never (every view at once)"""
+  lazy   the pending pair forward of render(): adaptive rule (default) | always wait for the partner | never (every view at once)
+  lazymax  B3GS_DROPIN_LAZY_MAX 2 | 8"""
 import statistics
 import sys
 import time
@@ -25,7 +26,16 @@ def set_lazy(mode):
     R._S.adapt.clear()
 
 
-EXPERIMENTS = {"lazy": (("adaptive", "always", "never"), set_lazy)}
+def set_lazy_max(mode):
+    R._flush_pending()
+    R._LAZY_FWD, R._LAZY_WHEN_IDLE = True, True
+    R._LAZY_MAX = int(mode)
+
+
+EXPERIMENTS = {"lazy": (("adaptive", "always", "never"), set_lazy),
+               # renders per pending forward: 2 = the second render of a pair launches the batch when it returns; 8 = nothing
+               # launches until an output is touched (or eight renders are pending)
+               "lazymax": (("2", "8"), set_lazy_max)}
 modes, setter = EXPERIMENTS[exp]
 
 
