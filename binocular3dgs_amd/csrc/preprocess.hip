@@ -959,10 +959,19 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
   __shared__ uint32_t s_wcnt[B3GS_MAX_FUSED_VIEWS][4];
   __shared__ uint32_t s_chunk[B3GS_MAX_FUSED_VIEWS * 4];      // view | first position << 8 | positions << 20
   __shared__ uint32_t s_nchunk;
-  const int blk_first = first + (int)blockIdx.x * ACC_BLOCK;
+  // One workgroup per GROUP of CH_GROUP list entries of a scan block (round 6; until then one workgroup per scan block looped
+  // over its groups): the lists of neighbouring blocks differ wildly when the storage order of the Gaussians is spatially
+  // coherent -- a model stored in Morton order put 1024 entries into some blocks and none into most, and the chain rule took
+  // 53 us per view instead of 20 (tools/spatial_order_probe.py) -- while the scan wants its 1024-Gaussian blocks for streaming.
+  // Empty groups exit on their first load.
+  // (part-major: workgroups go round-robin over the eight XCDs by index, and with block-major numbering the first groups --
+  // the only ones with work when the lists are short -- all landed on XCDs 0 and 4: measured, 20 -> 37 us per view)
+  const uint32_t nblk = gridDim.x / (uint32_t)ACC_PER_THREAD;
+  const uint32_t blk = blockIdx.x % nblk, part = blockIdx.x / nblk;
+  const int blk_first = first + (int)blk * ACC_BLOCK;
   const int nrest = 3 * (base.M - 1);
-  const uint32_t* __restrict__ s_list = g_list + (size_t)blockIdx.x * ACC_BLOCK;
-  const uint32_t n_list = g_count[blockIdx.x];
+  const uint32_t* __restrict__ s_list = g_list + (size_t)blk * ACC_BLOCK;
+  const uint32_t n_list = min(g_count[blk], (part + 1u) * (uint32_t)CH_GROUP);
   const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   SceneX sx_;
@@ -971,7 +980,7 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
   sx_.raw_mode = 1;
   sx_.tight = 0;
 #pragma unroll 1
-  for (uint32_t e0 = 0; e0 < n_list; e0 += CH_GROUP) {
+  for (uint32_t e0 = part * (uint32_t)CH_GROUP; e0 < n_list; e0 += CH_GROUP) {   // (at most one trip)
     const uint32_t e = e0 + threadIdx.x;
     const uint32_t ent = e < n_list ? s_list[e] : 0u;
     const uint32_t mask = ent >> 16;
@@ -1154,7 +1163,7 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   if (big) {
     const dim3 grid((count + 1023) / 1024);
     hipLaunchKernelGGL(accumulate_scan_kernel<4>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
-    hipLaunchKernelGGL(accumulate_chain_kernel<4>, grid, dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
+    hipLaunchKernelGGL(accumulate_chain_kernel<4>, dim3(grid.x * 4), dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
   } else {
     const dim3 grid((count + 255) / 256);
     hipLaunchKernelGGL(accumulate_scan_kernel<1>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);

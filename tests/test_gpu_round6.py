@@ -80,3 +80,64 @@ def test_an_error_inside_a_cpp_node_keeps_its_python_type_through_the_engine():
     v = ssim(x, torch.rand(1, 3, 8, 8, device="cuda"))
     with pytest.raises(RuntimeError):                          # a gradient of the wrong shape: refused by the engine itself
         v.backward(torch.ones(2, device="cuda"))
+
+
+def test_chain_rule_with_long_lists_per_scan_block_spatially_coherent_storage_order():
+    """The multi-view chain rule cuts every 1024-Gaussian scan block's list of touched Gaussians into groups of 256, one
+    workgroup each (round 6).  A model stored in RANDOM order puts ~200 entries into every block (one group); the same Gaussians
+    stored in Morton order of their positions put up to 1024 into some blocks and none into most -- all four groups of a block,
+    and empty workgroups, then really occur.  Same Gaussians, same six views, same pixel gradients: the parameter gradients and
+    the densification statistics must be the permutation of each other."""
+    import numpy as np
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.fused import FusedRasterizer
+    from binocular3dgs_amd.gaussian_model import GaussianModel
+    from helpers import rel_l2
+    P, W, H = 800_000, 400, 300
+    raw = synth.synth_gaussians(P, seed=12, width=W, height=H)
+    q = ((raw["xyz"] - raw["xyz"].min(0).values) / (raw["xyz"].max(0).values - raw["xyz"].min(0).values) * 1023).long().clamp(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+    perm = torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)
+    pairs = synth.synth_view_set(W, H, device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=3, device="cuda")
+
+    def run(order):
+        t = {n: (v if order is None else v[order]).contiguous() for n, v in raw.items()}
+        model = GaussianModel.from_tensors(t["xyz"], t["features_dc"], t["features_rest"], t["scaling"], t["rotation"],
+                                           t["opacity"], sh_degree=1, active_sh_degree=1, device="cuda")
+        model.init_densification_stats()
+        fr = FusedRasterizer(model, W, H, num_slots=6, want_means2D=False, seg1_fraction=0.0)
+        views = [(c, 2 * k + r, r == 0) for k, (cam, scam, _) in enumerate(pairs) for r, c in enumerate((cam, scam))]
+        fr.fit_capacity([(c, s) for c, s, _ in views], bg)
+        outs = fr.render_batch(views, bg)
+        o_t, g_t = [], []
+        for o, (_, _, prim) in zip(outs, views):
+            o_t.append(o["render"]); g_t.append(gc)
+            if prim:
+                o_t += [o["rendered_depth"], o["rendered_alpha"]]; g_t += [gd, ga]
+        torch.autograd.backward(o_t, g_t)
+        torch.cuda.synchronize()
+        assert int(fr.overflow_flag.item()) == 0
+        return ([p.grad.detach().cpu().numpy() for p in model.parameters()], model.xyz_gradient_accum.cpu().numpy().ravel(),
+                model.denom.cpu().numpy().ravel())
+
+    ga_r, acc_r, den_r = run(None)
+    ga_m, acc_m, den_m = run(perm)
+    pn = perm.numpy()
+    assert np.array_equal(den_m, den_r[pn]) and den_r.max() >= 1
+    # (the bars of the oracle comparisons: another storage order is another order of the fp32 atomic sums, and equal depth keys --
+    # ties keep their index order -- blend in another order)
+    assert rel_l2(acc_m, acc_r[pn]) < 2e-4
+    touched = np.abs(ga_r[0]).sum(1) > 0
+    assert 0.02 < touched.mean() < 0.9
+    # the Morton-ordered run really had scan blocks whose lists exceed one group of 256 (and blocks with none)
+    per_block = np.add.reduceat((np.abs(ga_m[0]).sum(1) > 0).astype(np.int64), np.arange(0, P, 1024))
+    assert per_block.max() > 256 and per_block.min() == 0
+    for a, b, n in zip(ga_m, ga_r, "xyz f_dc f_rest scaling rotation opacity".split()):
+        assert rel_l2(a, b[pn]) < 2e-4, n
