@@ -253,6 +253,14 @@ _ORDER_HINT = os.environ.get("B3GS_DROPIN_ORDER_HINT", "1") != "0"
 # B3GS_DROPIN_LAZY=0: every render() launches its forward before it returns (see _LazyOut / _launch_forward)
 _LAZY_FWD = os.environ.get("B3GS_DROPIN_LAZY", "1") != "0"
 _LAZY_MAX = max(1, min(8, int(os.environ.get("B3GS_DROPIN_LAZY_MAX", "2"))))    # renders per batched forward (a pair)
+# Round 6: the number of renders a pending forward waits for FOLLOWS THE LOOP unless B3GS_DROPIN_LAZY_MAX pins it: train.py
+# renders a pair and consumes it (2: the second render launches the batch when it returns, no NaN fill, nothing moves behind the
+# first touch -- measured 1.4-4 % better for that loop than "wait until touched"); a loop that renders its six views before it
+# consumes any gets ONE six-view forward (+18 % on the 6-view iteration).  Rule (_lazy_adapt_step, once per backward()): grow to
+# the number of differentiated renders since the previous backward (at most 8) when none of the pending batches of that
+# iteration was consumed before it was full; a batch consumed early (a touch while fewer than the current maximum are pending)
+# shrinks the maximum to that size and blocks growth for a while (4, 8, ... 64 iterations).  B3GS_DROPIN_LAZY_ADAPT=0: fixed.
+_LAZY_ADAPT = ("B3GS_DROPIN_LAZY_MAX" not in os.environ) and os.environ.get("B3GS_DROPIN_LAZY_ADAPT", "1") != "0"
 # B3GS_DROPIN_LAZY_IDLE=0: a render waits for its partner only while the stream is busy or while an adaptive rule (see
 # _RasterizeRaw.forward) finds that starting at once does not overlap anything.  Default 1 = always wait: measured INTERLEAVED
 # inside one process (tools/ab_interleaved.py lazy: blocks of 40 iterations cycling through the settings, medians of 12 --
@@ -282,6 +290,7 @@ class _DropinState:
         self.word_ring = {}       # device index -> [zeroed int32 ring, next slot]
         self.busy = {}            # (device index, stream) -> event behind the last forward / backward this module launched there
         self.adapt = {}           # (device index, stream) -> the eager-on-idle rule's memory (see _RasterizeRaw.forward)
+        self.lazy_adapt = {}      # device index -> the adaptive batch size of pending forwards (see _LAZY_ADAPT)
         self.stats = {"hinted": 0, "trusted": 0, "deferred": 0, "batched_views": 0, "launches": 0, "lazy_batches": 0,
                       "lazy_views": 0, "shared": 0, "eager_idle": 0}   # (tests / bench read these)
 
@@ -412,6 +421,37 @@ class _LazyOut(torch.Tensor):
             return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
 
 
+def _lazy_max(di) -> int:
+    """Renders a pending forward of device `di` waits for (>= _LAZY_MAX: a test or tool that raises _LAZY_MAX still gets it)."""
+    if not _LAZY_ADAPT:
+        return _LAZY_MAX
+    a = _S.lazy_adapt.get(di)
+    return _LAZY_MAX if a is None else max(_LAZY_MAX, a["max"])
+
+
+def _lazy_adapt_state(di):
+    a = _S.lazy_adapt.get(di)
+    if a is None:
+        a = _S.lazy_adapt[di] = {"max": _LAZY_MAX, "renders": 0, "small": 0, "hold": 0, "fails": 0}
+    return a
+
+
+def _lazy_adapt_step():
+    """Once per backward() (its final callback): see _LAZY_ADAPT."""
+    for a in _S.lazy_adapt.values():
+        renders, a["renders"] = a["renders"], 0
+        small, a["small"] = a["small"], 0
+        if small:
+            if small < a["max"]:
+                a["max"] = max(_LAZY_MAX, small)
+                a["hold"] = min(64, 4 << a["fails"])
+                a["fails"] = min(a["fails"] + 1, 4)
+        elif a["hold"] > 0:
+            a["hold"] -= 1
+        elif renders > a["max"]:
+            a["max"] = min(8, renders)
+
+
 def touch_pending(*tensors):
     """For consumers that do NOT go through torch's function dispatch -- the entry points of the compiled `_C` module read
     raw pointers: a pending output among `tensors` launches what is pending first (what `_LazyOut.__torch_function__` does
@@ -424,11 +464,14 @@ def touch_pending(*tensors):
 
 
 @_locked
-def _flush_pending(di=None):
-    """Launch the pending forwards (of one device, or of all)."""
+def _flush_pending(di=None, full=False):
+    """Launch the pending forwards (of one device, or of all).  full: the batch reached its size (not: somebody needed it)."""
     for d in ([di] if di is not None else list(_pending_fwd)):
         lst = _pending_fwd.pop(d, None)
         if lst:
+            if _LAZY_ADAPT and not full and len(lst) < _lazy_max(d):
+                a = _lazy_adapt_state(d)
+                a["small"] = len(lst) if not a["small"] else min(a["small"], len(lst))
             _launch_forward(lst)
 
 
@@ -662,6 +705,8 @@ def _end_of_backward(task):
     st = _S.tasks.pop(task, None)
     if st is None:
         return
+    if _LAZY_ADAPT:
+        _lazy_adapt_step()
     for ref in st.flush:
         node = ref()
         jobs = getattr(node, "pending", None) if node is not None else None
@@ -835,7 +880,10 @@ class _RasterizeRaw(torch.autograd.Function):
         # ([5,H,W]: colour | depth | alpha) and render()'s `visibility_filter` = radii > 0 (written by the projection,
         # B3gsForwardView::visible).  The image state is recycled allocator memory: `fresh_image` tells the library to read
         # nothing from it.  A render that will wait for its partner gets NaN images (see _LazyOut) unless it completes the batch
-        nan_fill = wait and len(pend or ()) + 1 < _LAZY_MAX
+        lazy_max = _lazy_max(di)
+        if _LAZY_ADAPT and cfg["differentiated"]:
+            _lazy_adapt_state(di)["renders"] += 1
+        nan_fill = wait and len(pend or ()) + 1 < lazy_max
         view, geom, img, out, color, depth, alpha, radii, vis, binning = _C.raw_prepare(
             xyz, f_dc, f_rest, scaling, rotation, opacity, cfg["bg"], cfg["viewmatrix"], cfg["projmatrix"], cfg["campos"], W, H,
             cfg["tanfovx"], cfg["tanfovy"], cfg["scale_modifier"], int(cfg["sh_degree"]), bool(cfg["debug"]), cap,
@@ -868,8 +916,8 @@ class _RasterizeRaw(torch.autograd.Function):
             cfg["pending"] = p
             lst = _pending_fwd.setdefault(di, [])
             lst.append(p)
-            if len(lst) >= _LAZY_MAX:
-                _flush_pending(di)
+            if len(lst) >= lazy_max:
+                _flush_pending(di, full=True)
         else:
             first = True
             while True:

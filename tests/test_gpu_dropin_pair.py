@@ -74,6 +74,7 @@ def _forward_mode(request):
     returns, which is what the depth-order hint / adoption mechanism they pin is about."""
     import binocular3dgs_amd.rasterizer as R
     R._flush_pending()
+    R._S.lazy_adapt.clear()       # (the adaptive batch size of pending forwards starts from its initial state in every test)
     old = R._LAZY_FWD, R._LAZY_WHEN_IDLE
     R._LAZY_FWD = request.node.name.startswith("test_lazy")
     R._LAZY_WHEN_IDLE = True      # (these tests pin the pending-forward machinery itself: it must engage on an idle device too)
@@ -855,6 +856,69 @@ def test_lazy_max_above_two_batches_every_pending_render_of_the_iteration():
 # ---------------------------------------------------------------------------------------------------------------------
 # round 5: hardening of the zero-change surface
 # ---------------------------------------------------------------------------------------------------------------------
+def test_lazy_batch_size_follows_the_loop():
+    """Round 6: the number of renders a pending forward waits for adapts to the loop (rasterizer._LAZY_ADAPT).
+    (i) a loop that renders its six views before it consumes any: two renders per forward in the first iteration, ONE six-view
+        forward from the second on, the same gradients;
+    (ii) the same six renders consumed pair by pair: the first early touch shrinks the batch back to a pair, growth is blocked;
+    (iii) train.py's shape (a pair, consumed at once) never leaves two."""
+    import binocular3dgs_amd.rasterizer as R
+    from binocular3dgs_amd import synth
+    from binocular3dgs_amd.render import PipelineParams, render
+    assert R._LAZY_ADAPT and R._LAZY_MAX == 2
+    W, H = 160, 120
+    model = _model(P=8000, W=W, H=H)
+    bg = torch.zeros(3, device="cuda")
+    pairs = synth.synth_view_set(W, H, device="cuda")
+    gc, gd, ga = synth.synth_pixel_grads(W, H, seed=1, device="cuda")
+    pipe = PipelineParams()
+
+    def iteration(consume_per_pair):
+        for p in model.parameters():
+            p.grad = None
+        outs, total = [], 0.0
+        for cam, scam, _ in pairs:
+            a, b = render(cam, model, pipe, bg), render(scam, model, pipe, bg)
+            if consume_per_pair:
+                total = total + _loss(a, b, gc, gd, ga)
+            else:
+                outs.append((a, b))
+        for a, b in outs:
+            total = total + _loss(a, b, gc, gd, ga)
+        total.backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    s0 = R._stats["lazy_batches"]
+    g1 = iteration(False)
+    assert R._stats["lazy_batches"] == s0 + 3 and R._lazy_max(0) == 6          # three pairs; the rule saw six renders, all full
+    g2 = iteration(False)
+    assert R._stats["lazy_batches"] == s0 + 4                                    # ONE six-view forward
+    g3 = iteration(False)
+    assert R._stats["lazy_batches"] == s0 + 5 and R._lazy_max(0) == 6
+    for a, b, c in zip(g1, g2, g3):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5 and rel_l2(c.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    # (ii) the consumer now touches every pair as soon as it exists
+    s1 = R._stats["lazy_batches"]
+    g4 = iteration(True)
+    assert R._stats["lazy_batches"] == s1 + 3 and R._lazy_max(0) == 2 and R._S.lazy_adapt[0]["hold"] >= 4
+    g5 = iteration(True)
+    assert R._stats["lazy_batches"] == s1 + 6 and R._lazy_max(0) == 2
+    for a, b in zip(g1, g5):
+        assert rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    iteration(False)                         # growth stays blocked for a while after an early touch
+    assert R._lazy_max(0) == 2
+    # (iii) one pair per iteration, consumed at once
+    R._S.lazy_adapt.clear()
+    cam, scam, _ = pairs[0]
+    for _ in range(4):
+        for p in model.parameters():
+            p.grad = None
+        a, b = render(cam, model, pipe, bg), render(scam, model, pipe, bg)
+        assert not R._pending_fwd               # the second render launched the pair when it returned
+        _loss(a, b, gc, gd, ga).backward()
+        assert R._lazy_max(0) == 2
+
+
 def test_lazy_outputs_become_plain_tensors_once_launched_and_survive_save_dlpack_numpy_deepcopy(tmp_path):
     """A pending output handed out by render() is a private subclass only WHILE it is pending: whatever launches the
     forward turns every handed-out object back into torch.Tensor.  torch.save / load, dlpack, __cuda_array_interface__,

@@ -28,7 +28,7 @@ def set_lazy(mode):
 
 def set_lazy_max(mode):
     R._flush_pending()
-    R._LAZY_FWD, R._LAZY_WHEN_IDLE = True, True
+    R._LAZY_FWD, R._LAZY_WHEN_IDLE, R._LAZY_ADAPT = True, True, False
     R._LAZY_MAX = int(mode)
 
 
