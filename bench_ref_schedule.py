@@ -33,7 +33,6 @@ import gc
 import random
 import time
 
-import numpy as np
 import torch
 
 LR = (0.00016, 0.0025, 0.0025 / 20.0, 0.005, 0.001, 0.05)      # model order: xyz, f_dc, f_rest, scaling, rotation, opacity
