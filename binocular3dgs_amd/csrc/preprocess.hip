@@ -1180,7 +1180,9 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   // scratch of the two-kernel pass: the depth-sort ping-pong arrays of view 0's geometry buffer (P words each) are idle
   // once the forward has built its tile lists
   static const int force = getenv("B3GS_ACC_PER_THREAD") ? atoi(getenv("B3GS_ACC_PER_THREAD")) : 0;   // (A/B switch)
-  const bool big = force ? force >= 4 : count >= (1 << 19) + (1 << 18);   // from 768k Gaussians: 1024 per workgroup
+  // from 384k Gaussians: 1024 per scan workgroup (round 6: 768k until the chain rule ran one workgroup per list group -- the
+  // 500k-Gaussian ranges of the pipelined data-parallel tail at 1M then gain 1 %: 602-607 -> 610-613 iters/s on the 1-rank group)
+  const bool big = force ? force >= 4 : count >= (1 << 18) + (1 << 17);
   if (big) {
     const dim3 grid((count + 1023) / 1024);
     hipLaunchKernelGGL(accumulate_scan_kernel<4>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
