@@ -11,9 +11,28 @@ Layout:
   synth.py              deterministic synthetic scenes of BASELINE.md section 3
   step.py               view-sharded training step (loss block of train.py:123-149, RCCL all-reduce)
 """
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
-                         _C, _RasterizeGaussians)
+import os as _os
+import sysconfig as _sysconfig
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C",
            "_RasterizeGaussians"]
 __version__ = "0.1.0"
+
+_EXT = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_C" + (_sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+if _os.path.exists(_EXT):
+    from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,  # noqa: F401
+                             _C, _RasterizeGaussians)
+else:
+    # A tree that has not been built yet: `python -m binocular3dgs_amd.build` (and __graft_entry__.build()) must be able to
+    # import the package to reach build.py; every product name fails loudly until the compiled module exists -- there is no
+    # python or CPU stand-in for it.
+    def __getattr__(name):
+        if name not in __all__:
+            raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+        if not _os.path.exists(_EXT):
+            raise ImportError(f"{_EXT} has not been built: run `python -m binocular3dgs_amd.build` "
+                              "(hipcc for gfx950 + g++ against the torch headers); there is no fallback")
+        import importlib
+        if name == "_C":
+            return importlib.import_module("._C", __name__)
+        return getattr(importlib.import_module(".rasterizer", __name__), name)
