@@ -72,6 +72,12 @@ static Scene make_scene(const Tensor& background, const Tensor& means3D_in, cons
   if (bg.numel() != 3 || vm.numel() != 16 || pm.numel() != 16 || cp.numel() != 3)
     throw py::value_error("bg/campos must have 3 and viewmatrix/projmatrix 16 elements");
   for (const Tensor& t : {opacity_t, bg, vm, pm, cp}) s.keep.push_back(t);
+  // one launch reads every tensor through raw pointers on the device of means3D: a tensor of another GPU would be a wild
+  // pointer there (the upstream binding leaves that to the CUDA runtime; here it is an argument error)
+  for (const Tensor& t : s.keep)
+    if (t.device() != s.dev)
+      throw py::value_error("all rasterizer inputs must live on the device of means3D (" + s.dev.str() + "), got a tensor on " +
+                            t.device().str());
   B3gsScene& c = s.sc;
   c.P = (int32_t)s.P, c.D = (int32_t)degree, c.M = (int32_t)s.M, c.W = (int32_t)W, c.H = (int32_t)H;
   c.tan_fovx = (float)tan_fovx, c.tan_fovy = (float)tan_fovy, c.scale_modifier = (float)scale_modifier;
