@@ -4,7 +4,7 @@
 var=$1; vals=$2
 for f in $vals; do
   export $var=$f
-  timeout 900 python -m pytest tests/test_gpu_bwd_kernels.py tests/test_gpu_fused.py tests/test_gpu_bench_config.py -x -q 2>&1 | tail -1
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bwd_kernels.py tests/test_gpu_fused.py tests/test_gpu_bench_config.py -x -q 2>&1 | tail -1
 done
 run() { python bench.py --steps 40 --warmup 5 --no-extras --no-pmc --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
