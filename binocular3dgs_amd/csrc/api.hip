@@ -656,6 +656,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
     return fail(B3GS_ERR_ARG, "%s", "NULL gradient buffer");
   B3gsViewRef refs[B3GS_MAX_FUSED_VIEWS];
   uint32_t *list = nullptr, *counts = nullptr;
+  static const bool no_staged = getenv("B3GS_NO_STAGED") != nullptr;   // (A/B switch, read once: every visible row is read)
   for (int k = 0; k < nviews; k++) {
     const B3gsFusedView& fv = views[k];
     if (!fv.view || !fv.radii || !fv.geometry || !fv.scratch) return fail(B3GS_ERR_ARG, "%s", "NULL view state");
@@ -666,7 +667,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
     if (k == 0) { list = g.skey[1]; counts = g.skey[0]; }   // idle after the forward's depth sort
     refs[k] = B3gsViewRef{fv.view->W, fv.view->H, fv.view->tan_fovx, fv.view->tan_fovy, fv.view->viewmatrix,
                           fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D,
-                          fv.densify_stats};
+                          fv.densify_stats, no_staged ? nullptr : g.staged, g.header + B3GS_GEOM_EPOCH};
   }
   if (stats && (!stats->xyz_gradient_accum || !stats->denom || !stats->max_radii2D))
     return fail(B3GS_ERR_ARG, "%s", "densify stats need all three arrays");

@@ -43,7 +43,14 @@ struct GeomView {       // sized by P
                         //       Gaussians in depth order (local index | view flags); their number in fcount
   uint32_t* fcount;     // [ceil(P / 4096)]
   uint32_t* tsum;       // [ceil(P / 4096)] tile instances of every 4096-Gaussian tile of the depth order
+  uint8_t* staged;      // [P]   staged[i] == the forward's epoch (header[B3GS_GEOM_EPOCH]): Gaussian i sits in some tile's list
+                        //       below that tile's deepest used position, i.e. the blend backward MAY flush into its scratch
+                        //       row; any other value (an older forward's epoch, garbage of a fresh buffer): it cannot.  The
+                        //       chain rule's scan reads the 40-byte rows of the marked Gaussians only (~5 % of the visible ones).
 };
+// word of GeomView::header: the forward's epoch, 1..255, advanced by the first scan of every forward (binning.hip); a stale
+// mark that happens to carry the current value again (255 forwards later, or garbage) only costs the scan a row read
+#define B3GS_GEOM_EPOCH 8
 
 struct BinView {        // sized by N (and P for the histogram)
   uint32_t* key[2];     // [N] tile id ping/pong
@@ -132,6 +139,7 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.flist = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096 * 4096);
   t.fcount = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096);
   t.tsum = b3gs_carve<uint32_t>(cur, (p + 4095) / 4096);
+  t.staged = b3gs_carve<uint8_t>(cur, p);
   if (v) *v = t;
   return (size_t)(cur - base);
 }
@@ -338,6 +346,8 @@ struct BlendView {
                            //          2 = all tiles over segment 1 + segment 2 (re-blend of a finished forward's state)
   uint32_t idx_mask;       // Gaussian index = point_list[j] & idx_mask (packed tile|index words, see b3gs_packed_idx_bits)
   const float4* rec;
+  uint8_t* staged;         // forward: GeomView::staged (null: no marks) and the epoch to write there
+  const uint32_t* epoch;
   const float* bg;
   float* final_T;          // forward: written; backward: read
   uint32_t* n_contrib;
@@ -384,6 +394,8 @@ struct B3gsViewRef {
   float* scratch;            // the view's phase-1 sums (reset to zero here)
   float* dL_dmeans2D;        // optional
   int32_t densify_stats;
+  const uint8_t* staged;     // GeomView::staged / the epoch its forward wrote (null: read every visible Gaussian's row)
+  const uint32_t* epoch;
 };
 void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& raw, int nviews, const B3gsViewRef* views,
                                   const B3gsRawGrads& rg, int overwrite, const B3gsDensifyStats* stats, int first, int count,

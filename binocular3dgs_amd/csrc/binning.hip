@@ -532,6 +532,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_chunk_offsets(ScanBatch sb)
     job.header[0] = tot;   // N (segment 1)
     job.header[1] = totv;  // V
     job.header[2] = 0u;    // N2: set by the second binning round, if one runs
+    job.header[B3GS_GEOM_EPOCH] = job.header[B3GS_GEOM_EPOCH] % 255u + 1u;   // this forward's staged-mark value (1..255)
     if (job.img_header) { job.img_header[0] = tot; job.img_header[1] = totv; job.img_header[2] = 0u; job.img_header[3] = 0u; }
     if (job.n_out) *job.n_out = (int32_t)tot;
     if (job.high_water) atomicMax(job.high_water, (int32_t)min(tot, 0x7FFFFFFFu));

@@ -880,6 +880,11 @@ __global__ void __launch_bounds__(256, 8)
   const int nrest = 3 * (base.M - 1);
   // a step rendered from truncated tile lists leaves the densification statistics alone (B3gsDensifyStats)
   const bool skip_stats = ds.skip_if_nonzero && *ds.skip_if_nonzero != 0;
+  // the epoch byte of every view's forward (GeomView::staged), read once: eight bytes in one scalar pair
+  unsigned long long epochs = 0ull;
+#pragma unroll
+  for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++)
+    if (v < mv.n && mv.v[v].staged) epochs |= (unsigned long long)(*mv.v[v].epoch & 0xFFu) << (8 * v);
 
   // ---- phase 1 ------------------------------------------------------------------------------------------
 #pragma unroll 1
@@ -891,27 +896,46 @@ __global__ void __launch_bounds__(256, 8)
       const size_t i3 = 3 * (size_t)i;
       float st_norm = 0.f, st_cnt = 0.f;
       int st_rad = 0;
+      // every view's radius and mark first, all loads in flight together (no control flow around them); the blend forward
+      // marks the Gaussians that sit below the deepest used position of some tile's list (GeomView::staged): only their
+      // rows can hold anything -- ~5 % of the visible ones -- and the others are known to be zero without being read
+      uint32_t vis = 0u, stg = 0u;
+#pragma unroll
+      for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++) {
+        if (v < mv.n) {
+          const B3gsViewRef& vr = mv.v[v];
+          const int rad = vr.radii[i];
+          const uint8_t ep = (uint8_t)(epochs >> (8 * v));
+          const uint8_t mk = vr.staged ? vr.staged[i] : ep;
+          if (rad > 0) {
+            vis |= 1u << v;
+            if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
+              st_cnt += 1.0f;
+              st_rad = max(st_rad, rad);
+            }
+          }
+          if (mk == ep) stg |= 1u << v;
+        }
+      }
       for (int v = 0; v < mv.n; v++) {
         const B3gsViewRef& vr = mv.v[v];
         float* m2d = vr.dL_dmeans2D;
-        const int rad = vr.radii[i];
-        if (rad <= 0) {
+        if (!((vis >> v) & 1u)) {
           if (m2d) { m2d[i3] = 0.f; m2d[i3 + 1] = 0.f; m2d[i3 + 2] = 0.f; }
           continue;
         }
-        const float2* row = reinterpret_cast<const float2*>(vr.scratch) + 5 * (size_t)i;
-        const float2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+        float2 r0 = make_float2(0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+        if ((stg >> v) & 1u) {
+          const float2* row = reinterpret_cast<const float2*>(vr.scratch) + 5 * (size_t)i;
+          r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4];
+        }
         // sums are never -0.0 (atomic adds onto +0.0), so the bit pattern tells "nothing arrived"
         const uint32_t any = ((__float_as_uint(r0.x) | __float_as_uint(r0.y)) | (__float_as_uint(r1.x) | __float_as_uint(r1.y))) |
                              ((__float_as_uint(r2.x) | __float_as_uint(r2.y)) | (__float_as_uint(r3.x) | __float_as_uint(r3.y))) |
                              (__float_as_uint(r4.x) | __float_as_uint(r4.y));
         if (any) mask |= 1u << v;
         if (m2d) { m2d[i3] = r2.x; m2d[i3 + 1] = r2.y; m2d[i3 + 2] = 0.f; }
-        if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
-          st_norm += sqrtf(r2.x * r2.x + r2.y * r2.y);
-          st_cnt += 1.0f;
-          st_rad = max(st_rad, rad);
-        }
+        if (vr.densify_stats) st_norm += sqrtf(r2.x * r2.x + r2.y * r2.y);
       }
       if (ds.denom && st_cnt > 0.f && !skip_stats) {
         ds.xyz_gradient_accum[i] += st_norm;
@@ -1183,7 +1207,11 @@ void b3gs_launch_accumulate_views(const B3gsScene& base, const B3gsRawParams& ra
   // from 384k Gaussians: 1024 per scan workgroup (round 6: 768k until the chain rule ran one workgroup per list group -- the
   // 500k-Gaussian ranges of the pipelined data-parallel tail at 1M then gain 1 %: 602-607 -> 610-613 iters/s on the 1-rank group)
   const bool big = force ? force >= 4 : count >= (1 << 18) + (1 << 17);
-  if (big) {
+  if (force == 2) {   // (experiment: 512 Gaussians per scan workgroup)
+    const dim3 grid((count + 511) / 512);
+    hipLaunchKernelGGL(accumulate_scan_kernel<2>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
+    hipLaunchKernelGGL(accumulate_chain_kernel<2>, dim3(grid.x * 2), dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);
+  } else if (big) {
     const dim3 grid((count + 1023) / 1024);
     hipLaunchKernelGGL(accumulate_scan_kernel<4>, grid, dim3(256), 0, s, base, mv, rg, overwrite, first, count, ds, list, counts);
     hipLaunchKernelGGL(accumulate_chain_kernel<4>, dim3(grid.x * 4), dim3(256), 0, s, base, raw, mv, rg, overwrite, first, list, counts);

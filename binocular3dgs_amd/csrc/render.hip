@@ -297,6 +297,17 @@ __device__ __forceinline__ void render_fwd_tile(const BlendView bv, int bid, uns
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
     if (lane == 0) s_work[w] = m;
     __syncthreads();
+    // GeomView::staged: the Gaussians at list positions below the tile's work are the only ones the blend backward of this
+    // tile can flush a gradient for; their mark gets this forward's epoch (the chain rule's scan reads only marked rows).
+    // (A tile re-blended by the second round marks again, over segment 1 + segment 2.)
+    if (bv.staged) {
+      const uint32_t wk = max(max(s_work[0], s_work[1]), max(s_work[2], s_work[3]));
+      const uint8_t ep = (uint8_t)*bv.epoch;
+      for (uint32_t q = tid; q < wk; q += 256u) {
+        const uint32_t word = q < tl.len1 ? tl.list1[tl.first1 + q] : tl.list2[tl.first2 + (q - tl.len1)];
+        bv.staged[word & bv.idx_mask] = ep;
+      }
+    }
     if (tid == 0) {
       const uint32_t work = max(max(s_work[0], s_work[1]), max(s_work[2], s_work[3]));
       bv.tile_work[tile] = work;
@@ -1159,6 +1170,9 @@ BlendView b3gs_blend_view(const B3gsScene& sc, const GeomView& g, const BinView&
   const int idx_bits = b3gs_packed_idx_bits(sc.P, sc.W, sc.H);
   v.idx_mask = (idx_bits < 0 || idx_bits >= 32) ? 0xFFFFFFFFu : ((1u << idx_bits) - 1u);
   v.rec = g.rec;
+  static const bool no_staged = getenv("B3GS_NO_STAGED") != nullptr;   // (A/B switch, read once: the scan then reads every row)
+  v.staged = no_staged ? nullptr : g.staged;
+  v.epoch = g.header + B3GS_GEOM_EPOCH;
   v.bg = sc.background;
   v.final_T = im.final_T;
   v.n_contrib = im.n_contrib;

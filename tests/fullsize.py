@@ -260,6 +260,10 @@ def fused_metrics(P, W, H, fov=60.0, seed=0, views=6, check_lists=True, seg1_fra
             g_t += [b, c]
     torch.autograd.backward(o_t, g_t)
     torch.cuda.synchronize()
+    # every scratch row the blend backward flushed into was read and reset by the chain rule's scan, which looks only at the
+    # rows of the Gaussians the blend forward marked (GeomView::staged): nothing may be left behind
+    for _c, s_, _p, _g in vlist:
+        assert float(fr.slots[s_].scratch.abs().max()) == 0.0, "a scratch row outside the marked set received a gradient"
     nr = fr.num_rendered()
     assert max(nr) <= fr.capacity and int(fr.overflow_flag.item()) == 0, "binning capacity overflow"
     m = dict(P=P, W=W, H=H, views=len(vlist), N_binned=nr, seg1_fraction=fr.seg1_fraction)

@@ -605,6 +605,11 @@ def test_two_round_binning_equals_one_round(scene):
         torch.autograd.backward(o, g)
         torch.cuda.synchronize()
         assert not fr.overflowed()
+        # the chain rule's scan reads -- and resets -- only the scratch rows of the Gaussians the blend forward marked
+        # (GeomView::staged: list positions below a tile's deepest used one, both binning rounds): a flush into an unmarked
+        # row would be left behind here (and its gradient missing below)
+        for v in vs:
+            assert float(fr.slots[v[1]].scratch.abs().max()) == 0.0, "a scratch row outside the marked set received a gradient"
         imgs = [[x[k].detach().clone() for k in ("render", "rendered_depth", "rendered_alpha")] for x in outs]
         st = [state_views(P, W, H, fr.capacity, fr.slots[v[1]].geom, fr.slots[v[1]].binning, fr.slots[v[1]].img) for v in vs]
         aux = [(v["final_T"].clone(), v["n_contrib"].clone(), int(v["counts"][0]), int(v["counts"][2])) for v in st]
