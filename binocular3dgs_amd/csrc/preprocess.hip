@@ -864,7 +864,7 @@ struct MultiViews {
 // they were a quarter of a workgroup per CU and pure latency (100k Gaussians, 2 views: 76 us in the chain-rule kernel;
 // a 250k-Gaussian range of the headline scene: 86 us per call whatever the range held)
 template <int ACC_PER_THREAD>
-__global__ void __launch_bounds__(256, 8)
+__global__ void __launch_bounds__(256, ACC_PER_THREAD >= 4 ? 4 : 8)
     accumulate_scan_kernel(B3gsScene base, MultiViews mv, B3gsRawGrads rg, int overwrite, int first, int count,
                            B3gsDensifyStats ds, uint32_t* __restrict__ g_list, uint32_t* __restrict__ g_count) {
   constexpr int ACC_BLOCK = 256 * ACC_PER_THREAD;
@@ -887,36 +887,57 @@ __global__ void __launch_bounds__(256, 8)
     if (v < mv.n && mv.v[v].staged) epochs |= (unsigned long long)(*mv.v[v].epoch & 0xFFu) << (8 * v);
 
   // ---- phase 1 ------------------------------------------------------------------------------------------
-#pragma unroll 1
+  // Load stage: the radii and marks of every view and the three statistics words of ALL of this thread's Gaussians are
+  // requested before anything is consumed (ACC_PER_THREAD x 15 independent loads: one round trip instead of two or three per
+  // Gaussian -- the 977 workgroups of a 1M-Gaussian call fill less than half of the chip's wave slots, so the pass is paid in
+  // round trips).  The blend forward marks the Gaussians that sit below the deepest used position of some tile's list
+  // (GeomView::staged): only their rows can hold anything -- ~5 % of the visible ones -- and the others are known to be zero
+  // without being read.
+  uint32_t vis_j[ACC_PER_THREAD], stg_j[ACC_PER_THREAD];
+  int rad_j[ACC_PER_THREAD];
+  float cnt_j[ACC_PER_THREAD], acc_j[ACC_PER_THREAD], den_j[ACC_PER_THREAD], mxr_j[ACC_PER_THREAD];
+  const bool do_stats = ds.denom && !skip_stats;
+#pragma unroll
+  for (int j = 0; j < ACC_PER_THREAD; j++) {
+    const int i = blk_first + j * 256 + (int)threadIdx.x;
+    const bool valid = i < end;
+    const int ic = valid ? i : end - 1;   // (end > first >= 0: the load stage has no control flow around its loads)
+    uint32_t vis = 0u, stg = 0u;
+    int st_rad = 0;
+    float st_cnt = 0.f;
+#pragma unroll
+    for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++) {
+      if (v < mv.n) {
+        const B3gsViewRef& vr = mv.v[v];
+        const int rad = vr.radii[ic];
+        const uint8_t ep = (uint8_t)(epochs >> (8 * v));
+        const uint8_t mk = vr.staged ? vr.staged[ic] : ep;
+        if (rad > 0) {
+          vis |= 1u << v;
+          if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
+            st_cnt += 1.0f;
+            st_rad = max(st_rad, rad);
+          }
+        }
+        if (mk == ep) stg |= 1u << v;
+      }
+    }
+    vis_j[j] = valid ? vis : 0u, stg_j[j] = stg, rad_j[j] = st_rad, cnt_j[j] = valid ? st_cnt : 0.f;
+    acc_j[j] = do_stats ? ds.xyz_gradient_accum[ic] : 0.f;
+    den_j[j] = do_stats ? ds.denom[ic] : 0.f;
+    mxr_j[j] = do_stats ? ds.max_radii2D[ic] : 0.f;
+  }
+#pragma unroll
   for (int j = 0; j < ACC_PER_THREAD; j++) {
     const int li = j * 256 + (int)threadIdx.x;
     const int i = blk_first + li;
     uint32_t mask = 0;
     if (i < end) {
       const size_t i3 = 3 * (size_t)i;
-      float st_norm = 0.f, st_cnt = 0.f;
-      int st_rad = 0;
-      // every view's radius and mark first, all loads in flight together (no control flow around them); the blend forward
-      // marks the Gaussians that sit below the deepest used position of some tile's list (GeomView::staged): only their
-      // rows can hold anything -- ~5 % of the visible ones -- and the others are known to be zero without being read
-      uint32_t vis = 0u, stg = 0u;
-#pragma unroll
-      for (int v = 0; v < B3GS_MAX_FUSED_VIEWS; v++) {
-        if (v < mv.n) {
-          const B3gsViewRef& vr = mv.v[v];
-          const int rad = vr.radii[i];
-          const uint8_t ep = (uint8_t)(epochs >> (8 * v));
-          const uint8_t mk = vr.staged ? vr.staged[i] : ep;
-          if (rad > 0) {
-            vis |= 1u << v;
-            if (vr.densify_stats) {   // visibility_filter = radii > 0 (train.py:178-179), contribution or not
-              st_cnt += 1.0f;
-              st_rad = max(st_rad, rad);
-            }
-          }
-          if (mk == ep) stg |= 1u << v;
-        }
-      }
+      float st_norm = 0.f;
+      const float st_cnt = cnt_j[j];
+      const int st_rad = rad_j[j];
+      const uint32_t vis = vis_j[j], stg = stg_j[j];
       for (int v = 0; v < mv.n; v++) {
         const B3gsViewRef& vr = mv.v[v];
         float* m2d = vr.dL_dmeans2D;
@@ -937,10 +958,10 @@ __global__ void __launch_bounds__(256, 8)
         if (m2d) { m2d[i3] = r2.x; m2d[i3 + 1] = r2.y; m2d[i3 + 2] = 0.f; }
         if (vr.densify_stats) st_norm += sqrtf(r2.x * r2.x + r2.y * r2.y);
       }
-      if (ds.denom && st_cnt > 0.f && !skip_stats) {
-        ds.xyz_gradient_accum[i] += st_norm;
-        ds.denom[i] += st_cnt;
-        ds.max_radii2D[i] = fmaxf(ds.max_radii2D[i], (float)st_rad);
+      if (do_stats && st_cnt > 0.f) {
+        ds.xyz_gradient_accum[i] = acc_j[j] + st_norm;
+        ds.denom[i] = den_j[j] + st_cnt;
+        ds.max_radii2D[i] = fmaxf(mxr_j[j], (float)st_rad);
       }
       if (mask == 0u && overwrite && !rg.touched_rows) {   // no view has a gradient for this Gaussian: its rows of the slab are zero
         rg.xyz[i3] = 0.f; rg.xyz[i3 + 1] = 0.f; rg.xyz[i3 + 2] = 0.f;
