@@ -666,7 +666,7 @@ int b3gs_backward_raw_accumulate_range(int32_t nviews, const B3gsFusedView* view
     b3gs_geom_view(const_cast<char*>(fv.geometry), v0->P, &g);
     if (k == 0) { list = g.skey[1]; counts = g.skey[0]; }   // idle after the forward's depth sort
     refs[k] = B3gsViewRef{fv.view->W, fv.view->H, fv.view->tan_fovx, fv.view->tan_fovy, fv.view->viewmatrix,
-                          fv.view->projmatrix, fv.view->campos, fv.radii, g.clamped, fv.scratch, fv.dL_dmeans2D,
+                          fv.view->projmatrix, fv.view->campos, fv.radii, reinterpret_cast<const float*>(g.rec), fv.scratch, fv.dL_dmeans2D,
                           fv.densify_stats, no_staged ? nullptr : g.staged, g.header + B3GS_GEOM_EPOCH};
   }
   if (stats && (!stats->xyz_gradient_accum || !stats->denom || !stats->max_radii2D))

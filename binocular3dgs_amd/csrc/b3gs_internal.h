@@ -390,7 +390,7 @@ struct B3gsViewRef {
   const float* projmatrix;
   const float* campos;
   const int32_t* radii;
-  const uint32_t* clamped;   // inside the view's geometry buffer
+  const float* rec_words;    // the view's render records as words (16 per Gaussian): word 12 = the SH clamp bits
   float* scratch;            // the view's phase-1 sums (reset to zero here)
   float* dL_dmeans2D;        // optional
   int32_t densify_stats;

@@ -400,15 +400,15 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
         // The fourth 16 bytes of the 64-byte record are padding nobody reads -- and they are written all the same (round 5):
         // a slot written 48 bytes out of 64 is a masked (read-modify-write) access at the memory side, a whole 64-byte slot
         // is not.  Same-box A/B at the headline: projection 240 -> 191 us per iteration (-20 %), 594-599 -> 610-613 iters/s,
-        // for 16 more bytes per visible Gaussian and view.  (-DB3GS_PRE_PARTIAL_RECORD restores the 48-byte store.)
+        // for 16 more bytes per visible Gaussian and view.  (A 48-byte store was `-DB3GS_PRE_PARTIAL_RECORD` until the fourth part got a use.)
         // tools/ubench/slot_store.hip, 6M slots: 48 of 64 bytes 156 us, these four 16-byte stores per lane 112 us, the
         // quarters of a quad's four records transposed across its lanes (DPP) so that every instruction writes whole lines
         // 64 us (a dense stream: 63).  The last step was built here too (64 VALU instructions per view, bit-identical
         // records) and changes nothing -- 183.4 against 184.4 us: spread over this kernel's 180 us the stores are far from
         // either rate; its time is the dependent chain per view at 5 waves per SIMD.  Not kept.
-#ifndef B3GS_PRE_PARTIAL_RECORD
-        rec[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
+        // Since round 6 its first word carries the SH clamp bits (bit c: colour channel c clamped at 0), which only the chain
+        // rule of the ~2 % touched (Gaussian, view) pairs reads: they were a 4-byte store stream of their own before.
+        rec[3] = make_float4(__uint_as_float(clamp_bits), 0.f, 0.f, 0.f);
         radius_out = (int32_t)fminf(rad_f, 2147483520.0f);
         touched = (uint32_t)area;
         rect = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16));
@@ -455,7 +455,6 @@ __global__ void __launch_bounds__(256, B3GS_PRE_WAVES) preprocess_fwd_kernel(Pre
   if (g.rect_role == 1) held_rect = rect;
   else if (g.rect_role == 2) reinterpret_cast<uint4*>(g.rect - 1)[i] = make_uint4(held_rect.x, held_rect.y, rect.x, rect.y);
   else g.rect[(size_t)i * g.rect_stride] = rect;
-  g.clamped[i] = clamp_bits;
   }
   PRE_TRACE(9, wall_clock64());
 }
@@ -781,7 +780,7 @@ __global__ void __launch_bounds__(256)
   }
 
   GaussGrad gg;
-  const uint32_t cb = g.clamped[i];
+  const uint32_t cb = __float_as_uint(reinterpret_cast<const float*>(g.rec + 4 * (size_t)i + 3)[0]);   // clamp bits: record word 12
   if (RAW) {
     ShAddMem sink{rg.features_dc + i3, rg.features_rest + (size_t)3 * (sc.M - 1) * i};
     gaussian_backward<true>(sx_, vm, pm, i, cb, in, true, true, gg, sink);
@@ -1108,7 +1107,7 @@ __global__ void __launch_bounds__(256, B3GS_ACC_WAVES)
       for (int k = 0; k < 12; k++) sink.acc[k] = 0.f;
       sink.rest = rg.features_rest + (size_t)nrest * i2;
       GaussGrad gg;
-      gaussian_backward<true>(sx_, vm, pm, i2, vr.clamped[i2], in, true, true, gg, sink);
+      gaussian_backward<true>(sx_, vm, pm, i2, __float_as_uint(vr.rec_words[16 * (size_t)i2 + 12]), in, true, true, gg, sink);
       float dsc[3];
       float4 dr;
       raw_chain(gg, dsc, dr);

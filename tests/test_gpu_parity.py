@@ -59,6 +59,9 @@ def _check_forward(d, st, out, px_tol=1e-3, flip_frac=0.0):
     np.testing.assert_array_equal(rec[vis][:, [2, 3, 4, 5]], st.conic_opacity[vis])
     np.testing.assert_array_equal(rec[vis][:, [6, 7, 8]], st.rgb[vis])
     np.testing.assert_array_equal(rec[vis, 9], st.depths[vis])
+    # word 12 of the record: the SH clamp bits the chain rule reads (bit c: colour channel c clamped at 0)
+    bits = st.clamped[:, 0].astype(np.uint32) | (st.clamped[:, 1].astype(np.uint32) << 1) | (st.clamped[:, 2].astype(np.uint32) << 2)
+    np.testing.assert_array_equal(np.ascontiguousarray(rec[:, 12]).view(np.uint32)[vis], bits[vis])
     for name, ref in (("color", st.color), ("depth", st.depth), ("alpha", st.alpha)):
         got = out[name].cpu().numpy()
         err = np.abs(got - ref) / (1 + np.abs(ref))
