@@ -22,11 +22,10 @@
 
 struct GeomView {       // sized by P
   uint32_t* header;     // [64]  header[0] = N (tile instances), header[1] = V (visible)
-  float4* rec;          // [P*4] render record: x,y,cxx,cxy | cyy,op,r,g | b,depth,ext_x,ext_y | spare
+  float4* rec;          // [P*4] render record: x,y,cxx,cxy | cyy,op,r,g | b,depth,ext_x,ext_y | SH clamp bits (bit c: channel c clamped at 0), spare x 3
   uint32_t* depth_key;  // [P]   float bits of view z, 0xFFFFFFFF when culled
   uint32_t* tiles_touched;  // [P]
   uint2* rect;          // [2P]  packed u16 (x0 | y0<<16, x1 | y1<<16); [P] used unless a partner view interleaves its own
-  uint32_t* clamped;    // [P]   bit c set: SH colour channel c clamped at 0
   uint32_t* skey[2];    // [P]   depth-sort ping/pong keys
   uint32_t* sval[2];    // [P]   depth-sort ping/pong values (Gaussian index)
   uint32_t* soffs;      // [P]   segment 1: sums of the 256-Gaussian sub-blocks of the depth order ([ceil(K1/256)] words);
@@ -126,7 +125,6 @@ static inline size_t b3gs_geom_view(char* base, int32_t P, GeomView* v) {
   t.depth_key = b3gs_carve<uint32_t>(cur, p);
   t.tiles_touched = b3gs_carve<uint32_t>(cur, p);
   t.rect = b3gs_carve<uint2>(cur, 2 * p);  // second half: the binocular partner's rects, interleaved (stride 2)
-  t.clamped = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.skey[i] = b3gs_carve<uint32_t>(cur, p);
   for (int i = 0; i < 2; i++) t.sval[i] = b3gs_carve<uint32_t>(cur, p);
   t.soffs = b3gs_carve<uint32_t>(cur, p);
@@ -241,7 +239,6 @@ struct PreOut {
   int32_t rect_stride;  // 1, or 2 when a binocular pair shares one [P][2] array (one 16-byte gather serves both views)
   int32_t rect_role;    // 0: store rect[i * rect_stride]; 1: first of a pair, the NEXT view of the batch is its partner
                         //    (keep the rect in a register); 2: second of that pair: store both as one 16-byte word
-  uint32_t* clamped;
   int32_t* radii;
   uint8_t* visible = nullptr;   // optional: radii > 0 as bytes (B3gsForwardView::visible)
   uint2* ranges;

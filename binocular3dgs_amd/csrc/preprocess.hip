@@ -1176,7 +1176,6 @@ PreOut b3gs_pre_out(const B3gsScene& sc, const GeomView& g, const ImgView& im, i
   o.rect = g.rect;
   o.rect_stride = 1;
   o.rect_role = 0;
-  o.clamped = g.clamped;
   o.radii = radii;
   o.ranges = im.ranges;
   o.ranges2 = im.ranges2;
