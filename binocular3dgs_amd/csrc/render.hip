@@ -387,10 +387,12 @@ __global__ void __launch_bounds__(256) render_fwd_repair_kernel(BlendBatch batch
   // This is the last kernel of a two-round forward: the prediction the first blend pass collected (pred_next) becomes
   // the prediction of the NEXT forward into these image buffers.  Nothing below reads either bitmap (the second pass
   // does not predict), and the next forward's projection needs pred_rows complete before its first workgroup starts.
-  if (blockIdx.x == 0) {
+  // (one workgroup per view -- the grid holds at least eight per view: the six copies were six dependent round trips of workgroup
+  // 0, most of what this launch costs when nothing is left to repair)
+  if (blockIdx.x < (unsigned)B3GS_MAX_FUSED_VIEWS) {
 #pragma unroll
     for (int k = 0; k < B3GS_MAX_FUSED_VIEWS; k++)
-      if (k < batch.n && batch.v[k].pred_next) {
+      if (k == (int)blockIdx.x && k < batch.n && batch.v[k].pred_next) {
         const BlendView& v = batch.v[k];
         unsigned long long* pr = const_cast<unsigned long long*>(v.pred_rows);
         const int nwords = v.row_words * (v.ntiles / v.grid_x);
